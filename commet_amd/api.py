@@ -1,0 +1,199 @@
+"""Python mirror of the C ABI (include/commet_hip.h): same names, same argument
+meaning, errors raised as CommetError with the library's message.  All compute
+happens in the HIP library; numpy arrays only carry host buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+
+
+class CommetError(RuntimeError):
+    pass
+
+
+def _err(lib):
+    msg = lib.commet_last_error()
+    return msg.decode() if msg else "unknown error"
+
+
+def bits_nbytes(n):
+    """bytes of a BooleanVector over n reads (boolean_vector.h:130)"""
+    return n // 8 + 1
+
+
+def _as_bits(arr, n, what):
+    if arr is None:
+        return None
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.size < bits_nbytes(n):
+        raise CommetError(f"{what}: need {bits_nbytes(n)} bytes for {n} reads, got {a.size}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """commet_ctx: device, k, t, the 4-lane Bloom filter in HBM."""
+
+    def __init__(self, k, t=2, device=0):
+        self._lib = _l.load()
+        self._h = self._lib.commet_create(int(device), int(k), int(t))
+        if not self._h:
+            raise CommetError(_err(self._lib))
+        self.k = int(k)
+        self.t = self._lib.commet_min_hits(self._h)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.commet_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CommetError(_err(self._lib))
+
+    @property
+    def max_kmer(self):
+        return int(self._lib.commet_max_kmer(self._h))
+
+    def synchronize(self):
+        self._check(self._lib.commet_synchronize(self._h))
+
+    def filter_reset(self):
+        self._check(self._lib.commet_filter_reset(self._h))
+
+    def index_reads(self, rs, first=0, count=None, select_bits=None, want_kmers=True):
+        n = rs.num_reads
+        if count is None:
+            count = n - first
+        sel = _as_bits(select_bits, n, "select_bits")
+        fed = C.c_uint64(0)
+        self._check(self._lib.commet_index_reads(self._h, rs._h, first, count, _ptr(sel),
+                                                 C.byref(fed) if want_kmers else None))
+        return int(fed.value) if want_kmers else None
+
+    def search_reads(self, rs, active_bits=None):
+        n = rs.num_reads
+        act = _as_bits(active_bits, n, "active_bits")
+        found = np.zeros(bits_nbytes(n), dtype=np.uint8)
+        scanned = C.c_uint64(0)
+        nfound = C.c_uint64(0)
+        self._check(self._lib.commet_search_reads(self._h, rs._h, _ptr(act), _ptr(found), C.byref(scanned),
+                                                  C.byref(nfound)))
+        return found, int(scanned.value), int(nfound.value)
+
+    def index_and_search(self, index_rs, search_sets, index_select=None, search_selects=None):
+        """The chunk loop on resident sets.  Returns (tags, stats, info):
+        tags[i] = BooleanVector bytes of search set i, stats[i] = dict(indexed,
+        searched, shared) — the numbers of the reference's log line."""
+        ns = len(search_sets)
+        isel = _as_bits(index_select, index_rs.num_reads, "index_select")
+        ssel = [None] * ns
+        if search_selects is not None:
+            ssel = [_as_bits(s, rs.num_reads, "search_select") for s, rs in zip(search_selects, search_sets)]
+        tags = [np.zeros(bits_nbytes(rs.num_reads), dtype=np.uint8) for rs in search_sets]
+        rs_arr = (C.c_void_p * max(ns, 1))(*[rs._h for rs in search_sets])
+        sel_arr = (C.c_void_p * max(ns, 1))(*[(_ptr(s).value if s is not None else None) for s in ssel])
+        tag_arr = (C.c_void_p * max(ns, 1))(*[_ptr(t).value for t in tags])
+        stats = (_l.PairStats * max(ns, 1))()
+        info = _l.JobInfo()
+        self._check(self._lib.commet_index_and_search(self._h, index_rs._h, _ptr(isel), ns, rs_arr, sel_arr, tag_arr,
+                                                      stats, C.byref(info)))
+        st = [dict(indexed=int(stats[i].indexed), searched=int(stats[i].searched), shared=int(stats[i].shared))
+              for i in range(ns)]
+        inf = {f: getattr(info, f) for f, _ in _l.JobInfo._fields_}
+        return tags, st, inf
+
+    def export_filter_reference(self):
+        nbytes = int(2 ** (self.k - 1))
+        out = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        self._check(self._lib.commet_filter_export_reference(self._h, _ptr(out), out.size))
+        return out[:nbytes]
+
+    def last_kernel_ms(self):
+        i = C.c_double(0)
+        s = C.c_double(0)
+        self._check(self._lib.commet_last_kernel_ms(self._h, C.byref(i), C.byref(s)))
+        return i.value, s.value
+
+    def membench(self, atomic, table_bytes, n_access):
+        ms = C.c_double(0)
+        self._check(self._lib.commet_membench(self._h, int(bool(atomic)), int(table_bytes), int(n_access), C.byref(ms)))
+        return ms.value
+
+
+class ReadSet:
+    """commet_readset: the reads of one set, packed and resident in HBM."""
+
+    def __init__(self, ctx, max_reads, max_bases):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._h = self._lib.commet_readset_create(ctx._h, int(max_reads), int(max_bases))
+        if not self._h:
+            raise CommetError(_err(self._lib))
+
+    @classmethod
+    def from_files(cls, ctx, files):
+        """files: list of (bases uint8[...], offsets uint64[n+1]) — one entry per file of the set."""
+        nr = sum(len(o) - 1 for _, o in files)
+        nb = sum(int(o[-1]) for _, o in files)
+        rs = cls(ctx, nr, nb)
+        for b, o in files:
+            rs.add_file(b, o)
+        rs.finalize()
+        return rs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.commet_readset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CommetError(_err(self._lib))
+
+    def add_file(self, bases, offsets):
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if o.size < 1 or int(o[-1]) > b.size:
+            raise CommetError("offsets do not match bases")
+        self._check(self._lib.commet_readset_begin_file(self._h))
+        self._check(self._lib.commet_readset_append(self._h, _ptr(b), _ptr(o), o.size - 1))
+
+    def finalize(self):
+        self._check(self._lib.commet_readset_finalize(self._h))
+
+    @property
+    def num_reads(self):
+        return int(self._lib.commet_readset_num_reads(self._h))
+
+    @property
+    def num_files(self):
+        return int(self._lib.commet_readset_num_files(self._h))
+
+    def kmer_counts(self):
+        out = np.zeros(max(self.num_reads, 1), dtype=np.uint32)
+        self._check(self._lib.commet_readset_kmer_counts(self._h, _ptr(out)))
+        return out[:self.num_reads]

@@ -1,0 +1,723 @@
+// capi.hip — implementation of include/commet_hip.h on HIP (gfx950).
+// Host side: context, HBM residency of read sets, pinned double-buffered
+// ingest, the chunk loop of index_and_search on resident sets.
+#include "../../include/commet_hip.h"
+
+#include "kernels.hpp"
+#include "read_iter.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace commet;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define HIP_OK_NULL(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);           \
+            return nullptr;                                                                            \
+        }                                                                                              \
+    } while (0)
+
+inline uint64_t bitmap_words(uint64_t n) { return n / 64 + 1; }
+inline uint64_t bitmap_bytes_host(uint64_t n) { return n / 8 + 1; }   // boolean_vector.h:130
+
+constexpr uint64_t STAGE_BASES = 64ull << 20;
+constexpr uint64_t STAGE_READS = 1ull << 20;
+constexpr int      N_COUNTERS = 8;
+
+}  // namespace
+
+struct commet_ctx {
+    int device = 0;
+    int k = 0, t = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *filter = nullptr;       // 4 planes, contiguous
+    uint64_t plane_words = 0;
+    uint64_t filter_bytes = 0;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;   // pinned
+    hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    bool have_index_ev = false, have_search_ev = false;
+
+    FilterView view() const
+    {
+        FilterView f;
+        f.a = filter;
+        f.b = filter + plane_words;
+        f.c = filter + 2 * plane_words;
+        f.d = filter + 3 * plane_words;
+        return f;
+    }
+};
+
+struct commet_readset {
+    commet_ctx *ctx = nullptr;
+    uint64_t max_reads = 0, max_bases = 0;
+    uint64_t n_reads = 0, n_bases = 0;
+    uint32_t *d_planes = nullptr;
+    uint64_t *d_goff = nullptr;
+    uint32_t *d_kcnt = nullptr;
+    uint32_t *d_lenmm = nullptr;
+    uint64_t *d_sel = nullptr, *d_tags = nullptr, *d_found = nullptr;   // bitmaps, bitmap_words(max_reads)
+    struct Stage {
+        uint8_t *h_bases = nullptr;
+        uint64_t *h_offs = nullptr;
+        uint8_t *d_bases = nullptr;
+        uint64_t *d_offs = nullptr;
+        hipEvent_t done = nullptr;
+        bool inflight = false;
+    } st[2];
+    int cur = 0;
+    bool acquired = false;
+    uint64_t stage_bases = 0, stage_reads = 0;
+    std::vector<FileSpan> files;
+    std::vector<uint64_t> empty_reads;
+    std::vector<uint32_t> h_kcnt;
+    uint32_t uniform_len = 0;
+    bool finalized = false;
+
+    ReadsView view() const
+    {
+        ReadsView v;
+        v.planes = d_planes;
+        v.goff = d_goff;
+        v.uniform_len = uniform_len;
+        v.n = n_reads;
+        return v;
+    }
+};
+
+extern "C" {
+
+const char *commet_version(void) { return "commet-amd 0.1 (gfx950)"; }
+const char *commet_last_error(void) { return g_err.c_str(); }
+
+int commet_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+commet_ctx *commet_create(int device, int kmer_size, int min_hits)
+{
+    if (kmer_size < 1 || kmer_size > 38) {
+        fail("k-mer size %d out of range [1,38]", kmer_size);
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail("no HIP device available: the index_and_search path has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail("device %d out of range (have %d)", device, ndev);
+        return nullptr;
+    }
+    HIP_OK_NULL(hipSetDevice(device));
+    commet_ctx *c = new commet_ctx;
+    c->device = device;
+    c->k = kmer_size;
+    c->t = min_hits < 1 ? 1 : min_hits;
+    // 2^k bits per plane, at least one word; 4 planes = 2^(k-1) bytes (bloom_filter.h:73)
+    const uint64_t plane_bits = 1ull << kmer_size;
+    c->plane_words = plane_bits < 32 ? 1 : plane_bits / 32;
+    c->filter_bytes = 4 * c->plane_words * sizeof(uint32_t);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **) &c->filter, c->filter_bytes);
+    if (e != hipSuccess) {
+        if (e == hipErrorOutOfMemory)
+            fail("Index memory allocation impossible, try with a lower k value or with more RAM memory");
+        else fail("context creation failed: %s", hipGetErrorString(e));
+        commet_destroy(c);
+        return nullptr;
+    }
+    e = hipMalloc((void **) &c->d_counters, N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **) &c->h_counters, N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_i0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_i1);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_s0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_s1);
+    if (e == hipSuccess) e = hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream);
+    if (e != hipSuccess) {
+        fail("context creation failed: %s", hipGetErrorString(e));
+        commet_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void commet_destroy(commet_ctx *c)
+{
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->filter) (void) hipFree(c->filter);
+    if (c->d_counters) (void) hipFree(c->d_counters);
+    if (c->h_counters) (void) hipHostFree(c->h_counters);
+    if (c->ev_i0) (void) hipEventDestroy(c->ev_i0);
+    if (c->ev_i1) (void) hipEventDestroy(c->ev_i1);
+    if (c->ev_s0) (void) hipEventDestroy(c->ev_s0);
+    if (c->ev_s1) (void) hipEventDestroy(c->ev_s1);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int commet_kmer_size(const commet_ctx *c) { return c->k; }
+int commet_min_hits(const commet_ctx *c) { return c->t; }
+
+uint64_t commet_max_kmer(const commet_ctx *c)
+{
+    return (uint64_t) (1000000000.0 / pow(2, 33 - c->k));   // index_and_search.cpp:73,146
+}
+
+int commet_synchronize(commet_ctx *c)
+{
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* ---- read sets ------------------------------------------------------------ */
+
+commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_t max_bases)
+{
+    if (!c) {
+        fail("null context");
+        return nullptr;
+    }
+    HIP_OK_NULL(hipSetDevice(c->device));
+    commet_readset *rs = new commet_readset;
+    rs->ctx = c;
+    rs->max_reads = max_reads;
+    rs->max_bases = max_bases;
+    rs->stage_bases = max_bases < STAGE_BASES ? (max_bases ? max_bases : 1) : STAGE_BASES;
+    rs->stage_reads = max_reads < STAGE_READS ? (max_reads ? max_reads : 1) : STAGE_READS;
+    const uint64_t triples = (max_bases >> 5) + max_reads + 1;
+    const uint64_t bw = bitmap_words(max_reads);
+    hipError_t e = hipMalloc((void **) &rs->d_planes, triples * 3 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_goff, (max_reads + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_kcnt, (max_reads + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_lenmm, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_sel, bw * 8);
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_tags, bw * 8);
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_found, bw * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void **) &rs->st[i].h_bases, rs->stage_bases);
+        if (e == hipSuccess) e = hipHostMalloc((void **) &rs->st[i].h_offs, (rs->stage_reads + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **) &rs->st[i].d_bases, rs->stage_bases);
+        if (e == hipSuccess) e = hipMalloc((void **) &rs->st[i].d_offs, (rs->stage_reads + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&rs->st[i].done, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        const uint32_t mm[2] = {0xFFFFFFFFu, 0u};
+        e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) {
+        fail("read set allocation failed (%llu reads, %llu bases): %s", (unsigned long long) max_reads,
+             (unsigned long long) max_bases, hipGetErrorString(e));
+        commet_readset_destroy(rs);
+        return nullptr;
+    }
+    return rs;
+}
+
+void commet_readset_destroy(commet_readset *rs)
+{
+    if (!rs) return;
+    (void) hipSetDevice(rs->ctx->device);
+    (void) hipStreamSynchronize(rs->ctx->stream);
+    (void) hipFree(rs->d_planes);
+    (void) hipFree(rs->d_goff);
+    (void) hipFree(rs->d_kcnt);
+    (void) hipFree(rs->d_lenmm);
+    (void) hipFree(rs->d_sel);
+    (void) hipFree(rs->d_tags);
+    (void) hipFree(rs->d_found);
+    for (int i = 0; i < 2; ++i) {
+        if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
+        if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);
+        (void) hipFree(rs->st[i].d_bases);
+        (void) hipFree(rs->st[i].d_offs);
+        if (rs->st[i].done) (void) hipEventDestroy(rs->st[i].done);
+    }
+    delete rs;
+}
+
+int commet_readset_begin_file(commet_readset *rs)
+{
+    if (rs->finalized) return fail("read set already finalized");
+    if (rs->acquired) return fail("begin_file with an uncommitted staging buffer");
+    rs->files.push_back(FileSpan{rs->n_reads, 0});
+    return 0;
+}
+
+int commet_readset_stage_acquire(commet_readset *rs, uint8_t **bases, uint64_t *bases_cap, uint64_t **offsets,
+                                 uint64_t *reads_cap)
+{
+    if (rs->finalized) return fail("read set already finalized");
+    if (rs->files.empty()) return fail("commet_readset_begin_file must be called first");
+    if (rs->acquired) return fail("staging buffer already acquired");
+    HIP_OK(hipSetDevice(rs->ctx->device));
+    commet_readset::Stage &s = rs->st[rs->cur];
+    if (s.inflight) {
+        HIP_OK(hipEventSynchronize(s.done));
+        s.inflight = false;
+    }
+    *bases = s.h_bases;
+    *bases_cap = rs->stage_bases;
+    *offsets = s.h_offs;
+    *reads_cap = rs->stage_reads;
+    rs->acquired = true;
+    return 0;
+}
+
+int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
+{
+    if (!rs->acquired) return fail("commit without acquire");
+    rs->acquired = false;
+    if (n == 0) return 0;
+    commet_readset::Stage &s = rs->st[rs->cur];
+    if (n > rs->stage_reads) return fail("too many reads in one staging batch");
+    if (s.h_offs[0] != 0) return fail("offsets[0] must be 0");
+    const uint64_t nbases = s.h_offs[n];
+    if (nbases > rs->stage_bases) return fail("staging batch overflows its base buffer");
+    if (rs->n_reads + n > rs->max_reads || rs->n_bases + nbases > rs->max_bases)
+        return fail("read set capacity exceeded (%llu reads / %llu bases reserved)", (unsigned long long) rs->max_reads,
+                    (unsigned long long) rs->max_bases);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (s.h_offs[i + 1] < s.h_offs[i]) return fail("offsets must be non-decreasing");
+        if (s.h_offs[i + 1] - s.h_offs[i] > 0x7FFFFFFFull) return fail("read longer than 2^31-1 bases");
+        if (s.h_offs[i + 1] == s.h_offs[i]) rs->empty_reads.push_back(rs->n_reads + i);
+    }
+    commet_ctx *c = rs->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    if (nbases) HIP_OK(hipMemcpyAsync(s.d_bases, s.h_bases, nbases, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(s.d_offs, s.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned) ((n + 1 + 255) / 256);
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->stream, s.d_bases, s.d_offs, n, rs->n_reads,
+                       rs->n_bases, rs->d_planes, rs->d_goff, rs->d_kcnt, rs->d_lenmm, c->k);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(s.done, c->stream));
+    s.inflight = true;
+    rs->n_reads += n;
+    rs->n_bases += nbases;
+    rs->files.back().count += n;
+    rs->cur ^= 1;
+    return 0;
+}
+
+int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    uint64_t done = 0;
+    while (done < n_reads) {
+        uint8_t *hb;
+        uint64_t *ho;
+        uint64_t bcap, rcap;
+        if (commet_readset_stage_acquire(rs, &hb, &bcap, &ho, &rcap)) return 1;
+        uint64_t take = 0;
+        const uint64_t b0 = offsets[done];
+        while (done + take < n_reads && take < rcap && offsets[done + take + 1] - b0 <= bcap) ++take;
+        if (take == 0) {
+            rs->acquired = false;
+            return fail("read %llu does not fit the staging buffer (%llu bases)", (unsigned long long) done,
+                        (unsigned long long) bcap);
+        }
+        for (uint64_t i = 0; i <= take; ++i) ho[i] = offsets[done + i] - b0;
+        memcpy(hb, bases + b0, ho[take]);
+        if (commet_readset_stage_commit(rs, take)) return 1;
+        done += take;
+    }
+    return 0;
+}
+
+int commet_readset_finalize(commet_readset *rs)
+{
+    if (rs->finalized) return 0;
+    if (rs->acquired) return fail("finalize with an uncommitted staging buffer");
+    commet_ctx *c = rs->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    rs->st[0].inflight = rs->st[1].inflight = false;
+    rs->h_kcnt.resize(rs->n_reads);
+    uint32_t mm[2] = {0, 0};
+    if (rs->n_reads) {
+        HIP_OK(hipMemcpy(rs->h_kcnt.data(), rs->d_kcnt, rs->n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
+    }
+    rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
+    // the staging buffers are no longer needed: give the memory back
+    for (int i = 0; i < 2; ++i) {
+        if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
+        if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);
+        (void) hipFree(rs->st[i].d_bases);
+        (void) hipFree(rs->st[i].d_offs);
+        rs->st[i].h_bases = nullptr;
+        rs->st[i].h_offs = nullptr;
+        rs->st[i].d_bases = nullptr;
+        rs->st[i].d_offs = nullptr;
+    }
+    rs->finalized = true;
+    return 0;
+}
+
+uint64_t commet_readset_num_reads(const commet_readset *rs) { return rs->n_reads; }
+uint64_t commet_readset_num_files(const commet_readset *rs) { return rs->files.size(); }
+
+int commet_readset_kmer_counts(const commet_readset *rs, uint32_t *out)
+{
+    if (!rs->finalized) return fail("read set not finalized");
+    if (rs->n_reads) memcpy(out, rs->h_kcnt.data(), rs->n_reads * sizeof(uint32_t));
+    return 0;
+}
+
+/* ---- kernels -------------------------------------------------------------- */
+
+int commet_filter_reset(commet_ctx *c)
+{
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// uploads a host bit array (n/8+1 bytes) into a device bitmap of bitmap_words(n) words
+int upload_bits(commet_ctx *c, uint64_t *d_bits, const uint8_t *h_bits, uint64_t n)
+{
+    HIP_OK(hipMemsetAsync(d_bits, 0, bitmap_words(n) * 8, c->stream));
+    HIP_OK(hipMemcpyAsync(d_bits, h_bits, bitmap_bytes_host(n), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                 unsigned long long *d_fed)
+{
+    if (count == 0) return 0;
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return fail("index launch too large");
+    if (c->k <= 32)
+        hipLaunchKernelGGL(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, first, count, d_sel, d_fed);
+    else
+        hipLaunchKernelGGL(index_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, first, count, d_sel, d_fed);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
+                  unsigned long long *d_counters)
+{
+    if (rs->n_reads == 0) return 0;
+    const uint64_t blocks = (rs->n_reads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return fail("search launch too large");
+    if (c->k <= 32)
+        hipLaunchKernelGGL(search_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, c->t, d_sel, d_tags, d_found, d_counters);
+    else
+        hipLaunchKernelGGL(search_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, c->t, d_sel, d_tags, d_found, d_counters);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int commet_index_reads(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count,
+                       const uint8_t *select_bits, uint64_t *kmers_fed)
+{
+    if (!rs->finalized) return fail("read set not finalized");
+    if (rs->ctx != c) return fail("read set belongs to another context");
+    if (first > rs->n_reads || count > rs->n_reads - first) return fail("index range out of bounds");
+    HIP_OK(hipSetDevice(c->device));
+    const uint64_t *d_sel = nullptr;
+    if (select_bits) {
+        if (upload_bits(c, rs->d_sel, select_bits, rs->n_reads)) return 1;
+        d_sel = rs->d_sel;
+    }
+    unsigned long long *d_fed = nullptr;
+    if (kmers_fed) {
+        HIP_OK(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
+        d_fed = c->d_counters;
+    }
+    HIP_OK(hipEventRecord(c->ev_i0, c->stream));
+    if (launch_index(c, rs, first, count, d_sel, d_fed)) return 1;
+    HIP_OK(hipEventRecord(c->ev_i1, c->stream));
+    c->have_index_ev = true;
+    if (kmers_fed) {
+        HIP_OK(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        *kmers_fed = c->h_counters[0];
+    }
+    return 0;
+}
+
+int commet_search_reads(commet_ctx *c, const commet_readset *rs, const uint8_t *active_bits, uint8_t *found_bits,
+                        uint64_t *n_scanned, uint64_t *n_found)
+{
+    if (!rs->finalized) return fail("read set not finalized");
+    if (rs->ctx != c) return fail("read set belongs to another context");
+    HIP_OK(hipSetDevice(c->device));
+    const uint64_t *d_sel = nullptr;
+    if (active_bits) {
+        if (upload_bits(c, rs->d_sel, active_bits, rs->n_reads)) return 1;
+        d_sel = rs->d_sel;
+    }
+    HIP_OK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_OK(hipMemsetAsync(rs->d_found, 0, bitmap_words(rs->n_reads) * 8, c->stream));
+    HIP_OK(hipEventRecord(c->ev_s0, c->stream));
+    if (launch_search(c, rs, d_sel, nullptr, rs->d_found, c->d_counters)) return 1;
+    HIP_OK(hipEventRecord(c->ev_s1, c->stream));
+    c->have_search_ev = true;
+    HIP_OK(hipMemcpyAsync(c->h_counters, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (found_bits)
+        HIP_OK(hipMemcpyAsync(found_bits, rs->d_found, bitmap_bytes_host(rs->n_reads), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (n_scanned) *n_scanned = c->h_counters[0];
+    if (n_found) *n_found = c->h_counters[1];
+    return 0;
+}
+
+/* ---- the chunk loop (index_and_search.cpp:241-277) ------------------------ */
+
+int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const uint8_t *index_select, int n_search,
+                            const commet_readset *const *search_rs, const uint8_t *const *search_select,
+                            uint8_t *const *tags_out, commet_pair_stats *stats, commet_job_info *info)
+{
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (!index_rs->finalized) return fail("index read set not finalized");
+    if (index_rs->ctx != c) return fail("index read set belongs to another context");
+    for (int s = 0; s < n_search; ++s) {
+        if (!search_rs[s]->finalized) return fail("search read set %d not finalized", s);
+        if (search_rs[s]->ctx != c) return fail("search read set %d belongs to another context", s);
+        if (search_rs[s] == index_rs) return fail("a set cannot be searched against itself in one call");
+        for (int q = 0; q < s; ++q)
+            if (search_rs[q] == search_rs[s]) return fail("search read set listed twice");
+    }
+    HIP_OK(hipSetDevice(c->device));
+
+    // host plan: chunks of the index set, visited reads of each search set
+    const IndexPlan plan = plan_index(index_rs->files, index_select, index_rs->empty_reads, index_rs->h_kcnt.data(),
+                                      index_rs->n_reads, commet_max_kmer(c));
+    std::vector<uint64_t> visited(n_search, 0);
+    std::vector<std::vector<uint8_t>> vis(n_search);
+    if (upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
+    for (int s = 0; s < n_search; ++s) {
+        const commet_readset *rs = search_rs[s];
+        vis[s] = plan_search(rs->files, search_select ? search_select[s] : nullptr, rs->empty_reads, rs->n_reads, &visited[s]);
+        if (upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
+        HIP_OK(hipMemsetAsync(rs->d_tags, 0, bitmap_words(rs->n_reads) * 8, c->stream));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));   // the host bit arrays above are pageable
+
+    // per (chunk, set) counters {scanned, found}
+    const uint64_t n_chunks = plan.chunks.size();
+    const uint64_t n_cnt = 2 * n_chunks * (uint64_t) n_search;
+    unsigned long long *d_cnt = nullptr;
+    std::vector<unsigned long long> h_cnt(n_cnt ? n_cnt : 1, 0);
+    if (n_cnt) {
+        HIP_OK(hipMalloc((void **) &d_cnt, n_cnt * sizeof(unsigned long long)));
+        HIP_OK(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(unsigned long long), c->stream));
+    }
+
+    // device timing: one event pair around all index work and one around all
+    // search work would overlap; instead accumulate per phase with event pairs
+    // on the (in-order) stream.
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&](hipEvent_t *e) -> int {
+        HIP_OK(hipEventCreate(e));
+        evs.push_back(*e);
+        return 0;
+    };
+    const bool timed = info != nullptr && n_chunks <= 4096;
+    std::vector<hipEvent_t> e_idx0, e_idx1, e_srch1;
+
+    int rc = 0;
+    for (uint64_t ci = 0; ci < n_chunks && !rc; ++ci) {
+        const Chunk &ch = plan.chunks[ci];
+        hipEvent_t a = nullptr, b = nullptr, d = nullptr;
+        if (timed) {
+            if (new_event(&a) || new_event(&b) || new_event(&d)) { rc = 1; break; }
+            (void) hipEventRecord(a, c->stream);
+        }
+        if (commet_filter_reset(c)) { rc = 1; break; }                       // new BloomFilter per chunk
+        if (ch.n_reads)
+            if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr)) { rc = 1; break; }
+        if (timed) (void) hipEventRecord(b, c->stream);
+        for (int s = 0; s < n_search; ++s) {
+            const commet_readset *rs = search_rs[s];
+            if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, d_cnt + 2 * (ci * n_search + s))) { rc = 1; break; }
+        }
+        if (timed) {
+            (void) hipEventRecord(d, c->stream);
+            e_idx0.push_back(a);
+            e_idx1.push_back(b);
+            e_srch1.push_back(d);
+        }
+    }
+    if (!rc && n_cnt)
+        if (hipMemcpyAsync(h_cnt.data(), d_cnt, n_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = fail("counter copy failed");
+    for (int s = 0; s < n_search && !rc; ++s) {
+        const commet_readset *rs = search_rs[s];
+        if (tags_out && tags_out[s])
+            if (hipMemcpyAsync(tags_out[s], rs->d_tags, bitmap_bytes_host(rs->n_reads), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+                rc = fail("tag copy failed");
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+
+    if (!rc) {
+        uint64_t scans = 0;
+        for (int s = 0; s < n_search; ++s) {
+            uint64_t shared = 0, last_scanned = 0;
+            for (uint64_t ci = 0; ci < n_chunks; ++ci) {
+                const unsigned long long *p = &h_cnt[2 * (ci * n_search + s)];
+                // an empty search set launches nothing: scanned = visited - found so far
+                last_scanned = visited[s] - shared;
+                scans += last_scanned;
+                if (search_rs[s]->n_reads && p[0] != last_scanned)
+                    rc = fail("internal error: device scanned %llu reads, host plan says %llu (chunk %llu, set %d)",
+                              p[0], (unsigned long long) last_scanned, (unsigned long long) ci, s);
+                shared += p[1];
+            }
+            if (stats) {
+                stats[s].indexed = plan.indexed_reads;
+                stats[s].searched = n_chunks ? last_scanned : 0;
+                stats[s].shared = shared;
+            }
+        }
+        if (info) {
+            info->n_chunks = n_chunks;
+            info->kmers_indexed = plan.kmers;
+            info->reads_scanned = scans;
+            info->index_ms = info->search_ms = 0;
+            if (timed) {
+                for (size_t i = 0; i < e_idx0.size(); ++i) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, e_idx0[i], e_idx1[i]) == hipSuccess) info->index_ms += ms;
+                    if (hipEventElapsedTime(&ms, e_idx1[i], e_srch1[i]) == hipSuccess) info->search_ms += ms;
+                }
+            }
+        }
+    }
+    for (hipEvent_t e : evs) (void) hipEventDestroy(e);
+    if (d_cnt) (void) hipFree(d_cnt);
+    if (info && !rc)
+        info->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return rc;
+}
+
+/* ---- hooks ---------------------------------------------------------------- */
+
+int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_bytes)
+{
+    const uint64_t nbytes = (uint64_t) pow(2, c->k - 1);   // bloom_filter.h:73
+    if (out_bytes < nbytes) return fail("export buffer too small");
+    if (nbytes == 0) return 0;
+    HIP_OK(hipSetDevice(c->device));
+    uint8_t *d_out = nullptr;
+    HIP_OK(hipMalloc((void **) &d_out, nbytes));
+    const uint64_t blocks = (nbytes + 255) / 256;
+    hipLaunchKernelGGL(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), nbytes, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void) hipFree(d_out);
+    if (e != hipSuccess) return fail("filter export failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int commet_last_kernel_ms(commet_ctx *c, double *index_ms, double *search_ms)
+{
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    if (index_ms) {
+        *index_ms = 0;
+        if (c->have_index_ev) {
+            HIP_OK(hipEventElapsedTime(&ms, c->ev_i0, c->ev_i1));
+            *index_ms = ms;
+        }
+    }
+    if (search_ms) {
+        *search_ms = 0;
+        if (c->have_search_ev) {
+            HIP_OK(hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1));
+            *search_ms = ms;
+        }
+    }
+    return 0;
+}
+
+int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms_out)
+{
+    HIP_OK(hipSetDevice(c->device));
+    uint64_t words = 1;
+    while (words * 2 * 4 <= table_bytes) words *= 2;   // power of two words
+    uint32_t *table = nullptr, *sink = nullptr;
+    HIP_OK(hipMalloc((void **) &table, words * 4));
+    HIP_OK(hipMalloc((void **) &sink, 4));
+    HIP_OK(hipMemsetAsync(table, 0, words * 4, c->stream));
+    const uint64_t threads = 256ull * 256 * 32;   // 32 blocks of 256 per CU
+    const uint32_t iters = (uint32_t) std::max<uint64_t>(1, n_access / threads);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {   // rep 0 warms up
+        HIP_OK(hipEventRecord(e0, c->stream));
+        if (atomic)
+            hipLaunchKernelGGL(membench_kernel<true>, dim3((unsigned) (threads / 256)), dim3(256), 0, c->stream, table,
+                               words - 1, iters, sink);
+        else
+            hipLaunchKernelGGL(membench_kernel<false>, dim3((unsigned) (threads / 256)), dim3(256), 0, c->stream, table,
+                               words - 1, iters, sink);
+        HIP_OK(hipEventRecord(e1, c->stream));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / ((double) iters * threads) * (double) n_access;   // scaled to n_access
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) hipFree(table);
+    (void) hipFree(sink);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// kernels.hpp — CDNA4 (gfx950) device code of the index_and_search hot path.
+//
+// Data layout in HBM:
+//   reads   : per read, ceil(len/32) word-triples {hi, lo, valid}; bit j of a
+//             word = base 32*w+j.  hi = 1 for G/T, lo = 1 for C/T, valid = 1
+//             for ACGTacgt.  Read r starts at triple index (goff[r] >> 5) + r,
+//             goff = cumulative base offsets (n+1 entries).
+//   filter  : four bit-planes A,B,C,D of 2^k bits each (plane p at words
+//             [p*plane_words, (p+1)*plane_words)), bit `key` of plane X =
+//             lane X of the reference filter at that key.
+//   bitmaps : 64 reads per uint64 word, LSB-first (== BooleanVector bytes).
+//
+// Hash structure used everywhere below (hash_key.h:63-123):
+//   with the window W_x of plane x held LSB = oldest base of the k-mer,
+//     forward  keya = bitreverse_k(W_hi), keyb = bitreverse_k(W_lo)
+//     reverse  keya = ~W_hi & mask,       keyb = ~W_lo & mask
+//     keyc = keya ^ keyb, keyd = keya | keyb   (both strands)
+//   so one left-to-right rolling window serves both strands.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace commet {
+
+struct ReadsView {
+    const uint32_t *planes;      // word triples
+    const uint64_t *goff;        // n+1 cumulative base offsets (unused when uniform_len != 0)
+    uint32_t        uniform_len; // != 0: every read has this length, goff[r] = r * uniform_len
+    uint64_t        n;
+};
+
+struct FilterView {
+    uint32_t *a, *b, *c, *d;     // bit-planes, 2^k bits each
+};
+
+template <typename W> struct KeyTraits;
+template <> struct KeyTraits<uint32_t> {
+    static constexpr int BITS = 32;
+    __device__ static __forceinline__ uint32_t brev(uint32_t x) { return __brev(x); }
+};
+template <> struct KeyTraits<uint64_t> {
+    static constexpr int BITS = 64;
+    __device__ static __forceinline__ uint64_t brev(uint64_t x) { return __brevll(x); }
+};
+
+__device__ __forceinline__ void read_extent(const ReadsView &rv, uint64_t r, uint64_t &triple0, uint32_t &len)
+{
+    uint64_t o;
+    if (rv.uniform_len) {
+        o = r * (uint64_t) rv.uniform_len;
+        len = rv.uniform_len;
+    } else {
+        o = rv.goff[r];
+        len = (uint32_t) (rv.goff[r + 1] - o);
+    }
+    triple0 = (o >> 5) + r;
+}
+
+template <typename W>
+__device__ __forceinline__ uint32_t test_bit(const uint32_t *plane, W key)
+{
+    return (plane[key >> 5] >> ((uint32_t) key & 31u)) & 1u;
+}
+
+template <typename W>
+__device__ __forceinline__ void set_bit(uint32_t *plane, W key)
+{
+    // result unused -> global_atomic_or without return, executed at L2
+    (void) __hip_atomic_fetch_or(plane + (key >> 5), 1u << ((uint32_t) key & 31u), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------
+// pack: ASCII -> {hi, lo, valid} planes, per-read complete-k-mer counts.
+// One lane per read.  Replaces the per-char work of Alphabet::is_in
+// (alphabet.h:44-58) and HashKey::add's base classes (hash_key.h:72-88).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restrict__ bases,
+                                                         const uint64_t *__restrict__ offs, uint64_t n_batch,
+                                                         uint64_t read0, uint64_t base0,
+                                                         uint32_t *__restrict__ planes, uint64_t *__restrict__ goff,
+                                                         uint32_t *__restrict__ kcnt, uint32_t *__restrict__ len_minmax,
+                                                         int k)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i > n_batch) return;
+    const uint64_t o = offs[i];
+    goff[read0 + i] = base0 + o;             // entry n_batch closes the batch
+    if (i == n_batch) return;
+    const uint32_t len = (uint32_t) (offs[i + 1] - o);
+    const uint8_t *s = bases + o;
+    uint32_t *dst = planes + 3 * (((base0 + o) >> 5) + read0 + i);
+    uint32_t run = 0, cnt = 0;
+    for (uint32_t w = 0; w * 32u < len; ++w) {
+        uint32_t hi = 0, lo = 0, va = 0;
+        const uint32_t nb = min(32u, len - w * 32u);
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t ch = s[w * 32u + j];
+            const uint32_t u = ch & 0xDFu;   // fold case
+            const uint32_t v = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+            const uint32_t h = (ch >> 2) & 1u;                 // G/T
+            const uint32_t l = ((ch >> 1) ^ (ch >> 2)) & 1u;   // C/T
+            hi |= (v & h) << j;
+            lo |= (v & l) << j;
+            va |= v << j;
+            run = v ? run + 1 : 0;
+            cnt += (run >= (uint32_t) k);
+        }
+        dst[3 * w + 0] = hi;
+        dst[3 * w + 1] = lo;
+        dst[3 * w + 2] = va;
+    }
+    kcnt[read0 + i] = cnt;
+    atomicMin(&len_minmax[0], len);
+    atomicMax(&len_minmax[1], len);
+}
+
+// ---------------------------------------------------------------------------
+// index: one lane per read, rolling forward keys, 4 atomic ORs per k-mer.
+// Replaces index_reads.h:51-59 + BloomFilter::feed (bloom_filter.h:112-118).
+// ---------------------------------------------------------------------------
+template <typename W>
+__global__ __launch_bounds__(256) void index_kernel(ReadsView rv, FilterView f, int k, uint64_t first, uint64_t count,
+                                                    const uint64_t *__restrict__ sel,
+                                                    unsigned long long *__restrict__ kmers_fed)
+{
+    using T = KeyTraits<W>;
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t r = first + i;
+    bool act = i < count;
+    if (act && sel) act = (sel[r >> 6] >> (r & 63)) & 1ull;
+    uint32_t fed = 0;
+    if (act) {
+        uint64_t t0;
+        uint32_t len;
+        read_extent(rv, r, t0, len);
+        const uint32_t *p = rv.planes + 3 * t0;
+        W wh = 0, wl = 0;
+        uint32_t run = 0;
+        const int sh = T::BITS - k;
+        for (uint32_t w = 0; w * 32u < len; ++w) {
+            const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
+            const uint32_t nb = min(32u, len - w * 32u);
+            for (uint32_t j = 0; j < nb; ++j) {
+                wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
+                run = ((va >> j) & 1u) ? run + 1 : 0;
+                if (run >= (uint32_t) k) {
+                    const W ka = T::brev(wh) >> sh;
+                    const W kb = T::brev(wl) >> sh;
+                    set_bit<W>(f.a, ka);
+                    set_bit<W>(f.b, kb);
+                    set_bit<W>(f.c, ka ^ kb);
+                    set_bit<W>(f.d, ka | kb);
+                    ++fed;
+                }
+            }
+        }
+    }
+    if (kmers_fed) {
+        // wave reduction, one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) fed += __shfl_down(fed, o, 64);
+        if ((threadIdx.x & 63) == 0 && fed) atomicAdd(kmers_fed, (unsigned long long) fed);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// search: one lane per read, exact reference control flow per lane:
+// forward scan, greedy non-overlapping hits, stop at t; reverse scan only if
+// the forward one failed (search_reads.h:45-83); 4-lane probe short-circuits
+// a -> b -> c -> d (bloom_filter.h:124-131).  64 found flags leave the wave as
+// one __ballot word = 8 bytes of the BooleanVector.
+// ---------------------------------------------------------------------------
+template <typename W>
+__global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f, int k, int t,
+                                                     const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
+                                                     uint64_t *__restrict__ found_out,
+                                                     unsigned long long *__restrict__ counters)
+{
+    using T = KeyTraits<W>;
+    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t word = r >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = (word << 6) < rv.n;
+    uint64_t selw = ~0ull, tagw = 0;
+    if (in_range) {
+        if (sel) selw = sel[word];
+        if (tags) tagw = tags[word];
+    }
+    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    bool found = false;
+    if (active) {
+        uint64_t t0;
+        uint32_t len;
+        read_extent(rv, r, t0, len);
+        const uint32_t *p = rv.planes + 3 * t0;
+        const int sh = T::BITS - k;
+        const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+        for (int strand = 0; strand < 2 && !found; ++strand) {
+            W wh = 0, wl = 0;
+            uint32_t run = 0;
+            int seen = 0;
+            for (uint32_t w = 0; w * 32u < len && !found; ++w) {
+                const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
+                const uint32_t nb = min(32u, len - w * 32u);
+                for (uint32_t j = 0; j < nb && !found; ++j) {
+                    wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                    wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
+                    run = ((va >> j) & 1u) ? run + 1 : 0;
+                    if (run >= (uint32_t) k) {
+                        W ka, kb;
+                        if (strand == 0) {
+                            ka = T::brev(wh) >> sh;
+                            kb = T::brev(wl) >> sh;
+                        } else {
+                            ka = ~wh & mask;
+                            kb = ~wl & mask;
+                        }
+                        if (test_bit<W>(f.a, ka) && test_bit<W>(f.b, kb) && test_bit<W>(f.c, ka ^ kb) &&
+                            test_bit<W>(f.d, ka | kb)) {
+                            ++seen;
+                            run = 0;                       // hash.clear(), search_reads.h:60
+                            if (seen >= t) found = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const uint64_t fb = __ballot(found);
+    const uint64_t ab = __ballot(active);
+    if (lane == 0 && in_range) {
+        if (tags) tags[word] = tagw | fb;
+        if (found_out) found_out[word] = fb;
+        if (counters) {
+            if (ab) atomicAdd(&counters[0], (unsigned long long) __popcll(ab));
+            if (fb) atomicAdd(&counters[1], (unsigned long long) __popcll(fb));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// filter -> reference byte layout (bloom_filter.h:63-70,114-117); tests only.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void export_reference_kernel(FilterView f, uint64_t nbytes, uint8_t *__restrict__ out)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= nbytes) return;
+    const uint64_t k0 = 2 * i, k1 = 2 * i + 1;
+    uint32_t b = 0;
+    b |= test_bit<uint64_t>(f.a, k0) << 7;
+    b |= test_bit<uint64_t>(f.b, k0) << 6;
+    b |= test_bit<uint64_t>(f.c, k0) << 5;
+    b |= test_bit<uint64_t>(f.d, k0) << 4;
+    b |= test_bit<uint64_t>(f.a, k1) << 3;
+    b |= test_bit<uint64_t>(f.b, k1) << 2;
+    b |= test_bit<uint64_t>(f.c, k1) << 1;
+    b |= test_bit<uint64_t>(f.d, k1);
+    out[i] = (uint8_t) b;
+}
+
+// ---------------------------------------------------------------------------
+// random-access microbenchmarks (practical ceilings)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <bool ATOMIC>
+__global__ __launch_bounds__(256) void membench_kernel(uint32_t *__restrict__ table, uint64_t word_mask, uint32_t iters,
+                                                       uint32_t *__restrict__ sink)
+{
+    const uint64_t tid = blockIdx.x * 256ull + threadIdx.x;
+    uint32_t acc = 0;
+    uint64_t s = tid * 0x100000001B3ull + 12345;
+    for (uint32_t i = 0; i < iters; ++i) {
+        s = splitmix64(s);
+        const uint64_t idx = s & word_mask;
+        if (ATOMIC) (void) __hip_atomic_fetch_or(table + idx, 1u << (s >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else acc ^= table[idx];
+    }
+    if (!ATOMIC && acc == 0x12345678u) sink[0] = acc;   // keep the loads alive
+}
+
+}  // namespace commet

@@ -1,0 +1,194 @@
+// read_iter.hpp — host-side restatement of the reference's read iteration rules,
+// turned from a pull iterator into a *plan* over resident reads.
+//
+// The reference walks a set through FileManager::get_next_read_to_compare()
+// (include/file_manager.h:88-112) on top of FastaFile::get_next_read()
+// (include/fasta_file.h:132-183).  Which reads come out, in which order, where
+// a pass stops, and how many fetches are counted decide
+//   - the reads of every index chunk, incl. the look-ahead read that is
+//     dropped when a chunk fills (index_reads.h:49,60)            [SURVEY Q1-Q3]
+//   - which reads a search pass scans (a set stops at a file with no selected
+//     read, file_manager.h:90-98)                                  [SURVEY Q6]
+//   - the loop condition of main() (index_and_search.cpp:255)     [SURVEY Q2]
+// The classes below keep the same counters (current_read_pos, first_read,
+// _cnt_valid_reads, current_file, nb_seen_reads) but run over read *numbers*.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace commet {
+
+struct FileSpan {
+    uint64_t first;   // set-wide number of the file's first read
+    uint64_t count;   // reads in the file (selected or not)
+};
+
+inline bool bit_at(const uint8_t *bits, uint64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
+inline void bit_on(uint8_t *bits, uint64_t i) { bits[i >> 3] |= (uint8_t) (1u << (i & 7)); }
+
+// One file: FastaFile's iterator state (fasta_file.h:132-183, 258-264).
+struct FileCursor {
+    FileSpan span{0, 0};
+    uint64_t nb_valid = 0;    // _nb_valid_reads = popcount of the input filter
+    uint64_t cnt_valid = 0;   // _cnt_valid_reads
+    uint64_t pos = 0;         // current_read_pos
+    bool     first_read = true;
+
+    void rewind()
+    {
+        cnt_valid = 0;
+        pos = 0;
+        first_read = true;
+    }
+};
+
+class SetIterator {
+public:
+    static constexpr uint64_t NONE = ~0ull;   // the empty-string sentinel
+
+    // select: set-wide input-filter bits (nullptr = all ones); empty_reads:
+    // sorted set-wide numbers of reads whose sequence is empty.
+    SetIterator(const std::vector<FileSpan> &files, const uint8_t *select, const std::vector<uint64_t> &empty_reads)
+        : select_(select), empty_(empty_reads)
+    {
+        for (const FileSpan &s : files) {
+            FileCursor c;
+            c.span = s;
+            if (!select) c.nb_valid = s.count;
+            else {
+                uint64_t n = 0;
+                for (uint64_t i = 0; i < s.count; ++i) n += bit_at(select, s.first + i);
+                c.nb_valid = n;
+            }
+            files_.push_back(c);
+        }
+        current_file_ = files_.empty() ? -1 : 0;
+    }
+
+    uint64_t total_valid() const   // FileManager::get_total_nb_reads, file_manager.h:268-274
+    {
+        uint64_t s = 0;
+        for (const FileCursor &c : files_) s += c.nb_valid;
+        return s;
+    }
+    uint64_t seen() const { return nb_seen_; }
+
+    void rewind()   // file_manager.h:223-229
+    {
+        current_file_ = 0;
+        nb_seen_ = 0;
+        for (FileCursor &c : files_) c.rewind();
+    }
+
+    // get_next_read_to_compare with an all-false tag vector (tagged reads are
+    // skipped later on the device; skipping never changes which of the other
+    // reads are produced).  Returns a set-wide read number or NONE.
+    uint64_t next()
+    {
+        const int nfiles = (int) files_.size();
+        if (current_file_ < 0 || current_file_ >= nfiles) {   // reference: out-of-range access (UB)
+            ++nb_seen_;
+            return NONE;
+        }
+        uint64_t r = file_next(files_[current_file_]);
+        if (r == NONE) {
+            ++current_file_;
+            if (current_file_ >= nfiles) {
+                ++nb_seen_;
+                return file_next(files_[current_file_ - 1]);   // file_manager.h:94-95
+            }
+            r = file_next(files_[current_file_]);
+        }
+        ++nb_seen_;
+        return r;
+    }
+
+private:
+    bool is_empty_read(uint64_t r) const { return std::binary_search(empty_.begin(), empty_.end(), r); }
+
+    // FastaFile::get_next_read
+    uint64_t file_next(FileCursor &c)
+    {
+        if (c.first_read) c.first_read = false;
+        else ++c.pos;
+        if (c.cnt_valid < c.nb_valid) {
+            if (select_) {
+                while (c.pos < c.span.count && !bit_at(select_, c.span.first + c.pos)) ++c.pos;   // :143-152
+            }
+            if (c.pos < c.span.count) {
+                const uint64_t r = c.span.first + c.pos;
+                if (!empty_.empty() && is_empty_read(r)) return NONE;   // empty sequence == EOF sentinel (:178-182)
+                ++c.cnt_valid;
+                return r;
+            }
+        }
+        return NONE;
+    }
+
+    std::vector<FileCursor> files_;
+    const uint8_t *select_;
+    const std::vector<uint64_t> &empty_;
+    int current_file_ = -1;
+    uint64_t nb_seen_ = 0;
+};
+
+struct Chunk {
+    uint64_t first = 0, last = 0;   // inclusive range of set-wide read numbers (valid when n_reads > 0)
+    uint64_t n_reads = 0;
+    uint64_t kmers = 0;
+};
+
+struct IndexPlan {
+    std::vector<Chunk>   chunks;
+    std::vector<uint8_t> indexed_bits;   // reads actually fed to a filter (selected, not dropped)
+    uint64_t             indexed_reads = 0;
+    uint64_t             kmers = 0;
+};
+
+// The chunk loop of main() (index_and_search.cpp:255-263) + index_reads
+// (index_reads.h:41-63) run over read numbers and per-read k-mer counts.
+inline IndexPlan plan_index(const std::vector<FileSpan> &files, const uint8_t *select,
+                            const std::vector<uint64_t> &empty_reads, const uint32_t *kcnt, uint64_t n_reads,
+                            uint64_t max_kmer)
+{
+    IndexPlan plan;
+    plan.indexed_bits.assign(n_reads / 8 + 1, 0);
+    SetIterator it(files, select, empty_reads);
+    const uint64_t to_index = it.total_valid();
+    while (it.seen() < to_index) {
+        Chunk ch;
+        uint64_t r = it.next();
+        while (r != SetIterator::NONE && ch.kmers < max_kmer) {
+            if (ch.n_reads == 0) ch.first = r;
+            ch.last = r;
+            ++ch.n_reads;
+            ch.kmers += kcnt[r];
+            bit_on(plan.indexed_bits.data(), r);
+            r = it.next();   // look-ahead fetch; dropped if the chunk is full
+        }
+        plan.indexed_reads += ch.n_reads;
+        plan.kmers += ch.kmers;
+        plan.chunks.push_back(ch);
+    }
+    return plan;
+}
+
+// Reads a search pass visits when nothing is tagged yet (search_reads.h:41-86).
+inline std::vector<uint8_t> plan_search(const std::vector<FileSpan> &files, const uint8_t *select,
+                                        const std::vector<uint64_t> &empty_reads, uint64_t n_reads, uint64_t *n_visited)
+{
+    std::vector<uint8_t> bits(n_reads / 8 + 1, 0);
+    SetIterator it(files, select, empty_reads);
+    it.rewind();
+    uint64_t n = 0;
+    for (uint64_t r = it.next(); r != SetIterator::NONE; r = it.next()) {
+        bit_on(bits.data(), r);
+        ++n;
+    }
+    if (n_visited) *n_visited = n;
+    return bits;
+}
+
+}  // namespace commet

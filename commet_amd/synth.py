@@ -1,0 +1,65 @@
+"""Synthetic read sets of SURVEY §8d, regenerated identically on every box.
+
+Set s uses numpy.random.default_rng(seed_base + s).  Reads are uniform i.i.d.
+over ACGT, fixed length L.  For s > 0 the first `copy_frac` of the reads are
+copies of the same-index reads of set 0 with `sub_rate` per-base substitutions,
+every `rc_every`-th copied read reverse-complemented.  `n_rate` of all bases
+become 'N'.  Substitution and N positions are drawn as (count ~ Binomial,
+positions uniform with replacement) so the generator stays O(output) in memory.
+"""
+import numpy as np
+
+# byte -> ASCII base of its low two bits (A,C,G,T = 0,1,2,3)
+_FOLD = bytes(b"ACGT"[i & 3] for i in range(256))
+
+
+def _raw(seed, n_bytes):
+    """n_bytes of the PCG64 byte stream of `seed` (a prefix of any longer request)."""
+    rng = np.random.default_rng(seed)
+    return rng, bytearray(rng.bytes(n_bytes))
+
+
+def synth_set(set_id, n_reads, read_len, seed_base=1000, copy_frac=0.25, sub_rate=0.01, rc_every=20, n_rate=0.001):
+    """Returns (bases uint8[n*L] ASCII, offsets uint64[n+1]).  Base code = random byte & 3."""
+    total = n_reads * read_len
+    rng, raw = _raw(seed_base + set_id, total)
+    codes = np.frombuffer(raw, dtype=np.uint8)          # writable view
+    if set_id > 0 and copy_frac > 0:
+        ncopy = int(n_reads * copy_frac)
+        if ncopy:
+            _, raw0 = _raw(seed_base, ncopy * read_len)  # set 0's first ncopy reads
+            cp = np.frombuffer(raw0, dtype=np.uint8).reshape(ncopy, read_len)
+            nsub = int(rng.binomial(ncopy * read_len, sub_rate))
+            pos = rng.integers(0, ncopy * read_len, size=nsub)
+            delta = rng.integers(1, 4, size=nsub).astype(np.uint8)
+            flat = cp.reshape(-1)
+            flat[pos] = (flat[pos] + delta) & 3
+            if rc_every:
+                idx = np.arange(0, ncopy, rc_every)
+                cp[idx] = 3 - (cp[idx, ::-1] & 3)        # A<->T, C<->G
+            codes[:ncopy * read_len] = flat
+            del cp, flat, raw0
+    del codes
+    bases = np.frombuffer(raw.translate(_FOLD), dtype=np.uint8)
+    del raw
+    nn = int(rng.binomial(total, n_rate)) if n_rate > 0 else 0
+    if nn:
+        bases[rng.integers(0, total, size=nn)] = ord("N")
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+    return bases, offsets
+
+
+def write_fasta(path, bases, offsets, width=0, lowercase_every=0):
+    """Header '>i', one sequence line (or `width`-column lines)."""
+    b = np.asarray(bases, dtype=np.uint8).tobytes()
+    with open(path, "wb") as fh:
+        for i in range(len(offsets) - 1):
+            s = b[int(offsets[i]):int(offsets[i + 1])]
+            if lowercase_every and i % lowercase_every == 0:
+                s = s.lower()
+            fh.write(b">%d\n" % i)
+            if width and len(s) > width:
+                for j in range(0, len(s), width):
+                    fh.write(s[j:j + width] + b"\n")
+            else:
+                fh.write(s + b"\n")

@@ -1,0 +1,161 @@
+/*
+ * commet_hip.h — C ABI of the MI355X-native index_and_search hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * The reference (pierrepeterlongo/commet) has no FFI for this path: its
+ * boundary is the two free functions
+ *     BloomFilter * index_reads (FileManager*, k, min_hits, max_kmer, &nb_indexed_reads)   include/index_reads.h:41
+ *     unsigned long search_reads(const BloomFilter*, FileManager*, k, min_hits, &nb_searched) include/search_reads.h:34
+ * plus the chunk loop of main() (src/index_and_search.cpp:241-277).  Those are
+ * pull-based on a std::string iterator, which a device path cannot use, so the
+ * entry points below are the batch-based equivalents.  Each
+ * declaration cites the reference interface it replaces.  INTEGRATION.md shows
+ * the binding a Commet maintainer would add in src/index_and_search.cpp.
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success, non-zero on error;
+ *     commet_last_error() then gives a message (thread-local).
+ *   - bit arrays are LSB-first per byte, exactly BooleanVector's layout
+ *     (include/boolean_vector.h:73-80, 222-233): read i = byte i/8, mask 1<<(i%8).
+ *     A bit array over n reads has n/8+1 bytes (boolean_vector.h:130).
+ *   - one ctx per (device, stream); calls on one ctx are serialised by the
+ *     caller; several ctxs may be used from several host threads.
+ *   - there is NO CPU fallback: without a usable HIP device commet_create fails.
+ */
+#ifndef COMMET_HIP_H_
+#define COMMET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct commet_ctx     commet_ctx;
+typedef struct commet_readset commet_readset;
+
+/* ---- library / device ---------------------------------------------------- */
+const char *commet_version(void);
+const char *commet_last_error(void);
+/* number of HIP devices visible (0 if none / no driver) */
+int         commet_device_count(void);
+
+/* ---- context: k, t, the Bloom filter in HBM ------------------------------ */
+/* Replaces `HashKey hash(kmer_size)` + `new BloomFilter(kmer_size)`
+ * (hash_key.h:40-49, bloom_filter.h:61-81): binds a device, creates a stream,
+ * allocates the 4-lane filter (2^(k-1) bytes of HBM, laid out as four bit-planes
+ * of 2^k bits).  1 <= k <= 38; t < 1 behaves as t = 1 (search_reads.h:55).
+ * Returns NULL on error. */
+commet_ctx *commet_create(int device, int kmer_size, int min_hits);
+void        commet_destroy(commet_ctx *ctx);
+int         commet_kmer_size(const commet_ctx *ctx);
+int         commet_min_hits(const commet_ctx *ctx);
+/* max_kmer = (unsigned long)(1e9 / 2^(33-k))  (src/index_and_search.cpp:73,146) */
+uint64_t    commet_max_kmer(const commet_ctx *ctx);
+/* blocks until everything queued on the ctx's stream has finished */
+int         commet_synchronize(commet_ctx *ctx);
+
+/* ---- read sets resident in HBM ------------------------------------------- */
+/* Replaces FileManager + ReadFile as the *source of reads* (file_manager.h:38-49,
+ * read_file.h:34-47): a read set is the virtual concatenation of its files;
+ * reads are 2-bit packed on the device into bit-planes (+ a validity plane for
+ * non-ACGT, alphabet.h:44-58).  max_reads / max_bases are capacity bounds
+ * (e.g. #'>' lines and file size). */
+commet_readset *commet_readset_create(commet_ctx *ctx, uint64_t max_reads, uint64_t max_bases);
+void            commet_readset_destroy(commet_readset *rs);
+/* Marks the start of a new file of the set (FileManager::addFile,
+ * file_manager.h:117-171).  Must be called before the first append of each file. */
+int             commet_readset_begin_file(commet_readset *rs);
+/* Pinned staging, double-buffered.  acquire() hands out a pinned host buffer
+ * (waiting for the copy that last used it); the parser writes sequence bytes
+ * (ASCII, no separators) into *bases and read boundaries into *offsets
+ * (offsets[0] = 0 ... offsets[n_reads] = bytes used); commit() queues the
+ * hipMemcpyAsync + the packing kernel and returns at once. */
+int             commet_readset_stage_acquire(commet_readset *rs, uint8_t **bases, uint64_t *bases_cap,
+                                             uint64_t **offsets, uint64_t *reads_cap);
+int             commet_readset_stage_commit(commet_readset *rs, uint64_t n_reads);
+/* Convenience: copies (bases, offsets[n_reads+1]) through the staging buffers. */
+int             commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets,
+                                      uint64_t n_reads);
+/* Ends loading: waits for the uploads, fetches the per-read counts of complete
+ * k-mers (what index_reads.h:55-57 would feed) needed for exact chunking. */
+int             commet_readset_finalize(commet_readset *rs);
+uint64_t        commet_readset_num_reads(const commet_readset *rs);
+uint64_t        commet_readset_num_files(const commet_readset *rs);
+/* kmers_out[n_reads]: complete k-mers of each read (valid after finalize) */
+int             commet_readset_kmer_counts(const commet_readset *rs, uint32_t *kmers_out);
+
+/* ---- the two kernels ------------------------------------------------------ */
+/* Replaces `new BloomFilter` per chunk (index_and_search.cpp:256-262,
+ * bloom_filter.h:73-76): zeroes the filter (asynchronous). */
+int commet_filter_reset(commet_ctx *ctx);
+
+/* Replaces the body of index_reads (index_reads.h:49-61) for reads
+ * [first, first+count) of rs whose select bit is 1 (select_bits indexed by the
+ * set-wide read number, NULL = all): every complete k-mer sets its 4 lane bits
+ * (bloom_filter.h:112-118).  Chunking (max_kmer, the dropped look-ahead read)
+ * is decided by the caller / commet_index_and_search.  *kmers_fed (optional)
+ * receives the number of k-mers fed; asking for it synchronises. */
+int commet_index_reads(commet_ctx *ctx, const commet_readset *rs, uint64_t first, uint64_t count,
+                       const uint8_t *select_bits, uint64_t *kmers_fed);
+
+/* Replaces search_reads (search_reads.h:34-87) for the reads of rs whose
+ * active bit is 1 (NULL = all): a read is found iff it has >= t non-overlapping
+ * k-mers present in all 4 lanes, scanning forward keys first and
+ * reverse-complement keys only if the forward scan failed.  found_bits
+ * (n/8+1 bytes, caller-allocated) gets 1 for found reads and 0 for all others.
+ * n_scanned = active reads, n_found = found reads (both optional). */
+int commet_search_reads(commet_ctx *ctx, const commet_readset *rs, const uint8_t *active_bits,
+                        uint8_t *found_bits, uint64_t *n_scanned, uint64_t *n_found);
+
+/* ---- the chunk loop on resident sets --------------------------------------- */
+typedef struct {
+    uint64_t indexed;       /* nb_indexed_reads  (index_and_search.cpp:286: excludes dropped reads) */
+    uint64_t searched;      /* nb_searched_reads of the LAST search pass (search_reads.h:39)        */
+    uint64_t shared;        /* nb_found_reads summed over chunks                                    */
+} commet_pair_stats;
+
+typedef struct {
+    uint64_t n_chunks;          /* filters built                          */
+    uint64_t kmers_indexed;     /* k-mers fed over all chunks             */
+    uint64_t reads_scanned;     /* search-read scans over all chunks/sets */
+    double   index_ms;          /* device time: filter zeroing + index kernels (hipEvents on the ctx stream) */
+    double   search_ms;         /* device time: search kernels            */
+    double   total_ms;          /* host wall time of the call             */
+} commet_job_info;
+
+/* Replaces the while loop of main() (index_and_search.cpp:241-277) together
+ * with the FileManager iteration rules it relies on (file_manager.h:88-112:
+ * input-filter bits, skipping of already tagged reads, file switching;
+ * index_reads.h:49,60: the look-ahead read that is dropped when a chunk fills):
+ *   while reads remain in index_rs: build the filter of the next chunk, search
+ *   every search set against it, OR the found bits into that set's tags.
+ * index_select / search_select[i]: per-file input-filter bits concatenated over
+ * the set (ReadFile::bv), NULL = all ones.  tags_out[i]: n_i/8+1 bytes, the
+ * FileManager::file_bvs of search set i at the end (what save_bv writes).
+ * stats[i] / info are optional. */
+int commet_index_and_search(commet_ctx *ctx,
+                            const commet_readset *index_rs, const uint8_t *index_select,
+                            int n_search, const commet_readset *const *search_rs,
+                            const uint8_t *const *search_select,
+                            uint8_t *const *tags_out, commet_pair_stats *stats,
+                            commet_job_info *info);
+
+/* ---- test / measurement hooks --------------------------------------------- */
+/* Copies the filter to the host in the REFERENCE byte layout (byte key/2,
+ * even keys 0x80/40/20/10, odd keys 0x08/04/02/01 for a/b/c/d,
+ * bloom_filter.h:63-70,114-117); out has 2^(k-1) bytes.  For parity tests. */
+int commet_filter_export_reference(commet_ctx *ctx, uint8_t *out, uint64_t out_bytes);
+/* Device time in ms of the most recent index / search kernel launch on this
+ * ctx, measured with hipEvents on the ctx's stream (synchronises). */
+int commet_last_kernel_ms(commet_ctx *ctx, double *index_ms, double *search_ms);
+/* Random 4-byte-gather / atomic-OR microbenchmarks over a table of
+ * table_bytes (practical random-access ceilings): n_access
+ * accesses, returns elapsed device ms in *ms. */
+int commet_membench(commet_ctx *ctx, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMMET_HIP_H_ */
