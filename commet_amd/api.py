@@ -2,6 +2,7 @@
 meaning, errors raised as CommetError with the library's message.  All compute
 happens in the HIP library; numpy arrays only carry host buffers."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -46,9 +47,12 @@ class Context:
         self.k = int(k)
         self.t = self._lib.commet_min_hits(self._h)
         self.device = int(device)
+        self._readsets = weakref.WeakSet()
 
     def close(self):
         if getattr(self, "_h", None):
+            for rs in list(self._readsets):      # read sets die with their context
+                rs.close()
             self._lib.commet_destroy(self._h)
             self._h = None
 
@@ -115,8 +119,8 @@ class Context:
         info = _l.JobInfo()
         self._check(self._lib.commet_index_and_search(self._h, index_rs._h, _ptr(isel), ns, rs_arr, sel_arr, tag_arr,
                                                       stats, C.byref(info)))
-        st = [dict(indexed=int(stats[i].indexed), searched=int(stats[i].searched), shared=int(stats[i].shared))
-              for i in range(ns)]
+        st = [dict(indexed=int(stats[i].indexed), searched=int(stats[i].searched), shared=int(stats[i].shared),
+                   search_ms=float(stats[i].search_ms)) for i in range(ns)]
         inf = {f: getattr(info, f) for f, _ in _l.JobInfo._fields_}
         return tags, st, inf
 
@@ -147,6 +151,7 @@ class ReadSet:
         self._h = self._lib.commet_readset_create(ctx._h, int(max_reads), int(max_bases))
         if not self._h:
             raise CommetError(_err(self._lib))
+        ctx._readsets.add(self)
 
     @classmethod
     def from_files(cls, ctx, files):

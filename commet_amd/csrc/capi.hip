@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -428,7 +429,7 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
 {
     if (count == 0) return 0;
     const uint64_t blocks = (count + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return fail("index launch too large");
+    if (blocks >= (1ull << 24)) return fail("index launch too large (>= 2^32 reads in one chunk)");
     if (c->k <= 32)
         hipLaunchKernelGGL(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
                            c->k, first, count, d_sel, d_fed);
@@ -444,7 +445,7 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
 {
     if (rs->n_reads == 0) return 0;
     const uint64_t blocks = (rs->n_reads + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return fail("search launch too large");
+    if (blocks >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
     if (c->k <= 32)
         hipLaunchKernelGGL(search_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
                            c->k, c->t, d_sel, d_tags, d_found, d_counters);
@@ -565,30 +566,35 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         evs.push_back(*e);
         return 0;
     };
-    const bool timed = info != nullptr && n_chunks <= 4096;
-    std::vector<hipEvent_t> e_idx0, e_idx1, e_srch1;
+    const bool timed = (info != nullptr || stats != nullptr) && n_chunks * (uint64_t) (n_search + 2) <= 16384;
+    std::vector<hipEvent_t> e_idx0, e_idx1;
+    std::vector<std::vector<hipEvent_t>> e_set(n_search);   // end of set s's search, per chunk
 
     int rc = 0;
     for (uint64_t ci = 0; ci < n_chunks && !rc; ++ci) {
         const Chunk &ch = plan.chunks[ci];
-        hipEvent_t a = nullptr, b = nullptr, d = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
         if (timed) {
-            if (new_event(&a) || new_event(&b) || new_event(&d)) { rc = 1; break; }
+            if (new_event(&a) || new_event(&b)) { rc = 1; break; }
             (void) hipEventRecord(a, c->stream);
         }
         if (commet_filter_reset(c)) { rc = 1; break; }                       // new BloomFilter per chunk
         if (ch.n_reads)
             if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr)) { rc = 1; break; }
-        if (timed) (void) hipEventRecord(b, c->stream);
+        if (timed) {
+            (void) hipEventRecord(b, c->stream);
+            e_idx0.push_back(a);
+            e_idx1.push_back(b);
+        }
         for (int s = 0; s < n_search; ++s) {
             const commet_readset *rs = search_rs[s];
             if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, d_cnt + 2 * (ci * n_search + s))) { rc = 1; break; }
-        }
-        if (timed) {
-            (void) hipEventRecord(d, c->stream);
-            e_idx0.push_back(a);
-            e_idx1.push_back(b);
-            e_srch1.push_back(d);
+            if (timed) {
+                hipEvent_t d = nullptr;
+                if (new_event(&d)) { rc = 1; break; }
+                (void) hipEventRecord(d, c->stream);
+                e_set[s].push_back(d);
+            }
         }
     }
     if (!rc && n_cnt)
@@ -620,20 +626,30 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 stats[s].indexed = plan.indexed_reads;
                 stats[s].searched = n_chunks ? last_scanned : 0;
                 stats[s].shared = shared;
+                stats[s].search_ms = 0;
+            }
+        }
+        double idx_ms = 0, srch_ms = 0;
+        if (timed && !rc) {
+            for (size_t i = 0; i < e_idx0.size(); ++i) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e_idx0[i], e_idx1[i]) == hipSuccess) idx_ms += ms;
+                for (int s = 0; s < n_search; ++s) {
+                    if (i >= e_set[s].size()) continue;
+                    hipEvent_t prev = s == 0 ? e_idx1[i] : e_set[s - 1][i];
+                    if (hipEventElapsedTime(&ms, prev, e_set[s][i]) == hipSuccess) {
+                        srch_ms += ms;
+                        if (stats) stats[s].search_ms += ms;
+                    }
+                }
             }
         }
         if (info) {
             info->n_chunks = n_chunks;
             info->kmers_indexed = plan.kmers;
             info->reads_scanned = scans;
-            info->index_ms = info->search_ms = 0;
-            if (timed) {
-                for (size_t i = 0; i < e_idx0.size(); ++i) {
-                    float ms = 0;
-                    if (hipEventElapsedTime(&ms, e_idx0[i], e_idx1[i]) == hipSuccess) info->index_ms += ms;
-                    if (hipEventElapsedTime(&ms, e_idx1[i], e_srch1[i]) == hipSuccess) info->search_ms += ms;
-                }
-            }
+            info->index_ms = idx_ms;
+            info->search_ms = srch_ms;
         }
     }
     for (hipEvent_t e : evs) (void) hipEventDestroy(e);
@@ -653,7 +669,7 @@ int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_byt
     HIP_OK(hipSetDevice(c->device));
     uint8_t *d_out = nullptr;
     HIP_OK(hipMalloc((void **) &d_out, nbytes));
-    const uint64_t blocks = (nbytes + 255) / 256;
+    const uint64_t blocks = std::min<uint64_t>((nbytes + 255) / 256, 1u << 20);   // grid-stride beyond
     hipLaunchKernelGGL(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), nbytes, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nbytes, hipMemcpyDeviceToHost, c->stream);

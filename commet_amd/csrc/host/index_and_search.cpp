@@ -1,0 +1,330 @@
+// index_and_search — drop-in replacement of Commet's tool of the same name
+// (reference: src/index_and_search.cpp:56-422), driving the MI355X path through
+// the C ABI of include/commet_hip.h.  Same flags, same set-config grammar, same
+// stdout banners, same OUT/<file>_in_<set>.bv bytes and LOG/<s>_in_<i>.log
+// format, so Commet.py (Commet.py:197,220,233) can call it unchanged.
+//
+// Host side = this file: argv, set-configs, FASTA -> pinned staging batches
+// (fasta_source.hpp), filter / output .bv files (bv_file.hpp).  Everything
+// between "reads are resident" and "tag bits are back" runs in the library.
+//
+// Extra (non-reference) controls: env COMMET_DEVICE=<n> picks the GPU.
+
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/commet_hip.h"
+#include "bv_file.hpp"
+#include "fasta_source.hpp"
+#include "set_config.hpp"
+
+using namespace commet_host;
+
+static const std::string version = "2.1";   // index_and_search.cpp:44 (interface version we mirror)
+
+static void print_usage()
+{
+    // index_and_search.cpp:407-422
+    std::cerr << "\nindex_and_search, version " << version << "\n";
+    std::cerr << "Usage : ./index_and_search -i <file> -s <file> [options]\n";
+    std::cerr << "Mandatory:\n";
+    std::cerr << "\t -i <file>: A file containing the list of files to index - MANDATORY\n";
+    std::cerr << "\t -s <file>: A file containing the list of files to search - MANDATORY\n";
+    std::cerr << "\t            Each line of the file corresponds to a set of files to search\n";
+    std::cerr << "Options:\n";
+    std::cerr << "\t -l </.../>: ABSOLUTE path to log folder\n";
+    std::cerr << "\t -o </.../>: ABSOLUTE path to output folder\n";
+    std::cerr << "\t -k <value>: Size of k-mers (value of k). [default=33]\n";
+    std::cerr << "\t -t <value>: Number of shared k-mers. [default=2]\n";
+    std::cerr << "\t -f: Full comparison of index set and the first searched set [default=false]\n";
+    std::cerr << "\t -h: Prints this message\n";
+    std::cerr << "\t -v: Prints the version number\n";
+}
+
+static void ensure_dir(const std::string &p)
+{
+    struct stat info;   // index_and_search.cpp:178-191
+    if (stat(p.c_str(), &info) != 0) mkdir(p.c_str(), S_IRWXU | S_IRGRP | S_IXGRP);
+    else if (!(info.st_mode & S_IFDIR)) {
+        std::cerr << "Error: " << p << " already exists and is not a directory\n";
+        exit(1);
+    }
+}
+
+struct LoadedFile {
+    std::string name;
+    uint64_t nb_reads = 0;
+    BitVector filter;     // ReadFile::bv
+};
+
+struct LoadedSet {
+    std::string nickname;
+    std::vector<LoadedFile> files;
+    commet_readset *rs = nullptr;
+    std::vector<uint8_t> select;   // set-wide input-filter bits
+    bool any_bv = false;
+    uint64_t n_reads = 0;
+};
+
+// FileManager::addFile for every entry of one set (file_manager.h:117-216),
+// FastaFile ctors (fasta_file.h:49-116), then streams the reads to HBM.
+static void load_set(commet_ctx *ctx, const std::string &nickname, const std::vector<SetEntry> &entries, LoadedSet &out)
+{
+    out.nickname = nickname;
+    std::vector<std::unique_ptr<MappedFile>> maps;
+    uint64_t max_reads = 0, max_bases = 0;
+    for (const SetEntry &en : entries) {
+        if (en.bv.empty()) std::cout << "open " << en.file << "\n";
+        else std::cout << "open " << en.file << "," << en.bv << "\n";
+        std::unique_ptr<MappedFile> mf(new MappedFile);
+        if (!mf->open_file(en.file)) {
+            if (en.bv.empty()) {
+                std::cerr << "Cannot open file file " << en.file << " -> ignore\n";   // file_manager.h:121-123
+                std::cerr << "Cannot open file " << en.file << " -> ignore\n";        // gz path, :144-147
+                exit(1);
+            }
+            std::cerr << "Cannot open file " << en.file << " -> ignore\n";            // file_manager.h:177-180
+            continue;
+        }
+        const char first = mf->size() ? mf->data()[0] : '\0';
+        if (first != '>') {
+            // '@' = FASTQ, anything else = gzip in the reference (file_manager.h:132-157)
+            std::cerr << "Unknown format: " << en.file << " -> ignore\n";
+            std::cerr << "(this build reads plain FASTA only)\n";
+            exit(1);
+        }
+        LoadedFile lf;
+        lf.name = en.file;
+        lf.nb_reads = count_fasta_records(mf->data(), mf->size());
+        if (en.bv.empty()) lf.filter.init_true(lf.nb_reads);
+        else {
+            if (!read_bv(en.bv, lf.filter)) exit(1);
+            out.any_bv = true;
+            if (lf.nb_reads != lf.filter.size) {   // fasta_file.h:108-111
+                std::cerr << "Number of reads in " << en.file << " and boolean vector size are not equal -> quit\n";
+                exit(1);
+            }
+        }
+        max_reads += lf.nb_reads;
+        max_bases += mf->size();
+        out.files.push_back(lf);
+        maps.push_back(std::move(mf));
+    }
+    out.rs = commet_readset_create(ctx, max_reads, max_bases);
+    if (!out.rs) {
+        std::cerr << "Error: " << commet_last_error() << "\n";
+        exit(1);
+    }
+    for (size_t i = 0; i < out.files.size(); ++i) {
+        std::string err;
+        if (commet_readset_begin_file(out.rs) || stream_fasta(out.rs, maps[i]->data(), maps[i]->size(), err)) {
+            std::cerr << "Error: " << (err.empty() ? commet_last_error() : err.c_str()) << "\n";
+            exit(1);
+        }
+    }
+    if (commet_readset_finalize(out.rs)) {
+        std::cerr << "Error: " << commet_last_error() << "\n";
+        exit(1);
+    }
+    out.n_reads = commet_readset_num_reads(out.rs);
+    if (out.n_reads != max_reads) {
+        std::cerr << "Error in Fasta format !!\n";   // fasta_file.h:158-161
+        exit(1);
+    }
+    // set-wide select bits = the per-file filters, concatenated
+    out.select.assign(out.n_reads / 8 + 1, 0);
+    uint64_t pos = 0;
+    for (const LoadedFile &lf : out.files) {
+        for (uint64_t i = 0; i < lf.nb_reads; ++i)
+            if (lf.filter.get(i)) out.select[(pos + i) >> 3] |= (uint8_t) (1u << ((pos + i) & 7));
+        pos += lf.nb_reads;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    std::string search_file_list, index_file_list;
+    int kmer_size = 33;   // index_and_search.cpp:71-72
+    int min_hits = 2;
+    std::string log_path = ".", out_path = ".";
+    bool full = false;
+
+    if (argc == 1) {
+        print_usage();
+        return 0;
+    }
+    int arg_pos = 1;
+    while (arg_pos < argc) {   // index_and_search.cpp:85-172
+        const std::string flag = argv[arg_pos];
+        auto need_arg = [&]() {
+            ++arg_pos;
+            if (arg_pos >= argc) {
+                std::cerr << "Error, flag " << argv[arg_pos - 1] << " needs an argument\n";
+                print_usage();
+                exit(1);
+            }
+        };
+        if (flag == "-i") {
+            need_arg();
+            if (!index_file_list.empty()) std::cerr << "index files already given (-i) -> ignore";
+            else index_file_list = argv[arg_pos];
+        } else if (flag == "-s") {
+            need_arg();
+            if (!search_file_list.empty()) std::cerr << "search files already given (-s) -> ignore";
+            else search_file_list = argv[arg_pos];
+        } else if (flag == "-l") {
+            need_arg();
+            log_path = argv[arg_pos];
+        } else if (flag == "-o") {
+            need_arg();
+            out_path = argv[arg_pos];
+        } else if (flag == "-k") {
+            need_arg();
+            kmer_size = atoi(argv[arg_pos]);
+            std::cout << "k-mer size (-k) = " << kmer_size << "\n";
+        } else if (flag == "-t") {
+            need_arg();
+            min_hits = atoi(argv[arg_pos]);
+            std::cout << "min hits (-t) = " << min_hits << "\n";
+        } else if (flag == "-f") {
+            full = true;
+        } else if (flag == "-h") {
+            print_usage();
+            return 0;
+        } else if (flag == "-v") {
+            std::cout << "\nindex_and_search version " << version << "\n";
+            return 0;
+        } else {
+            std::cerr << "Unknown option " << flag << "\n";
+            print_usage();
+            return 0;
+        }
+        ++arg_pos;
+    }
+    if (full) {
+        std::cerr << "Error: the -f (full comparison) mode is not provided by this build\n";
+        return 1;
+    }
+
+    ensure_dir(log_path);
+    ensure_dir(out_path);
+
+    const auto start_time = std::chrono::steady_clock::now();
+
+    SetMap index_sets, search_sets;
+    if (!read_sets(index_file_list, index_sets)) exit(1);
+    if (index_sets.size() != 1) {   // index_and_search.cpp:197-200
+        std::cerr << "Only one set of files is allowed for indexing\n";
+        exit(1);
+    }
+
+    const char *dev_env = getenv("COMMET_DEVICE");
+    commet_ctx *ctx = commet_create(dev_env ? atoi(dev_env) : 0, kmer_size, min_hits);
+    if (!ctx) {
+        std::cerr << commet_last_error() << "\n";
+        exit(1);
+    }
+
+    LoadedSet index_set;
+    load_set(ctx, index_sets.begin()->first, index_sets.begin()->second, index_set);
+
+    if (!read_sets(search_file_list, search_sets)) exit(1);
+    std::vector<LoadedSet> searches(search_sets.size());
+    {
+        size_t s = 0;
+        for (SetMap::iterator it = search_sets.begin(); it != search_sets.end(); ++it, ++s)
+            load_set(ctx, it->first, it->second, searches[s]);
+    }
+    if (searches.empty()) {
+        // the reference dereferences search_sets[0] here (index_and_search.cpp:247): undefined
+        std::cerr << "Error: no set to search\n";
+        exit(1);
+    }
+
+    // the chunk loop (index_and_search.cpp:241-277) on the device
+    const int ns = (int) searches.size();
+    std::vector<const commet_readset *> rs(ns);
+    std::vector<const uint8_t *> sel(ns);
+    std::vector<std::vector<uint8_t>> tags(ns);
+    std::vector<uint8_t *> tag_ptr(ns);
+    for (int s = 0; s < ns; ++s) {
+        rs[s] = searches[s].rs;
+        sel[s] = searches[s].any_bv ? searches[s].select.data() : nullptr;
+        tags[s].assign(searches[s].n_reads / 8 + 1, 0);
+        tag_ptr[s] = tags[s].data();
+    }
+    std::vector<commet_pair_stats> stats(ns);
+    commet_job_info info;
+    if (commet_index_and_search(ctx, index_set.rs, index_set.any_bv ? index_set.select.data() : nullptr, ns, rs.data(),
+                                sel.data(), tag_ptr.data(), stats.data(), &info)) {
+        std::cerr << "Error: " << commet_last_error() << "\n";
+        exit(1);
+    }
+
+    // per-chunk banners (index_and_search.cpp:267-269)
+    for (uint64_t c = 0; c < info.n_chunks; ++c)
+        for (int s = 0; s < ns; ++s) {
+            std::cout << "\n------------------------------------------------------------------\n";
+            std::cout << "finding reads from {" << searches[s].nickname << "} present in raw {" << index_set.nickname
+                      << "}\n";
+            std::cout << "------------------------------------------------------------------\n";
+        }
+
+    const float index_s = (float) (info.index_ms / 1000.0);
+    for (int s = 0; s < ns; ++s) {   // index_and_search.cpp:278-301
+        const float search_s = (float) (stats[s].search_ms / 1000.0);
+        auto total_s = [&]() {
+            return (float) std::chrono::duration<double>(std::chrono::steady_clock::now() - start_time).count();
+        };
+        std::cout << "\n------------------------------------------------------------------\n";
+        std::cout << "Reads from {" << searches[s].nickname << "} present in raw {" << index_set.nickname << "}\n";
+        std::cout << "------------------------------------------------------------------\n";
+        std::cout << "Index  time: " << index_s << " s\n";
+        std::cout << "Search time: " << search_s << " s\n";
+        std::cout << "Total  time: " << total_s() << " s\n";
+        std::cout << "[indexed " << stats[s].indexed << ", searched " << stats[s].searched << ", shared "
+                  << stats[s].shared << "]\n";
+        const std::string fname = log_path + "/" + searches[s].nickname + "_in_" + index_set.nickname + ".log";
+        std::ofstream log_file(fname.c_str());
+        if (!log_file.good()) {
+            std::cerr << "Cannot open log file : " << fname << "\n";
+            exit(1);
+        }
+        log_file << "Index  time: " << index_s << " s\n";
+        log_file << "Search time: " << search_s << " s\n";
+        log_file << "Total  time: " << total_s() << " s\n";
+        log_file << "[indexed " << stats[s].indexed << ", searched " << stats[s].searched << ", shared "
+                 << stats[s].shared << "]\n";
+        log_file.close();
+    }
+
+    // save_bv (index_and_search.cpp:397-399, file_manager.h:245-252)
+    for (int s = 0; s < ns; ++s) {
+        uint64_t pos = 0;
+        for (const LoadedFile &lf : searches[s].files) {
+            BitVector bv;
+            bv.init_false(lf.nb_reads);
+            for (uint64_t i = 0; i < lf.nb_reads; ++i)
+                if ((tags[s][(pos + i) >> 3] >> ((pos + i) & 7)) & 1) bv.set(i);
+            pos += lf.nb_reads;
+            const std::string base = lf.name.substr(lf.name.rfind("/") + 1);
+            bv.comment = lf.name + " in " + index_set.nickname;
+            if (!write_bv(out_path + "/" + base + "_in_" + index_set.nickname + ".bv", bv)) exit(1);
+        }
+    }
+
+    for (LoadedSet &ls : searches) commet_readset_destroy(ls.rs);
+    commet_readset_destroy(index_set.rs);
+    commet_destroy(ctx);
+    return 0;
+}

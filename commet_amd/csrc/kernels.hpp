@@ -245,19 +245,20 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void export_reference_kernel(FilterView f, uint64_t nbytes, uint8_t *__restrict__ out)
 {
-    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
-    if (i >= nbytes) return;
-    const uint64_t k0 = 2 * i, k1 = 2 * i + 1;
-    uint32_t b = 0;
-    b |= test_bit<uint64_t>(f.a, k0) << 7;
-    b |= test_bit<uint64_t>(f.b, k0) << 6;
-    b |= test_bit<uint64_t>(f.c, k0) << 5;
-    b |= test_bit<uint64_t>(f.d, k0) << 4;
-    b |= test_bit<uint64_t>(f.a, k1) << 3;
-    b |= test_bit<uint64_t>(f.b, k1) << 2;
-    b |= test_bit<uint64_t>(f.c, k1) << 1;
-    b |= test_bit<uint64_t>(f.d, k1);
-    out[i] = (uint8_t) b;
+    const uint64_t stride = (uint64_t) gridDim.x * 256ull;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nbytes; i += stride) {
+        const uint64_t k0 = 2 * i, k1 = 2 * i + 1;
+        uint32_t b = 0;
+        b |= test_bit<uint64_t>(f.a, k0) << 7;
+        b |= test_bit<uint64_t>(f.b, k0) << 6;
+        b |= test_bit<uint64_t>(f.c, k0) << 5;
+        b |= test_bit<uint64_t>(f.d, k0) << 4;
+        b |= test_bit<uint64_t>(f.a, k1) << 3;
+        b |= test_bit<uint64_t>(f.b, k1) << 2;
+        b |= test_bit<uint64_t>(f.c, k1) << 1;
+        b |= test_bit<uint64_t>(f.d, k1);
+        out[i] = (uint8_t) b;
+    }
 }
 
 // ---------------------------------------------------------------------------

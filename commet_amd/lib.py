@@ -15,7 +15,8 @@ f64p = C.POINTER(C.c_double)
 
 
 class PairStats(C.Structure):
-    _fields_ = [("indexed", C.c_uint64), ("searched", C.c_uint64), ("shared", C.c_uint64)]
+    _fields_ = [("indexed", C.c_uint64), ("searched", C.c_uint64), ("shared", C.c_uint64),
+                ("search_ms", C.c_double)]
 
 
 class JobInfo(C.Structure):

@@ -114,6 +114,7 @@ typedef struct {
     uint64_t indexed;       /* nb_indexed_reads  (index_and_search.cpp:286: excludes dropped reads) */
     uint64_t searched;      /* nb_searched_reads of the LAST search pass (search_reads.h:39)        */
     uint64_t shared;        /* nb_found_reads summed over chunks                                    */
+    double   search_ms;     /* device time of this set's search kernels (search_times[set_pos], :272) */
 } commet_pair_stats;
 
 typedef struct {

@@ -32,8 +32,8 @@ class Scenario:
                 # no empty sequences: the reference's behaviour on them is undefined
                 reads = [r if len(r) else b"A" for r in reads]
                 pool.extend(reads[: max(1, n // 2)])
-                fa = os.path.join(d, f"{name}_f{fi}.fa")
-                util.write_fasta(fa, reads, rng=rng, multiline=multiline, crlf=crlf)
+                fa = f"{name}_f{fi}.fa"          # relative: tools run with cwd = scenario dir
+                util.write_fasta(os.path.join(d, fa), reads, rng=rng, multiline=multiline, crlf=crlf)
                 bv = None
                 sel = np.ones(n, dtype=bool)
                 if allow_bv and rng.random() < 0.5:
@@ -45,16 +45,16 @@ class Scenario:
                     else:
                         sel = rng.random(n) < rng.uniform(0.2, 0.95)
                     bv = fa + ".bv"
-                    util.write_bv(bv, f"filter of {fa}", sel)
+                    util.write_bv(os.path.join(d, bv), f"filter of {fa}", sel)
                 files.append((fa, bv, reads, sel))
             self.sets[name] = files
         self.index_name = names[0]
         self.search_names = names[1:]
-        self.index_cfg = os.path.join(d, "index.txt")
-        self.search_cfg = os.path.join(d, "search.txt")
-        with open(self.index_cfg, "w") as fh:
+        self.index_cfg = "index.txt"
+        self.search_cfg = "search.txt"
+        with open(os.path.join(d, self.index_cfg), "w") as fh:
             fh.write(self._line(self.index_name) + "\n")
-        with open(self.search_cfg, "w") as fh:
+        with open(os.path.join(d, self.search_cfg), "w") as fh:
             for nme in self.search_names:
                 fh.write(self._line(nme) + "\n")
 
@@ -74,6 +74,28 @@ class Scenario:
         return bvs, logs
 
 
+def run_tool(tool, scn, out, log, extra_env=None):
+    """runs an index_and_search-compatible CLI inside the scenario dir"""
+    env = dict(os.environ)
+    if extra_env:
+        env.update(extra_env)
+    import subprocess
+    return subprocess.run([tool, "-i", scn.index_cfg, "-s", scn.search_cfg, "-o", out, "-l", log,
+                           "-k", str(scn.k), "-t", str(scn.t)], cwd=scn.dir, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def run_oracle(scn, out, log):
+    """the CPU checker in-process (paths resolved against the scenario dir)"""
+    import oracle_binding as ob
+    cwd = os.getcwd()
+    os.chdir(scn.dir)
+    try:
+        return ob.index_and_search(scn.index_cfg, scn.search_cfg, out, log, scn.k, scn.t)
+    finally:
+        os.chdir(cwd)
+
+
 def compare_runs(out_a, log_a, out_b, log_b, scn):
     bvs, logs = scn.expected_outputs()
     for b in bvs:
@@ -84,3 +106,57 @@ def compare_runs(out_a, log_a, out_b, log_b, scn):
         la = util.last_log_line(os.path.join(log_a, l))
         lb = util.last_log_line(os.path.join(log_b, l))
         assert la == lb, f"{l}: {la!r} != {lb!r} (k={scn.k} t={scn.t} dir={scn.dir})"
+
+
+class GoldenScenario:
+    """A committed scenario of tests/golden/scenarios (inputs + the reference's outputs)."""
+
+    def __init__(self, name):
+        import json
+        base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenarios")
+        meta = json.load(open(os.path.join(base, "index.json")))[name]
+        self.dir = os.path.join(base, name)
+        self.k, self.t = meta["k"], meta["t"]
+        self.index_name = meta["index"]
+        self.search_names = meta["search"]
+        self.index_cfg, self.search_cfg = "index.txt", "search.txt"
+        self.expected_dir = os.path.join(self.dir, "expected")
+        self.log_lines = json.load(open(os.path.join(self.expected_dir, "log_lines.json")))
+        self.sets = {}
+        for cfg in (self.index_cfg, self.search_cfg):
+            for line in open(os.path.join(self.dir, cfg)).read().split("\n"):
+                if not line:
+                    continue
+                tag, rest = line.split(":", 1)
+                files = []
+                for item in rest.split(";"):
+                    parts = item.strip(" ").split(",")
+                    fa = parts[0].strip(" ")
+                    bv = parts[1].strip(" ") if len(parts) > 1 else None
+                    reads = util.parse_fasta(os.path.join(self.dir, fa))
+                    if bv:
+                        _, n, bits = util.read_bv(os.path.join(self.dir, bv))
+                        sel = util.bools_from_bits(bits, n)
+                    else:
+                        sel = np.ones(len(reads), dtype=bool)
+                    files.append((fa, bv, reads, sel))
+                self.sets[tag] = files
+
+    @staticmethod
+    def names():
+        import json
+        base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenarios")
+        return sorted(json.load(open(os.path.join(base, "index.json"))).keys())
+
+    def expected_outputs(self):
+        return Scenario.expected_outputs(self)
+
+    def check_against_golden(self, out_dir, log_dir):
+        bvs, logs = self.expected_outputs()
+        for b in bvs:
+            got = open(os.path.join(out_dir, b), "rb").read()
+            exp = open(os.path.join(self.expected_dir, b), "rb").read()
+            assert got == exp, f"{b} differs from the reference's output ({self.dir})"
+        for l in logs:
+            got = util.last_log_line(os.path.join(log_dir, l))
+            assert got == self.log_lines[l], f"{l}: {got!r} != {self.log_lines[l]!r}"

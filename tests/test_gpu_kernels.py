@@ -1,0 +1,183 @@
+"""Parity of the HIP kernels with the CPU checker, through the C ABI.
+Bit-exact: integer / bit work only."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def commet():
+    import commet_amd
+    return commet_amd
+
+
+def _mixed_reads(seed, n=700, lo=0, hi=140):
+    rng = np.random.default_rng(seed)
+    base = util.random_reads(rng, n // 2, max(lo, 1), hi, n_rate=0.02)
+    rel = util.related_reads(rng, base, n - n // 2, max(lo, 1), hi, share=0.6, n_rate=0.02)
+    reads = base + rel
+    if lo == 0:
+        reads[3] = b""
+        reads[len(reads) // 2] = b""
+    return reads
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8, 13, 20, 31, 32, 33, 36])
+def test_pack_and_kmer_counts(commet, k):
+    reads = _mixed_reads(11 + k)
+    bases, offs = util.to_batch(reads)
+    with commet.Context(k=min(k, 20) if k > 33 else k, t=2) as ctx:
+        kk = ctx.k
+        rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+        got = rs.kmer_counts()
+        exp = ob.kmer_counts(bases, offs, kk)
+        assert np.array_equal(got, exp)
+        rs.close()
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 12, 16, 21, 25, 28])
+def test_index_filter_bits_match_reference_layout(commet, k):
+    reads = _mixed_reads(100 + k, n=900)
+    bases, offs = util.to_batch(reads)
+    rng = np.random.default_rng(k)
+    sel = rng.random(len(reads)) < 0.7
+    with commet.Context(k=k, t=2) as ctx:
+        rs = commet.ReadSet.from_files(ctx, [(bases[: int(offs[400])], offs[:401]),
+                                             (bases[int(offs[400]):], offs[400:] - offs[400])])
+        assert rs.num_reads == len(reads) and rs.num_files == 2
+        # all reads
+        ctx.filter_reset()
+        fed = ctx.index_reads(rs)
+        f = ob.Bloom(k)
+        assert fed == f.index(bases, offs)
+        assert np.array_equal(ctx.export_filter_reference(), f.bytes())
+        # a range with select bits
+        ctx.filter_reset()
+        first, count = 123, 555
+        fed = ctx.index_reads(rs, first, count, util.bits_from_bools(sel))
+        f2 = ob.Bloom(k)
+        sel2 = sel.copy()
+        sel2[:first] = False
+        sel2[first + count:] = False
+        assert fed == f2.index(bases, offs, util.bits_from_bools(sel2))
+        assert np.array_equal(ctx.export_filter_reference(), f2.bytes())
+        rs.close()
+
+
+@pytest.mark.parametrize("k,t", [(1, 1), (4, 3), (8, 1), (8, 2), (12, 2), (12, 4), (16, 2), (20, 1), (20, 2), (25, 3),
+                                  (28, 2), (31, 2), (32, 2)])
+def test_search_matches_oracle(commet, k, t):
+    rng = np.random.default_rng(1000 * k + t)
+    idx_reads = util.random_reads(rng, 500, 20, 130, n_rate=0.01)
+    q_reads = util.related_reads(rng, idx_reads, 1500, 1, 130, share=0.5, n_rate=0.02)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    active = rng.random(len(q_reads)) < 0.8
+    with commet.Context(k=k, t=t) as ctx:
+        irs = commet.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+        ctx.filter_reset()
+        ctx.index_reads(irs)
+        f = ob.Bloom(k)
+        f.index(ib, io)
+        # all reads
+        found, scanned, nfound = ctx.search_reads(qrs)
+        exp, nexp = f.search(t, qb, qo)
+        assert scanned == len(q_reads)
+        assert nfound == nexp
+        assert np.array_equal(found, exp)
+        # with an active mask: inactive reads stay 0
+        found, scanned, nfound = ctx.search_reads(qrs, util.bits_from_bools(active))
+        exp, nexp = f.search(t, qb, qo, util.bits_from_bools(active))
+        assert scanned == int(active.sum())
+        assert nfound == nexp
+        assert np.array_equal(found, exp)
+        irs.close()
+        qrs.close()
+
+
+@pytest.mark.parametrize("k", [33, 34])
+def test_wide_keys(commet, k):
+    """k > 32: 64-bit keys, 4 / 8 GiB filter in HBM (reference default is k = 33)."""
+    rng = np.random.default_rng(k)
+    idx_reads = util.random_reads(rng, 300, 40, 150, n_rate=0.01)
+    q_reads = util.related_reads(rng, idx_reads, 900, 1, 150, share=0.6, n_rate=0.01)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    with commet.Context(k=k, t=2) as ctx:
+        irs = commet.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+        ctx.filter_reset()
+        fed = ctx.index_reads(irs)
+        f = ob.Bloom(k)
+        assert fed == f.index(ib, io)
+        found, scanned, nfound = ctx.search_reads(qrs)
+        exp, nexp = f.search(2, qb, qo)
+        assert nfound == nexp and nexp > 0
+        assert np.array_equal(found, exp)
+        if k == 33:
+            assert np.array_equal(ctx.export_filter_reference(), f.bytes())
+        irs.close()
+        qrs.close()
+
+
+def test_uniform_and_ragged_layouts_agree(commet):
+    """fixed-length sets take the offset-free addressing; results must not depend on it"""
+    rng = np.random.default_rng(5)
+    L = 100
+    reads = util.random_reads(rng, 2000, L, L, n_rate=0.01)
+    ragged = reads + [b"ACGT" * 7]                 # one odd read switches the set to explicit offsets
+    k, t = 16, 2
+    ib, io = util.to_batch(reads[:800])
+    with commet.Context(k=k, t=t) as ctx:
+        irs = commet.ReadSet.from_files(ctx, [(ib, io)])
+        ctx.filter_reset()
+        ctx.index_reads(irs)
+        a = commet.ReadSet.from_files(ctx, [util.to_batch(reads)])
+        b = commet.ReadSet.from_files(ctx, [util.to_batch(ragged)])
+        fa, _, na = ctx.search_reads(a)
+        fb, _, nb = ctx.search_reads(b)
+        n = len(reads)
+        assert np.array_equal(util.bools_from_bits(fa, n), util.bools_from_bits(fb, n))
+        f = ob.Bloom(k)
+        f.index(ib, io)
+        exp, nexp = f.search(t, *util.to_batch(reads))
+        assert np.array_equal(fa, exp) and na == nexp
+        for r in (irs, a, b):
+            r.close()
+
+
+def test_empty_and_tiny_inputs(commet):
+    with commet.Context(k=12, t=2) as ctx:
+        e = commet.ReadSet.from_files(ctx, [(np.zeros(0, np.uint8), np.zeros(1, np.uint64))])
+        assert e.num_reads == 0
+        ctx.filter_reset()
+        assert ctx.index_reads(e) == 0
+        found, scanned, nfound = ctx.search_reads(e)
+        assert scanned == 0 and nfound == 0 and found.size == 1
+        one = commet.ReadSet.from_files(ctx, [util.to_batch([b"ACGTACGTACGTACGTACGTACGTACGT"])])
+        ctx.index_reads(one)
+        found, scanned, nfound = ctx.search_reads(one)
+        assert (scanned, nfound) == (1, 1) and found[0] == 1
+        e.close()
+        one.close()
+
+
+def test_errors_are_loud(commet):
+    with pytest.raises(commet.CommetError):
+        commet.Context(k=0)
+    with pytest.raises(commet.CommetError):
+        commet.Context(k=39)
+    with commet.Context(k=10) as ctx:
+        rs = commet.ReadSet(ctx, 10, 100)
+        with pytest.raises(commet.CommetError):
+            ctx.index_reads(rs)          # not finalized
+        rs.add_file(*util.to_batch([b"ACGTACGTACGTAA"]))
+        rs.finalize()
+        with pytest.raises(commet.CommetError):
+            ctx.index_reads(rs, 0, 5)    # out of range
+        rs.close()

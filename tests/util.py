@@ -120,3 +120,22 @@ def run(cmd, cwd=None, check=True):
 def last_log_line(path):
     lines = open(path).read().strip().split("\n")
     return lines[-1]
+
+
+def parse_fasta(path):
+    """Records the way the reference reads them (fasta_file.h:155-175): header
+    lines start with '>', every other non-empty line is appended verbatim
+    (only the '\\n' is stripped, a '\\r' stays in the sequence)."""
+    reads = []
+    cur = None
+    with open(path, "rb") as fh:
+        for line in fh.read().split(b"\n"):
+            if line.startswith(b">"):
+                if cur is not None:
+                    reads.append(b"".join(cur))
+                cur = []
+            elif cur is not None and line:
+                cur.append(line)
+    if cur is not None:
+        reads.append(b"".join(cur))
+    return reads
