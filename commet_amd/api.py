@@ -76,6 +76,9 @@ class Context:
     def max_kmer(self):
         return int(self._lib.commet_max_kmer(self._h))
 
+    def set_option(self, name, value):
+        self._check(self._lib.commet_set_option(self._h, name.encode(), int(value)))
+
     def synchronize(self):
         self._check(self._lib.commet_synchronize(self._h))
 

@@ -69,6 +69,7 @@ struct commet_ctx {
     unsigned long long *h_counters = nullptr;   // pinned
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     bool have_index_ev = false, have_search_ev = false;
+    bool count_probes = false;
 
     FilterView view() const
     {
@@ -441,17 +442,28 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
 }
 
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
-                  unsigned long long *d_counters)
+                  unsigned long long *d_counters, unsigned long long *d_probes = nullptr)
 {
     if (rs->n_reads == 0) return 0;
     const uint64_t blocks = (rs->n_reads + 255) / 256;
     if (blocks >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
-    if (c->k <= 32)
-        hipLaunchKernelGGL(search_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
-                           c->k, c->t, d_sel, d_tags, d_found, d_counters);
-    else
-        hipLaunchKernelGGL(search_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
-                           c->k, c->t, d_sel, d_tags, d_found, d_counters);
+    const dim3 g((unsigned) blocks), b(256);
+    const bool cnt = d_probes != nullptr;
+    if (c->k <= 32) {
+        if (cnt)
+            hipLaunchKernelGGL((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+                               d_tags, d_found, d_counters, d_probes);
+        else
+            hipLaunchKernelGGL((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+                               d_tags, d_found, d_counters, d_probes);
+    } else {
+        if (cnt)
+            hipLaunchKernelGGL((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+                               d_tags, d_found, d_counters, d_probes);
+        else
+            hipLaunchKernelGGL((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+                               d_tags, d_found, d_counters, d_probes);
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -549,13 +561,11 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
 
     // per (chunk, set) counters {scanned, found}
     const uint64_t n_chunks = plan.chunks.size();
-    const uint64_t n_cnt = 2 * n_chunks * (uint64_t) n_search;
+    const uint64_t n_cnt = 2 * n_chunks * (uint64_t) n_search + 1;   // last slot: probe counter
     unsigned long long *d_cnt = nullptr;
-    std::vector<unsigned long long> h_cnt(n_cnt ? n_cnt : 1, 0);
-    if (n_cnt) {
-        HIP_OK(hipMalloc((void **) &d_cnt, n_cnt * sizeof(unsigned long long)));
-        HIP_OK(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(unsigned long long), c->stream));
-    }
+    std::vector<unsigned long long> h_cnt(n_cnt, 0);
+    HIP_OK(hipMalloc((void **) &d_cnt, n_cnt * sizeof(unsigned long long)));
+    HIP_OK(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(unsigned long long), c->stream));
 
     // device timing: one event pair around all index work and one around all
     // search work would overlap; instead accumulate per phase with event pairs
@@ -567,28 +577,35 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         return 0;
     };
     const bool timed = (info != nullptr || stats != nullptr) && n_chunks * (uint64_t) (n_search + 2) <= 16384;
-    std::vector<hipEvent_t> e_idx0, e_idx1;
+    std::vector<hipEvent_t> e_idx0, e_zero, e_idx1;
     std::vector<std::vector<hipEvent_t>> e_set(n_search);   // end of set s's search, per chunk
+    uint64_t n_index_launches = 0, n_search_launches = 0;
+    unsigned long long *d_probes = c->count_probes ? d_cnt + (n_cnt - 1) : nullptr;
 
     int rc = 0;
     for (uint64_t ci = 0; ci < n_chunks && !rc; ++ci) {
         const Chunk &ch = plan.chunks[ci];
-        hipEvent_t a = nullptr, b = nullptr;
+        hipEvent_t a = nullptr, z = nullptr, b = nullptr;
         if (timed) {
-            if (new_event(&a) || new_event(&b)) { rc = 1; break; }
+            if (new_event(&a) || new_event(&z) || new_event(&b)) { rc = 1; break; }
             (void) hipEventRecord(a, c->stream);
         }
         if (commet_filter_reset(c)) { rc = 1; break; }                       // new BloomFilter per chunk
-        if (ch.n_reads)
+        if (timed) (void) hipEventRecord(z, c->stream);
+        if (ch.n_reads) {
             if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr)) { rc = 1; break; }
+            ++n_index_launches;
+        }
         if (timed) {
             (void) hipEventRecord(b, c->stream);
             e_idx0.push_back(a);
+            e_zero.push_back(z);
             e_idx1.push_back(b);
         }
         for (int s = 0; s < n_search; ++s) {
             const commet_readset *rs = search_rs[s];
-            if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, d_cnt + 2 * (ci * n_search + s))) { rc = 1; break; }
+            if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, d_cnt + 2 * (ci * n_search + s), d_probes)) { rc = 1; break; }
+            if (rs->n_reads) ++n_search_launches;
             if (timed) {
                 hipEvent_t d = nullptr;
                 if (new_event(&d)) { rc = 1; break; }
@@ -597,7 +614,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             }
         }
     }
-    if (!rc && n_cnt)
+    if (!rc)
         if (hipMemcpyAsync(h_cnt.data(), d_cnt, n_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail("counter copy failed");
     for (int s = 0; s < n_search && !rc; ++s) {
@@ -629,11 +646,12 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 stats[s].search_ms = 0;
             }
         }
-        double idx_ms = 0, srch_ms = 0;
+        double idx_ms = 0, srch_ms = 0, zero_ms = 0;
         if (timed && !rc) {
             for (size_t i = 0; i < e_idx0.size(); ++i) {
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, e_idx0[i], e_idx1[i]) == hipSuccess) idx_ms += ms;
+                if (hipEventElapsedTime(&ms, e_idx0[i], e_zero[i]) == hipSuccess) zero_ms += ms;
                 for (int s = 0; s < n_search; ++s) {
                     if (i >= e_set[s].size()) continue;
                     hipEvent_t prev = s == 0 ? e_idx1[i] : e_set[s - 1][i];
@@ -648,7 +666,13 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             info->n_chunks = n_chunks;
             info->kmers_indexed = plan.kmers;
             info->reads_scanned = scans;
+            info->reads_indexed = plan.indexed_reads;
+            info->index_launches = n_index_launches;
+            info->search_launches = n_search_launches;
+            info->probes = h_cnt[n_cnt - 1];
+            info->zero_ms = zero_ms;
             info->index_ms = idx_ms;
+            info->index_kernel_ms = idx_ms - zero_ms;
             info->search_ms = srch_ms;
         }
     }
@@ -660,6 +684,15 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
 }
 
 /* ---- hooks ---------------------------------------------------------------- */
+
+int commet_set_option(commet_ctx *c, const char *name, int64_t value)
+{
+    if (!strcmp(name, "count_probes")) {
+        c->count_probes = value != 0;
+        return 0;
+    }
+    return fail("unknown option '%s'", name);
+}
 
 int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_bytes)
 {

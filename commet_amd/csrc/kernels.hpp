@@ -172,11 +172,12 @@ __global__ __launch_bounds__(256) void index_kernel(ReadsView rv, FilterView f, 
 // a -> b -> c -> d (bloom_filter.h:124-131).  64 found flags leave the wave as
 // one __ballot word = 8 bytes of the BooleanVector.
 // ---------------------------------------------------------------------------
-template <typename W>
+template <typename W, bool COUNT>
 __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f, int k, int t,
                                                      const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                      uint64_t *__restrict__ found_out,
-                                                     unsigned long long *__restrict__ counters)
+                                                     unsigned long long *__restrict__ counters,
+                                                     unsigned long long *__restrict__ probe_counter)
 {
     using T = KeyTraits<W>;
     const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
     bool found = false;
+    uint32_t probes = 0;   // filter words loaded (COUNT builds only)
     if (active) {
         uint64_t t0;
         uint32_t len;
@@ -217,8 +219,21 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
                             ka = ~wh & mask;
                             kb = ~wl & mask;
                         }
-                        if (test_bit<W>(f.a, ka) && test_bit<W>(f.b, kb) && test_bit<W>(f.c, ka ^ kb) &&
-                            test_bit<W>(f.d, ka | kb)) {
+                        bool hit = test_bit<W>(f.a, ka);
+                        if (COUNT) ++probes;
+                        if (hit) {
+                            hit = test_bit<W>(f.b, kb);
+                            if (COUNT) ++probes;
+                            if (hit) {
+                                hit = test_bit<W>(f.c, ka ^ kb);
+                                if (COUNT) ++probes;
+                                if (hit) {
+                                    hit = test_bit<W>(f.d, ka | kb);
+                                    if (COUNT) ++probes;
+                                }
+                            }
+                        }
+                        if (hit) {
                             ++seen;
                             run = 0;                       // hash.clear(), search_reads.h:60
                             if (seen >= t) found = true;
@@ -237,6 +252,10 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
             if (ab) atomicAdd(&counters[0], (unsigned long long) __popcll(ab));
             if (fb) atomicAdd(&counters[1], (unsigned long long) __popcll(fb));
         }
+    }
+    if (COUNT && probe_counter) {
+        for (int o = 32; o > 0; o >>= 1) probes += __shfl_down(probes, o, 64);
+        if (lane == 0 && probes) atomicAdd(probe_counter, (unsigned long long) probes);
     }
 }
 

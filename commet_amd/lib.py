@@ -21,7 +21,9 @@ class PairStats(C.Structure):
 
 class JobInfo(C.Structure):
     _fields_ = [("n_chunks", C.c_uint64), ("kmers_indexed", C.c_uint64), ("reads_scanned", C.c_uint64),
-                ("index_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double)]
+                ("reads_indexed", C.c_uint64), ("index_launches", C.c_uint64), ("search_launches", C.c_uint64),
+                ("probes", C.c_uint64), ("zero_ms", C.c_double), ("index_ms", C.c_double),
+                ("index_kernel_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 # name -> (restype, argtypes); the test-suite checks that every symbol declared
@@ -52,6 +54,7 @@ SIGNATURES = {
     "commet_index_and_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(PairStats),
                                           C.POINTER(JobInfo)]),
+    "commet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "commet_filter_export_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_last_kernel_ms": (C.c_int, [C.c_void_p, f64p, f64p]),
     "commet_membench": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, f64p]),

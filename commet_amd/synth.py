@@ -19,15 +19,17 @@ def _raw(seed, n_bytes):
     return rng, bytearray(rng.bytes(n_bytes))
 
 
-def synth_set(set_id, n_reads, read_len, seed_base=1000, copy_frac=0.25, sub_rate=0.01, rc_every=20, n_rate=0.001):
-    """Returns (bases uint8[n*L] ASCII, offsets uint64[n+1]).  Base code = random byte & 3."""
+def synth_set(set_id, n_reads, read_len, seed_base=1000, copy_frac=0.25, sub_rate=0.01, rc_every=20, n_rate=0.001,
+              base_set=0):
+    """Returns (bases uint8[n*L] ASCII, offsets uint64[n+1]).  Base code = random byte & 3.
+    Copies are taken from set `base_set` (0 in SURVEY 8d; bench.py gives every GPU its own pair)."""
     total = n_reads * read_len
     rng, raw = _raw(seed_base + set_id, total)
     codes = np.frombuffer(raw, dtype=np.uint8)          # writable view
-    if set_id > 0 and copy_frac > 0:
+    if set_id != base_set and copy_frac > 0:
         ncopy = int(n_reads * copy_frac)
         if ncopy:
-            _, raw0 = _raw(seed_base, ncopy * read_len)  # set 0's first ncopy reads
+            _, raw0 = _raw(seed_base + base_set, ncopy * read_len)  # the base set's first ncopy reads
             cp = np.frombuffer(raw0, dtype=np.uint8).reshape(ncopy, read_len)
             nsub = int(rng.binomial(ncopy * read_len, sub_rate))
             pos = rng.integers(0, ncopy * read_len, size=nsub)

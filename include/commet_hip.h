@@ -121,7 +121,14 @@ typedef struct {
     uint64_t n_chunks;          /* filters built                          */
     uint64_t kmers_indexed;     /* k-mers fed over all chunks             */
     uint64_t reads_scanned;     /* search-read scans over all chunks/sets */
-    double   index_ms;          /* device time: filter zeroing + index kernels (hipEvents on the ctx stream) */
+    uint64_t reads_indexed;     /* reads fed to a filter (dropped look-ahead reads excluded) */
+    uint64_t index_launches;    /* index kernel launches                  */
+    uint64_t search_launches;   /* search kernel launches                 */
+    uint64_t probes;            /* filter words loaded by the search kernels = P_ref of the reference's
+                                   control flow; 0 unless option "count_probes" is set */
+    double   zero_ms;           /* device time: filter zeroing (hipEvents on the ctx stream) */
+    double   index_ms;          /* device time: filter zeroing + index kernels */
+    double   index_kernel_ms;   /* device time: index kernels only        */
     double   search_ms;         /* device time: search kernels            */
     double   total_ms;          /* host wall time of the call             */
 } commet_job_info;
@@ -144,6 +151,9 @@ int commet_index_and_search(commet_ctx *ctx,
                             commet_job_info *info);
 
 /* ---- test / measurement hooks --------------------------------------------- */
+/* Tunables / diagnostics, by name.  "count_probes" (0/1): the search kernels
+ * count the filter words they load.  Unknown names are an error. */
+int commet_set_option(commet_ctx *ctx, const char *name, int64_t value);
 /* Copies the filter to the host in the REFERENCE byte layout (byte key/2,
  * even keys 0x80/40/20/10, odd keys 0x08/04/02/01 for a/b/c/d,
  * bloom_filter.h:63-70,114-117); out has 2^(k-1) bytes.  For parity tests. */

@@ -35,7 +35,9 @@ def test_job_matches_oracle(tmp_path, seed):
             r, s = _load_set(commet, ctx, scn.sets[nme], scn.dir)
             srs.append(r)
             ssel.append(s)
+        ctx.set_option("count_probes", 1)
         tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
+        assert info["probes"] == sum(r["probes"] for r in res)        # P_ref: the reference's own probe count
         assert info["n_chunks"] == chunks
         assert info["kmers_indexed"] == kmers
         by_name = {r["name"]: r for r in res}
