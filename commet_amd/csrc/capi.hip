@@ -4,6 +4,7 @@
 #include "../../include/commet_hip.h"
 
 #include "kernels.hpp"
+#include "index_part.hpp"
 #include "read_iter.hpp"
 
 #include <hip/hip_runtime.h>
@@ -70,6 +71,15 @@ struct commet_ctx {
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     bool have_index_ev = false, have_search_ev = false;
     bool count_probes = false;
+    int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
+    uint64_t part_min_kmers = 8ull << 20;
+    // workspace of the bucketed construction (index_part.hpp)
+    uint32_t *part_bufA = nullptr, *part_bufB = nullptr;
+    uint64_t part_cap_keys = 0;
+    uint32_t *part_hist = nullptr, *part_wl = nullptr;
+    uint64_t *part_off = nullptr;
+    unsigned long long *part_cur1 = nullptr, *part_cur2 = nullptr;
+    uint32_t part_nb = 0;
 
     FilterView view() const
     {
@@ -105,7 +115,9 @@ struct commet_readset {
     std::vector<FileSpan> files;
     std::vector<uint64_t> empty_reads;
     std::vector<uint32_t> h_kcnt;
+    std::vector<uint64_t> h_kprefix;   // prefix sums of h_kcnt (fast chunk planning)
     uint32_t uniform_len = 0;
+    uint32_t max_kcnt = 0;
     bool finalized = false;
 
     ReadsView view() const
@@ -185,6 +197,13 @@ void commet_destroy(commet_ctx *c)
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->filter) (void) hipFree(c->filter);
+    (void) hipFree(c->part_bufA);
+    (void) hipFree(c->part_bufB);
+    (void) hipFree(c->part_hist);
+    (void) hipFree(c->part_wl);
+    (void) hipFree(c->part_off);
+    (void) hipFree(c->part_cur1);
+    (void) hipFree(c->part_cur2);
     if (c->d_counters) (void) hipFree(c->d_counters);
     if (c->h_counters) (void) hipHostFree(c->h_counters);
     if (c->ev_i0) (void) hipEventDestroy(c->ev_i0);
@@ -379,6 +398,9 @@ int commet_readset_finalize(commet_readset *rs)
         HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     }
     rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
+    rs->max_kcnt = 0;
+    for (uint32_t v : rs->h_kcnt) rs->max_kcnt = std::max(rs->max_kcnt, v);
+    build_kmer_prefix(rs->h_kcnt.data(), rs->n_reads, rs->h_kprefix);
     // the staging buffers are no longer needed: give the memory back
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
@@ -425,8 +447,8 @@ int upload_bits(commet_ctx *c, uint64_t *d_bits, const uint8_t *h_bits, uint64_t
     return 0;
 }
 
-int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                 unsigned long long *d_fed)
+int launch_index_atomic(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                        unsigned long long *d_fed)
 {
     if (count == 0) return 0;
     const uint64_t blocks = (count + 255) / 256;
@@ -439,6 +461,116 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
                            c->k, first, count, d_sel, d_fed);
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
+{
+    return c->k >= 20 && c->k <= 34 && (uint64_t) rs->max_kcnt * 4 <= S1_KEYS;
+}
+
+// Bucketed construction of the filter for one chunk (index_part.hpp).  The
+// filter must have been zeroed on the stream before.  kmers = exact number of
+// complete k-mers of the selected reads of [first, first+count).
+int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                             uint64_t kmers, bool additive)
+{
+    if (count == 0 || kmers == 0) return 0;
+    const PartGeom g = make_geom(c->k);
+    const uint64_t total = 4 * kmers;
+    if (c->part_nb != g.nb) {
+        (void) hipFree(c->part_hist); (void) hipFree(c->part_wl); (void) hipFree(c->part_off);
+        (void) hipFree(c->part_cur1); (void) hipFree(c->part_cur2);
+        c->part_hist = c->part_wl = nullptr; c->part_off = nullptr; c->part_cur1 = c->part_cur2 = nullptr;
+        HIP_OK(hipMalloc((void **) &c->part_hist, (g.nb + 1) * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &c->part_wl, (g.nb + 1) * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &c->part_off, (g.nb + 1) * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void **) &c->part_cur1, MAX_L1 * sizeof(unsigned long long)));
+        HIP_OK(hipMalloc((void **) &c->part_cur2, g.nb * sizeof(unsigned long long)));
+        c->part_nb = g.nb;
+    }
+    if (c->part_cap_keys < total) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) hipFree(c->part_bufA); (void) hipFree(c->part_bufB);
+        c->part_bufA = c->part_bufB = nullptr;
+        c->part_cap_keys = 0;
+        const uint64_t cap = total + total / 16 + 4096;
+        HIP_OK(hipMalloc((void **) &c->part_bufA, cap * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &c->part_bufB, cap * sizeof(uint32_t)));
+        c->part_cap_keys = cap;
+    }
+    const bool wide = c->k > 32;
+    HIP_OK(hipMemsetAsync(c->part_hist, 0, (g.nb + 1) * sizeof(uint32_t), c->stream));
+    // hist
+    {
+        const unsigned grid = (unsigned) std::min<uint64_t>(256, (count + 255) / 256);
+        for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
+            const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
+            const size_t lds = ((size_t) n_b + 524) * 4 + 256 * 8;
+            HIP_OK(hipFuncSetAttribute(wide ? (const void *) part_hist_kernel<uint64_t> : (const void *) part_hist_kernel<uint32_t>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            if (wide)
+                hipLaunchKernelGGL(part_hist_kernel<uint64_t>, dim3(grid), dim3(256), lds, c->stream, rs->view(), rs->d_kcnt,
+                                   d_sel, first, count, g, b_lo, n_b, c->part_hist);
+            else
+                hipLaunchKernelGGL(part_hist_kernel<uint32_t>, dim3(grid), dim3(256), lds, c->stream, rs->view(), rs->d_kcnt,
+                                   d_sel, first, count, g, b_lo, n_b, c->part_hist);
+            HIP_OK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, c->part_off, c->part_cur1,
+                       c->part_cur2, c->part_wl);
+    HIP_OK(hipGetLastError());
+    // scatter 1 (straight into the final buckets when there is a single level)
+    uint32_t *level1_out = g.b2 ? c->part_bufA : c->part_bufB;
+    {
+        const unsigned grid = (unsigned) std::min<uint64_t>(512, (count + 63) / 64);
+        if (wide)
+            hipLaunchKernelGGL(part_scatter1_kernel<uint64_t>, dim3(grid), dim3(256), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
+                               first, count, g, c->part_cur1, level1_out);
+        else
+            hipLaunchKernelGGL(part_scatter1_kernel<uint32_t>, dim3(grid), dim3(256), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
+                               first, count, g, c->part_cur1, level1_out);
+        HIP_OK(hipGetLastError());
+    }
+    if (g.b2) {
+        const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
+        if (grid >= (1ull << 24)) return fail("scatter launch too large");
+        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(256), 0, c->stream, c->part_bufA, c->part_bufB,
+                           c->part_off, g, c->part_cur2, total);
+        HIP_OK(hipGetLastError());
+    }
+    {
+        const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
+        if (grid >= (1ull << 24)) return fail("build launch too large");
+        HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int) (TILE_WORDS * sizeof(uint32_t))));
+        hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), c->stream,
+                           c->part_bufB, c->part_off, c->part_wl, g, c->filter, additive ? 1 : 0);
+        HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+// kmers: exact complete-k-mer count of the launch when known (enables the bucketed path), else ~0
+int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false)
+{
+    bool part = false;
+    if (c->index_mode == 2) {
+        if (!partition_eligible(c, rs)) return fail("bucketed index construction needs 20 <= k <= 34 and reads of at most %u k-mers", S1_KEYS / 4);
+        if (kmers == ~0ull) return fail("bucketed index construction needs the k-mer count of the launch");
+        part = true;
+    } else if (c->index_mode == 0) {
+        part = partition_eligible(c, rs) && kmers != ~0ull && kmers >= c->part_min_kmers;
+    }
+    if (!part) return launch_index_atomic(c, rs, first, count, d_sel, d_fed);
+    if (d_fed) {
+        // the count is known exactly on the host
+        const unsigned long long v = kmers;
+        HIP_OK(hipMemcpyAsync(d_fed, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter);
 }
 
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
@@ -490,7 +622,11 @@ int commet_index_reads(commet_ctx *c, const commet_readset *rs, uint64_t first, 
         d_fed = c->d_counters;
     }
     HIP_OK(hipEventRecord(c->ev_i0, c->stream));
-    if (launch_index(c, rs, first, count, d_sel, d_fed)) return 1;
+    // exact k-mer count of the launch (host copy of the per-read counts): lets the bucketed path run
+    uint64_t kmers = 0;
+    for (uint64_t r = first; r < first + count; ++r)
+        if (!select_bits || bit_at(select_bits, r)) kmers += rs->h_kcnt[r];
+    if (launch_index(c, rs, first, count, d_sel, d_fed, kmers, false)) return 1;
     HIP_OK(hipEventRecord(c->ev_i1, c->stream));
     c->have_index_ev = true;
     if (kmers_fed) {
@@ -546,14 +682,19 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     HIP_OK(hipSetDevice(c->device));
 
     // host plan: chunks of the index set, visited reads of each search set
-    const IndexPlan plan = plan_index(index_rs->files, index_select, index_rs->empty_reads, index_rs->h_kcnt.data(),
-                                      index_rs->n_reads, commet_max_kmer(c));
+    const uint64_t max_kmer = commet_max_kmer(c);
+    const IndexPlan plan = plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
+                               ? plan_index_fast(index_rs->h_kprefix, index_rs->n_reads, max_kmer)
+                               : plan_index(index_rs->files, index_select, index_rs->empty_reads, index_rs->h_kcnt.data(),
+                                            index_rs->n_reads, max_kmer);
     std::vector<uint64_t> visited(n_search, 0);
     std::vector<std::vector<uint8_t>> vis(n_search);
     if (upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
     for (int s = 0; s < n_search; ++s) {
         const commet_readset *rs = search_rs[s];
-        vis[s] = plan_search(rs->files, search_select ? search_select[s] : nullptr, rs->empty_reads, rs->n_reads, &visited[s]);
+        const uint8_t *ssel = search_select ? search_select[s] : nullptr;
+        vis[s] = plan_fast_ok(rs->files, ssel, rs->empty_reads, 1) ? plan_search_fast(rs->n_reads, &visited[s])
+                                                                    : plan_search(rs->files, ssel, rs->empty_reads, rs->n_reads, &visited[s]);
         if (upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
         HIP_OK(hipMemsetAsync(rs->d_tags, 0, bitmap_words(rs->n_reads) * 8, c->stream));
     }
@@ -593,7 +734,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         if (commet_filter_reset(c)) { rc = 1; break; }                       // new BloomFilter per chunk
         if (timed) (void) hipEventRecord(z, c->stream);
         if (ch.n_reads) {
-            if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr)) { rc = 1; break; }
+            if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true)) { rc = 1; break; }
             ++n_index_launches;
         }
         if (timed) {
@@ -689,6 +830,15 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
 {
     if (!strcmp(name, "count_probes")) {
         c->count_probes = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "index_mode")) {        // 0 auto, 1 atomic kernel, 2 bucketed construction
+        if (value < 0 || value > 2) return fail("index_mode must be 0, 1 or 2");
+        c->index_mode = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "part_min_kmers")) {    // auto mode: chunks with fewer k-mers use the atomic kernel
+        c->part_min_kmers = (uint64_t) value;
         return 0;
     }
     return fail("unknown option '%s'", name);

@@ -1,0 +1,526 @@
+// index_part.hpp — bucketed construction of the 4-lane Bloom filter (gfx950).
+//
+// Why: setting 4 random bits per k-mer with global atomics runs at the memory
+// system's atomic rate (~18 G atomic ORs/s on a 2 GiB table, measured,
+// profiles/r01_membench_random_access.jsonl), i.e. ~150 ms for the 6.7e8 k-mers
+// of BASELINE configs[1].  LDS atomics are two orders of magnitude faster, so
+// the filter is built tile by tile in LDS instead:
+//
+//   tile     = 2^19 consecutive bits of one plane (64 KiB of LDS)
+//   bucket   = (plane, key >> 19)                      NB = 4 * 2^(k-19) buckets
+//   hist     : count the keys of every bucket           (LDS histogram, 1 pass over the reads)
+//   scan     : exclusive scan -> exact bucket offsets, cursors, build work list
+//   scatter1 : keys -> 2^b1 coarse buckets (top b1 bits of the bucket id); per
+//              block an LDS counting sort, runs written coalesced     (bufA)
+//   scatter2 : every coarse bucket -> its 2^b2 final buckets, same scheme (bufB)
+//   build    : one workgroup per (tile, split): ds_or the bucket's keys into a
+//              zeroed LDS tile, write the tile to the filter with plain
+//              coalesced stores (tiles whose bucket is split over several
+//              workgroups OR their non-zero words in with atomics instead)
+//
+// All traffic is streaming: 2 x 4 B per key and level, plus the filter once.
+// Results are bit-identical to the atomic path (set semantics); which path runs
+// is a host decision (capi.hip: use_partition()).
+//
+// Replaces: BloomFilter::feed (bloom_filter.h:112-118) applied by index_reads
+// (index_reads.h:51-59) to a whole chunk.
+#pragma once
+
+#include "kernels.hpp"
+
+namespace commet {
+
+constexpr int      TILE_BITS = 19;
+constexpr uint32_t TILE_MASK = (1u << TILE_BITS) - 1;
+constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 KiB
+constexpr uint32_t S1_KEYS = 12288;                         // keys staged per scatter-1 round (48 KiB)
+constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (32 per thread)
+constexpr uint32_t S2_PER_THREAD = S2_KEYS / 256;
+constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build workgroup
+constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
+constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
+constexpr uint32_t MAX_L1 = 256;                            // 2^b1 upper bound
+
+struct PartGeom {
+    int      k;
+    int      nb_bits;    // log2(number of buckets) = k - 17
+    int      b1, b2;     // level-1 / level-2 radix bits (b2 may be 0)
+    uint32_t nb;         // buckets
+    uint32_t nb1;        // coarse buckets
+    int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
+};
+
+inline PartGeom make_geom(int k)
+{
+    PartGeom g;
+    g.k = k;
+    g.nb_bits = k - 17;
+    g.b1 = g.nb_bits <= 8 ? g.nb_bits : (g.nb_bits + 1) / 2;
+    if (g.b1 > 8) g.b1 = 8;
+    g.b2 = g.nb_bits - g.b1;
+    g.nb = 1u << g.nb_bits;
+    g.nb1 = 1u << g.b1;
+    g.plane_shift = k - TILE_BITS;
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// direct window extraction: the k-mer ending at base p = 32*w + j of a read,
+// from the word triples w-2, w-1, w (no serial rolling: any lane, any position)
+// ---------------------------------------------------------------------------
+template <typename W> struct ItemWords;
+template <> struct ItemWords<uint32_t> {
+    uint32_t hi[2], lo[2], va[2];   // [0] = word w-1, [1] = word w
+    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
+    {
+        hi[1] = p[3 * w], lo[1] = p[3 * w + 1], va[1] = p[3 * w + 2];
+        if (w) hi[0] = p[3 * w - 3], lo[0] = p[3 * w - 2], va[0] = p[3 * w - 1];
+        else hi[0] = lo[0] = va[0] = 0;
+    }
+    // window of the k bases ending at bit j of word w; false if any is not ACGT
+    __device__ __forceinline__ bool window(uint32_t j, int k, uint32_t mask, uint32_t &wh, uint32_t &wl) const
+    {
+        const uint32_t s = 33u + j - (uint32_t) k;   // 1..32
+        const uint32_t v = (uint32_t) ((((uint64_t) va[1] << 32) | va[0]) >> s) & mask;
+        wh = (uint32_t) ((((uint64_t) hi[1] << 32) | hi[0]) >> s) & mask;
+        wl = (uint32_t) ((((uint64_t) lo[1] << 32) | lo[0]) >> s) & mask;
+        return v == mask;
+    }
+};
+template <> struct ItemWords<uint64_t> {
+    uint32_t hi[3], lo[3], va[3];   // words w-2, w-1, w
+    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
+    {
+        hi[2] = p[3 * w], lo[2] = p[3 * w + 1], va[2] = p[3 * w + 2];
+        if (w) hi[1] = p[3 * w - 3], lo[1] = p[3 * w - 2], va[1] = p[3 * w - 1];
+        else hi[1] = lo[1] = va[1] = 0;
+        if (w > 1) hi[0] = p[3 * w - 6], lo[0] = p[3 * w - 5], va[0] = p[3 * w - 4];
+        else hi[0] = lo[0] = va[0] = 0;
+    }
+    __device__ __forceinline__ static uint64_t ext(const uint32_t *x, uint32_t s, uint64_t mask)
+    {
+        const uint64_t lo64 = ((uint64_t) x[1] << 32) | x[0];
+        return ((lo64 >> s) | ((uint64_t) x[2] << (64 - s))) & mask;   // 27 <= s <= 63 for 33 <= k <= 38
+    }
+    __device__ __forceinline__ bool window(uint32_t j, int k, uint64_t mask, uint64_t &wh, uint64_t &wl) const
+    {
+        const uint32_t s = 65u + j - (uint32_t) k;
+        wh = ext(hi, s, mask);
+        wl = ext(lo, s, mask);
+        return ext(va, s, mask) == mask;
+    }
+};
+
+// calls f(plane, key) for the 4 forward keys of every complete k-mer of item (read, word w)
+template <typename W, typename F>
+__device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t w, int k, F &&f)
+{
+    using T = KeyTraits<W>;
+    ItemWords<W> it;
+    it.load(p, w);
+    const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+    const int sh = T::BITS - k;
+    const uint32_t nb = min(32u, len - 32u * w);
+    for (uint32_t j = 0; j < nb; ++j) {
+        if (32u * w + j + 1u < (uint32_t) k) continue;
+        W wh, wl;
+        if (!it.window(j, k, mask, wh, wl)) continue;
+        const W ka = T::brev(wh) >> sh;
+        const W kb = T::brev(wl) >> sh;
+        f(0u, ka);
+        f(1u, kb);
+        f(2u, ka ^ kb);
+        f(3u, ka | kb);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// block-level helpers (256 threads)
+// ---------------------------------------------------------------------------
+// exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *wsum /* 4 words of LDS */, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = wsum[i];
+        if (i < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// in-place exclusive scan of cnt[0..n) (n <= 1024, multiple of... any), into base[]; 256 threads
+__device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, uint32_t n, uint32_t *wsum)
+{
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t b = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b + i < n) s += cnt[b + i];
+    uint32_t tot;
+    uint32_t ex = block_scan_256(s, wsum, &tot);
+    for (uint32_t i = 0; i < per; ++i)
+        if (b + i < n) {
+            base[b + i] = ex;
+            ex += cnt[b + i];
+        }
+    __syncthreads();
+}
+
+// Picks the next reads [r, r + R) of a block's range whose keys fit `cap`
+// (R <= 256, at least 1 when the range is not empty) and builds the item
+// table: istart[i] = first item of read i, one item per 32-base word.
+// kms = 4 * complete k-mers of read r+i (0 if not selected).
+struct RoundPlan {
+    uint32_t n_reads;
+    uint32_t n_items;
+};
+
+__device__ __forceinline__ RoundPlan plan_round(const ReadsView &rv, const uint32_t *__restrict__ kcnt,
+                                                const uint64_t *__restrict__ sel, uint64_t r, uint64_t r_end,
+                                                uint32_t cap, uint32_t *istart /* 257 */, uint32_t *rd_len /* 256 */,
+                                                uint64_t *rd_t0 /* 256 */, uint32_t *wsum, uint32_t *sh_n)
+{
+    const uint64_t me = r + threadIdx.x;
+    uint32_t keys = 0, items = 0, len = 0;
+    uint64_t t0 = 0;
+    if (me < r_end) {
+        const bool on = !sel || ((sel[me >> 6] >> (me & 63)) & 1ull);
+        const uint32_t km = on ? kcnt[me] : 0;
+        if (km) {
+            read_extent(rv, me, t0, len);
+            keys = 4 * km;
+            items = (len + 31) >> 5;
+        }
+    }
+    uint32_t tot;
+    const uint32_t kex = block_scan_256(keys, wsum, &tot);
+    // reads whose inclusive key prefix fits; a read past the range has keys = 0 and is cut below
+    const bool fits = (kex + keys <= cap) && (me < r_end);
+    if (threadIdx.x == 0) *sh_n = 0;
+    __syncthreads();
+    if (fits) atomicMax(sh_n, threadIdx.x + 1);   // prefix property: fits is monotone non-increasing
+    __syncthreads();
+    uint32_t R = *sh_n;
+    if (R == 0 && r < r_end) R = 1;               // oversize read: the host never sends those here
+    if (threadIdx.x >= R) items = 0;
+    uint32_t itot;
+    const uint32_t iex = block_scan_256(items, wsum, &itot);
+    istart[threadIdx.x] = iex;
+    rd_len[threadIdx.x] = len;
+    rd_t0[threadIdx.x] = t0;
+    if (threadIdx.x == 0) istart[256] = itot;
+    __syncthreads();
+    RoundPlan p;
+    p.n_reads = R;
+    p.n_items = itot;
+    return p;
+}
+
+// item id -> (read slot, word) by binary search in istart[0..R]
+__device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, uint32_t id, uint32_t &slot, uint32_t &w)
+{
+    uint32_t lo = 0, hi = R;   // largest slot with istart[slot] <= id
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (istart[mid] <= id) lo = mid;
+        else hi = mid;
+    }
+    slot = lo;
+    w = id - istart[lo];
+}
+
+// ---------------------------------------------------------------------------
+// hist: bucket histogram of the chunk, buckets [b_lo, b_lo + n_b) in LDS
+// ---------------------------------------------------------------------------
+template <typename W>
+__global__ __launch_bounds__(256) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
+                                                        const uint64_t *__restrict__ sel, uint64_t first, uint64_t count,
+                                                        PartGeom g, uint32_t b_lo, uint32_t n_b,
+                                                        uint32_t *__restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *h = smem;                          // n_b counters
+    uint32_t *istart = h + n_b;                  // 257
+    uint32_t *rd_len = istart + 260;             // 256
+    uint32_t *wsum = rd_len + 256;               // 4
+    uint32_t *sh_n = wsum + 4;                   // 1 (+3 pad)
+    uint64_t *rd_t0 = (uint64_t *) (sh_n + 4);   // 256
+    for (uint32_t i = threadIdx.x; i < n_b; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
+    uint64_t r = first + blockIdx.x * per;
+    const uint64_t r_end = min(first + count, r + per);
+    while (r < r_end) {
+        const RoundPlan rp = plan_round(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, istart, rd_len, rd_t0, wsum, sh_n);
+        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
+            uint32_t slot, w;
+            item_lookup(istart, rp.n_reads, id, slot, w);
+            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
+                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+                const uint32_t rel = b - b_lo;
+                if (rel < n_b) atomicAdd(&h[rel], 1u);
+            });
+        }
+        __syncthreads();
+        r += rp.n_reads;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_b; i += 256) {
+        const uint32_t v = h[i];
+        if (v) atomicAdd(&hist[b_lo + i], v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan: bucket offsets, cursors, build work list.  One block of 1024 threads.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ hist, PartGeom g,
+                                                         uint64_t *__restrict__ off /* nb+1 */,
+                                                         unsigned long long *__restrict__ cursor1 /* nb1 */,
+                                                         unsigned long long *__restrict__ cursor2 /* nb */,
+                                                         uint32_t *__restrict__ wl_off /* nb+1 */)
+{
+    __shared__ uint64_t s_sum[1024];
+    __shared__ uint32_t s_wl[1024];
+    const uint32_t per = (g.nb + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t s = 0;
+    uint32_t wl = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < g.nb) {
+            const uint32_t c = hist[b0 + i];
+            s += c;
+            wl += (c + BUILD_CAP - 1) / BUILD_CAP;   // empty buckets need no workgroup
+        }
+    s_sum[threadIdx.x] = s;
+    s_wl[threadIdx.x] = wl;
+    __syncthreads();
+    // Hillis-Steele over 1024 partials
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint64_t a = 0;
+        uint32_t b = 0;
+        if (threadIdx.x >= o) {
+            a = s_sum[threadIdx.x - o];
+            b = s_wl[threadIdx.x - o];
+        }
+        __syncthreads();
+        s_sum[threadIdx.x] += a;
+        s_wl[threadIdx.x] += b;
+        __syncthreads();
+    }
+    uint64_t ex = s_sum[threadIdx.x] - s;
+    uint32_t wex = s_wl[threadIdx.x] - wl;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < g.nb) {
+            const uint32_t b = b0 + i;
+            const uint32_t c = hist[b];
+            off[b] = ex;
+            cursor2[b] = ex;
+            if ((b & ((1u << g.b2) - 1)) == 0) cursor1[b >> g.b2] = ex;
+            wl_off[b] = wex;
+            ex += c;
+            wex += (c + BUILD_CAP - 1) / BUILD_CAP;
+        }
+    if (threadIdx.x == 1023) {
+        off[g.nb] = s_sum[1023];
+        wl_off[g.nb] = s_wl[1023];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scatter1: reads -> keys -> 2^b1 coarse buckets (LDS counting sort per round)
+// payload = ((bucket & (2^b2 - 1)) << 19) | (key & TILE_MASK)
+// ---------------------------------------------------------------------------
+template <typename W>
+__global__ __launch_bounds__(256) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
+                                                            const uint64_t *__restrict__ sel, uint64_t first,
+                                                            uint64_t count, PartGeom g,
+                                                            unsigned long long *__restrict__ cursor1,
+                                                            uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t sorted[S1_KEYS];
+    __shared__ uint32_t cnt[MAX_L1], base[MAX_L1], fill[MAX_L1];
+    __shared__ unsigned long long gbase[MAX_L1];
+    __shared__ uint32_t istart[260], rd_len[256], wsum[4], sh_n[4];
+    __shared__ uint64_t rd_t0[256];
+    const uint32_t sub_mask = (1u << g.b2) - 1;
+    const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
+    uint64_t r = first + blockIdx.x * per;
+    const uint64_t r_end = min(first + count, r + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    while (r < r_end) {
+        const RoundPlan rp = plan_round(rv, kcnt, sel, r, r_end, S1_KEYS, istart, rd_len, rd_t0, wsum, sh_n);
+        if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
+        __syncthreads();
+        // pass A: count
+        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
+            uint32_t slot, w;
+            item_lookup(istart, rp.n_reads, id, slot, w);
+            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
+                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+                atomicAdd(&cnt[b >> g.b2], 1u);
+            });
+        }
+        __syncthreads();
+        lds_scan(cnt, base, g.nb1, wsum);
+        if (threadIdx.x < g.nb1) {
+            const uint32_t c = cnt[threadIdx.x];
+            gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
+        }
+        // pass B: place (keys recomputed; only the counts have to agree with pass A)
+        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
+            uint32_t slot, w;
+            item_lookup(istart, rp.n_reads, id, slot, w);
+            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
+                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+                const uint32_t c1 = b >> g.b2;
+                const uint32_t pos = base[c1] + atomicAdd(&fill[c1], 1u);
+                if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
+            });
+        }
+        __syncthreads();
+        // write-out: one wave per run, consecutive lanes -> consecutive addresses
+        for (uint32_t c1 = wave; c1 < g.nb1; c1 += 4) {
+            const uint32_t n = cnt[c1], src = base[c1];
+            const unsigned long long dst = gbase[c1];
+            for (uint32_t i = lane; i < n; i += 64) out[dst + i] = sorted[src + i];
+        }
+        __syncthreads();
+        r += rp.n_reads;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scatter2: coarse buckets -> final buckets.  Flat grid over bufA; a slab that
+// straddles coarse buckets is processed segment by segment.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                            const uint64_t *__restrict__ off, PartGeom g,
+                                                            unsigned long long *__restrict__ cursor2, uint64_t total)
+{
+    __shared__ uint32_t sorted[S2_KEYS];
+    __shared__ uint32_t cnt[MAX_SUB], base[MAX_SUB], fill[MAX_SUB];
+    __shared__ unsigned long long gbase[MAX_SUB];
+    __shared__ uint32_t wsum[4];
+    const uint32_t nsub = 1u << g.b2;
+    const uint64_t s0 = (uint64_t) blockIdx.x * S2_KEYS;
+    if (s0 >= total) return;
+    const uint64_t s1 = min(total, s0 + S2_KEYS);
+    // coarse bucket containing s0: largest c with off[c << b2] <= s0
+    uint32_t lo = 0, hi = g.nb1;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[(uint64_t) mid << g.b2] <= s0) lo = mid;
+        else hi = mid;
+    }
+    uint32_t c1 = lo;
+    uint64_t pos = s0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    while (pos < s1) {
+        const uint64_t c_end = off[(uint64_t) (c1 + 1) << g.b2];
+        const uint64_t seg_end = min(s1, c_end);
+        if (seg_end <= pos) {   // empty coarse bucket
+            ++c1;
+            continue;
+        }
+        const uint32_t n = (uint32_t) (seg_end - pos);
+        for (uint32_t i = threadIdx.x; i < nsub; i += 256) cnt[i] = 0, fill[i] = 0;
+        __syncthreads();
+        uint32_t key[S2_PER_THREAD];
+#pragma unroll
+        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+            const uint32_t i = threadIdx.x + 256 * q;
+            key[q] = i < n ? in[pos + i] : 0xFFFFFFFFu;
+            if (i < n) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+        }
+        __syncthreads();
+        lds_scan(cnt, base, nsub, wsum);
+        for (uint32_t i = threadIdx.x; i < nsub; i += 256) {
+            const uint32_t c = cnt[i];
+            gbase[i] = c ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], (unsigned long long) c) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+            const uint32_t i = threadIdx.x + 256 * q;
+            if (i < n) {
+                const uint32_t sb = key[q] >> TILE_BITS;
+                sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
+            }
+        }
+        __syncthreads();
+        for (uint32_t sb = wave; sb < nsub; sb += 4) {
+            const uint32_t m = cnt[sb], src = base[sb];
+            const unsigned long long dst = gbase[sb];
+            for (uint32_t i = lane; i < m; i += 64) out[dst + i] = sorted[src + i];
+        }
+        __syncthreads();
+        pos = seg_end;
+        if (pos >= c_end) ++c1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// build: (tile, split) work items -> LDS tile -> filter
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restrict__ keys,
+                                                         const uint64_t *__restrict__ off,
+                                                         const uint32_t *__restrict__ wl_off, PartGeom g,
+                                                         uint32_t *__restrict__ filter, int additive)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // TILE_WORDS
+    const uint32_t total_items = wl_off[g.nb];
+    if (blockIdx.x >= total_items) return;
+    // bucket with wl_off[b] <= blockIdx.x < wl_off[b+1]
+    uint32_t lo = 0, hi = g.nb;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (wl_off[mid] <= blockIdx.x) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t b = lo;
+    const uint32_t split = blockIdx.x - wl_off[b];
+    const uint32_t n_split = wl_off[b + 1] - wl_off[b];
+    const uint64_t k0 = off[b] + (uint64_t) split * BUILD_CAP;
+    const uint64_t k1 = min(off[b + 1], k0 + BUILD_CAP);
+    uint4 *t4 = (uint4 *) tile;
+    for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) t4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint64_t i = k0 + threadIdx.x; i < k1; i += 256) {
+        const uint32_t key = keys[i];
+        atomicOr(&tile[key >> 5], 1u << (key & 31u));
+    }
+    __syncthreads();
+    // bucket b = (plane << plane_shift) | tile index: its words sit at b * TILE_WORDS of the 4-plane array
+    uint32_t *dst = filter + (uint64_t) b * TILE_WORDS;
+    if (n_split == 1) {
+        uint4 *d4 = (uint4 *) dst;
+        if (additive) {   // the filter already holds bits (commet_index_reads called again without a reset)
+            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) {
+                uint4 o = d4[i];
+                const uint4 n = t4[i];
+                o.x |= n.x, o.y |= n.y, o.z |= n.z, o.w |= n.w;
+                d4[i] = o;
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) d4[i] = t4[i];
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < TILE_WORDS; i += 256) {
+            const uint32_t v = tile[i];
+            if (v) (void) __hip_atomic_fetch_or(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace commet

@@ -191,4 +191,69 @@ inline std::vector<uint8_t> plan_search(const std::vector<FileSpan> &files, cons
     return bits;
 }
 
+// ---------------------------------------------------------------------------
+// Fast plans for the common case: no input filter, no empty sequence, no empty
+// file.  Then the iterator yields reads 0,1,2,... one per call, and the chunk
+// boundaries follow from prefix sums of the per-read k-mer counts:
+//   chunk [s, e-1], e = first index with P[e] - P[s] >= max_kmer (or n),
+//   read e is the dropped look-ahead, next chunk starts at e+1; the loop of
+//   main() ends when e+1 >= n (index_and_search.cpp:255).
+// Must agree with plan_index / plan_search exactly (tests/test_host_plan.py).
+// ---------------------------------------------------------------------------
+inline bool plan_fast_ok(const std::vector<FileSpan> &files, const uint8_t *select,
+                         const std::vector<uint64_t> &empty_reads, uint64_t max_kmer)
+{
+    if (select || !empty_reads.empty() || max_kmer == 0 || files.empty()) return false;
+    for (const FileSpan &f : files)
+        if (f.count == 0) return false;
+    return true;
+}
+
+inline void build_kmer_prefix(const uint32_t *kcnt, uint64_t n_reads, std::vector<uint64_t> &prefix)
+{
+    prefix.resize(n_reads + 1);
+    uint64_t s = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        prefix[i] = s;
+        s += kcnt[i];
+    }
+    prefix[n_reads] = s;
+}
+
+inline IndexPlan plan_index_fast(const std::vector<uint64_t> &prefix, uint64_t n_reads, uint64_t max_kmer)
+{
+    IndexPlan plan;
+    plan.indexed_bits.assign(n_reads / 8 + 1, 0);
+    for (uint64_t i = 0; i < n_reads / 8; ++i) plan.indexed_bits[i] = 0xFF;
+    for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i) bit_on(plan.indexed_bits.data(), i);
+    uint64_t s = 0;
+    while (s < n_reads) {
+        const uint64_t target = prefix[s] + max_kmer;
+        // first e in (s, n] with prefix[e] >= target
+        const uint64_t *b = prefix.data() + s + 1, *e_ptr = prefix.data() + n_reads + 1;
+        const uint64_t *it = std::lower_bound(b, e_ptr, target);
+        const uint64_t e = it == e_ptr ? n_reads : (uint64_t) (it - prefix.data());
+        Chunk ch;
+        ch.first = s;
+        ch.last = e - 1;
+        ch.n_reads = e - s;
+        ch.kmers = prefix[e] - prefix[s];
+        plan.chunks.push_back(ch);
+        plan.indexed_reads += ch.n_reads;
+        plan.kmers += ch.kmers;
+        if (e < n_reads) plan.indexed_bits[e >> 3] &= (uint8_t) ~(1u << (e & 7));   // dropped look-ahead read
+        s = e + 1;
+    }
+    return plan;
+}
+
+inline std::vector<uint8_t> plan_search_fast(uint64_t n_reads, uint64_t *n_visited)
+{
+    std::vector<uint8_t> bits(n_reads / 8 + 1, 0);
+    for (uint64_t i = 0; i < n_reads / 8; ++i) bits[i] = 0xFF;
+    for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i) bit_on(bits.data(), i);
+    if (n_visited) *n_visited = n_reads;
+    return bits;
+}
+
 }  // namespace commet

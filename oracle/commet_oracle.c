@@ -614,6 +614,31 @@ static int ok_read_sets(const char *path, ok_set **out)
 /* index_reads / search_reads over a FileManager                            */
 /* ======================================================================== */
 
+/* ---- optional chunk trace (for testing the host-side chunk planner) ---- */
+static uint64_t *g_trace = NULL;      /* 4 values per chunk: first, last, n_reads, kmers (set-wide read numbers) */
+static uint64_t g_trace_cap = 0, g_trace_n = 0;
+
+void ok_trace_begin(uint64_t *buf, uint64_t cap_chunks)
+{
+    g_trace = buf;
+    g_trace_cap = cap_chunks;
+    g_trace_n = 0;
+}
+
+uint64_t ok_trace_end(void)
+{
+    g_trace = NULL;
+    return g_trace_n;
+}
+
+static uint64_t fm_current_read_number(const ok_fm *m)
+{
+    int cf = m->current_file < m->nfiles ? m->current_file : m->nfiles - 1;
+    uint64_t base = 0;
+    for (int i = 0; i < cf; i++) base += m->files[i].nb_reads;
+    return base + m->files[cf].pos;
+}
+
 /* index_reads.h:41-63 */
 static ok_bloom *ok_index_reads(ok_fm *m, int k, uint64_t max_kmer, uint64_t *nb_indexed_reads, uint64_t *kmers_total)
 {
@@ -623,12 +648,25 @@ static ok_bloom *ok_index_reads(ok_fm *m, int k, uint64_t max_kmer, uint64_t *nb
     if (!f) exit(1);
     ok_hash_init(&h, k);
     uint64_t len;
+    uint64_t tr_first = 0, tr_last = 0, tr_n = 0;
     const char *read = ok_fm_next(m, &len);
     while (len != 0 && nb_indexed_kmers < max_kmer) {
         (*nb_indexed_reads)++;
+        if (g_trace) {
+            tr_last = fm_current_read_number(m);
+            if (tr_n == 0) tr_first = tr_last;
+            tr_n++;
+        }
         nb_indexed_kmers += index_one_read(f, &h, k, read, len);
         read = ok_fm_next(m, &len);      /* look-ahead fetch BEFORE the test (Q1) */
     }
+    if (g_trace && g_trace_n < g_trace_cap) {
+        g_trace[4 * g_trace_n + 0] = tr_first;
+        g_trace[4 * g_trace_n + 1] = tr_last;
+        g_trace[4 * g_trace_n + 2] = tr_n;
+        g_trace[4 * g_trace_n + 3] = nb_indexed_kmers;
+    }
+    if (g_trace) g_trace_n++;
     if (kmers_total) *kmers_total += nb_indexed_kmers;
     return f;
 }

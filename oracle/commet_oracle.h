@@ -101,6 +101,12 @@ int ok_index_and_search(const char *index_cfg, const char *search_cfg,
                         ok_set_result *results, int cap, int *n_results,
                         uint64_t *n_chunks, uint64_t *kmers_indexed, int quiet);
 
+/* Chunk trace of the next ok_index_and_search call: 4 values per chunk
+ * (first, last set-wide read number, reads, k-mers).  ok_trace_end returns the
+ * number of chunks seen. */
+void     ok_trace_begin(uint64_t *buf, uint64_t cap_chunks);
+uint64_t ok_trace_end(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,10 +21,10 @@ def _load_set(commet, ctx, files, sdir):
     return rs, (util.bits_from_bools(sel) if has_bv else None)
 
 
-@pytest.mark.parametrize("seed", range(60))
-def test_job_matches_oracle(tmp_path, seed):
+@pytest.mark.parametrize("seed,index_mode", [(s, 0) for s in range(60)] + [(s, 2) for s in range(60, 80)])
+def test_job_matches_oracle(tmp_path, seed, index_mode):
     import commet_amd as commet
-    scn = Scenario(str(tmp_path / "scn"), seed)
+    scn = Scenario(str(tmp_path / "scn"), seed, k=None if index_mode == 0 else [20, 21, 24, 25][seed % 4])
     out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
     rc, res, chunks, kmers = run_oracle(scn, out_o, log_o)
     assert rc == 0
@@ -36,6 +36,7 @@ def test_job_matches_oracle(tmp_path, seed):
             srs.append(r)
             ssel.append(s)
         ctx.set_option("count_probes", 1)
+        ctx.set_option("index_mode", index_mode)
         tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
         assert info["probes"] == sum(r["probes"] for r in res)        # P_ref: the reference's own probe count
         assert info["n_chunks"] == chunks

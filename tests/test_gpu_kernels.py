@@ -181,3 +181,59 @@ def test_errors_are_loud(commet):
         with pytest.raises(commet.CommetError):
             ctx.index_reads(rs, 0, 5)    # out of range
         rs.close()
+
+
+@pytest.mark.parametrize("k", [20, 21, 24, 26, 28])
+def test_bucketed_index_matches_oracle(commet, k):
+    """index_mode=2: the LDS-tile construction (index_part.hpp) must give the very same filter bits"""
+    reads = _mixed_reads(300 + k, n=3000, hi=160)
+    bases, offs = util.to_batch(reads)
+    rng = np.random.default_rng(k)
+    sel = rng.random(len(reads)) < 0.8
+    with commet.Context(k=k, t=2) as ctx:
+        ctx.set_option("index_mode", 2)
+        rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+        ctx.filter_reset()
+        fed = ctx.index_reads(rs)
+        f = ob.Bloom(k)
+        assert fed == f.index(bases, offs)
+        assert np.array_equal(ctx.export_filter_reference(), f.bytes())
+        # range + select, then a second additive call on the rest: union must equal the oracle's union
+        ctx.filter_reset()
+        sb = util.bits_from_bools(sel)
+        ctx.index_reads(rs, 100, 1900, sb)
+        ctx.index_reads(rs, 2000, 1000, sb)
+        f2 = ob.Bloom(k)
+        s2 = sel.copy()
+        s2[:100] = False
+        f2.index(bases, offs, util.bits_from_bools(s2))
+        assert np.array_equal(ctx.export_filter_reference(), f2.bytes())
+        rs.close()
+
+
+@pytest.mark.parametrize("k", [30, 32, 33])
+def test_bucketed_index_equals_atomic_index_large_k(commet, k):
+    """two-level radix geometry (k >= 26) incl. 64-bit keys; skewed input makes split tiles"""
+    rng = np.random.default_rng(k)
+    reads = util.random_reads(rng, 40000, 60, 120, n_rate=0.005)
+    reads += [b"A" * 150] * 3000 + [b"ACGT" * 30] * 2000 + [b"T" * 100 + b"G" * 40] * 1500     # hot buckets
+    bases, offs = util.to_batch(reads)
+    q = util.related_reads(rng, reads[:5000], 8000, 40, 120, share=0.5)
+    qb, qo = util.to_batch(q)
+    out = []
+    for mode in (1, 2):
+        with commet.Context(k=k, t=2) as ctx:
+            ctx.set_option("index_mode", mode)
+            rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+            qs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+            ctx.filter_reset()
+            fed = ctx.index_reads(rs)
+            found, _, nfound = ctx.search_reads(qs)
+            out.append((fed, nfound, found, ctx.export_filter_reference() if k <= 32 else None))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+    if k <= 32:
+        assert np.array_equal(out[0][3], out[1][3])
+        f = ob.Bloom(k)
+        f.index(bases, offs)
+        assert np.array_equal(out[1][3], f.bytes())
