@@ -118,6 +118,7 @@ struct commet_readset {
     std::vector<uint64_t> h_kprefix;   // prefix sums of h_kcnt (fast chunk planning)
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
+    uint32_t max_len = 0;
     bool finalized = false;
 
     ReadsView view() const
@@ -398,6 +399,7 @@ int commet_readset_finalize(commet_readset *rs)
         HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     }
     rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
+    rs->max_len = rs->n_reads ? mm[1] : 0;
     rs->max_kcnt = 0;
     for (uint32_t v : rs->h_kcnt) rs->max_kcnt = std::max(rs->max_kcnt, v);
     build_kmer_prefix(rs->h_kcnt.data(), rs->n_reads, rs->h_kprefix);
@@ -465,7 +467,8 @@ int launch_index_atomic(commet_ctx *c, const commet_readset *rs, uint64_t first,
 
 bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
 {
-    return c->k >= 20 && c->k <= 34 && (uint64_t) rs->max_kcnt * 4 <= S1_KEYS;
+    return c->k >= 20 && c->k <= 34 && (uint64_t) rs->max_kcnt * 4 <= S1_KEYS &&
+           ((uint64_t) rs->max_len + 7) / 8 <= S1_ITEMS;
 }
 
 // Bucketed construction of the filter for one chunk (index_part.hpp).  The
@@ -502,17 +505,17 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     HIP_OK(hipMemsetAsync(c->part_hist, 0, (g.nb + 1) * sizeof(uint32_t), c->stream));
     // hist
     {
-        const unsigned grid = (unsigned) std::min<uint64_t>(256, (count + 255) / 256);
+        const unsigned grid = (unsigned) std::min<uint64_t>(256, (count + HIST_NT - 1) / HIST_NT);
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
-            const size_t lds = ((size_t) n_b + 524) * 4 + 256 * 8;
+            const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
             HIP_OK(hipFuncSetAttribute(wide ? (const void *) part_hist_kernel<uint64_t> : (const void *) part_hist_kernel<uint32_t>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             if (wide)
-                hipLaunchKernelGGL(part_hist_kernel<uint64_t>, dim3(grid), dim3(256), lds, c->stream, rs->view(), rs->d_kcnt,
+                hipLaunchKernelGGL(part_hist_kernel<uint64_t>, dim3(grid), dim3(HIST_NT), lds, c->stream, rs->view(), rs->d_kcnt,
                                    d_sel, first, count, g, b_lo, n_b, c->part_hist);
             else
-                hipLaunchKernelGGL(part_hist_kernel<uint32_t>, dim3(grid), dim3(256), lds, c->stream, rs->view(), rs->d_kcnt,
+                hipLaunchKernelGGL(part_hist_kernel<uint32_t>, dim3(grid), dim3(HIST_NT), lds, c->stream, rs->view(), rs->d_kcnt,
                                    d_sel, first, count, g, b_lo, n_b, c->part_hist);
             HIP_OK(hipGetLastError());
         }
@@ -525,17 +528,17 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     {
         const unsigned grid = (unsigned) std::min<uint64_t>(512, (count + 63) / 64);
         if (wide)
-            hipLaunchKernelGGL(part_scatter1_kernel<uint64_t>, dim3(grid), dim3(256), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
+            hipLaunchKernelGGL(part_scatter1_kernel<uint64_t>, dim3(grid), dim3(S1_NT), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
                                first, count, g, c->part_cur1, level1_out);
         else
-            hipLaunchKernelGGL(part_scatter1_kernel<uint32_t>, dim3(grid), dim3(256), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
+            hipLaunchKernelGGL(part_scatter1_kernel<uint32_t>, dim3(grid), dim3(S1_NT), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
                                first, count, g, c->part_cur1, level1_out);
         HIP_OK(hipGetLastError());
     }
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
-        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(256), 0, c->stream, c->part_bufA, c->part_bufB,
+        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, c->stream, c->part_bufA, c->part_bufB,
                            c->part_off, g, c->part_cur2, total);
         HIP_OK(hipGetLastError());
     }

@@ -33,9 +33,13 @@ namespace commet {
 constexpr int      TILE_BITS = 19;
 constexpr uint32_t TILE_MASK = (1u << TILE_BITS) - 1;
 constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 KiB
-constexpr uint32_t S1_KEYS = 12288;                         // keys staged per scatter-1 round (48 KiB)
-constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (32 per thread)
-constexpr uint32_t S2_PER_THREAD = S2_KEYS / 256;
+constexpr int      S1_NT = 512;                             // scatter-1 workgroup size
+constexpr uint32_t S1_KEYS = 16384;                         // keys staged per scatter-1 round (64 KiB)
+constexpr uint32_t S1_ITEMS = 2 * S1_NT;                    // octet items per round (2 per thread, keys cached)
+constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
+constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
+constexpr uint32_t S2_PER_THREAD = S2_KEYS / S2_NT;
+constexpr int      HIST_NT = 1024;                          // histogram workgroup size
 constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build workgroup
 constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
 constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
@@ -111,18 +115,29 @@ template <> struct ItemWords<uint64_t> {
     }
 };
 
-// calls f(plane, key) for the 4 forward keys of every complete k-mer of item (read, word w)
+// An item = 8 consecutive bases of a read ("octet" q covers bases 8q..8q+7).
+// Octets below (k-1)>>3 hold no k-mer end and are never enumerated.
+__device__ __forceinline__ uint32_t octets_of(uint32_t len, int k)
+{
+    return len >= (uint32_t) k ? ((len - 1) >> 3) - ((uint32_t) (k - 1) >> 3) + 1 : 0;
+}
+
+// calls f(plane, key) for the 4 forward keys of every complete k-mer ending in octet q of the read at p
 template <typename W, typename F>
-__device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t w, int k, F &&f)
+__device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t q, int k, F &&f)
 {
     using T = KeyTraits<W>;
+    const uint32_t w = q >> 2;
     ItemWords<W> it;
     it.load(p, w);
     const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
     const int sh = T::BITS - k;
-    const uint32_t nb = min(32u, len - 32u * w);
-    for (uint32_t j = 0; j < nb; ++j) {
-        if (32u * w + j + 1u < (uint32_t) k) continue;
+    const uint32_t j0 = (q & 3u) * 8u;
+#pragma unroll
+    for (uint32_t jj = 0; jj < 8; ++jj) {
+        const uint32_t j = j0 + jj;
+        const uint32_t pos = 32u * w + j;
+        if (pos + 1u < (uint32_t) k || pos >= len) continue;
         W wh, wl;
         if (!it.window(j, k, mask, wh, wl)) continue;
         const W ka = T::brev(wh) >> sh;
@@ -138,8 +153,10 @@ __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, ui
 // block-level helpers (256 threads)
 // ---------------------------------------------------------------------------
 // exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *wsum /* 4 words of LDS */, uint32_t *total)
+template <int NT>
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *wsum /* NT/64 words of LDS */, uint32_t *total)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
     for (int o = 1; o < 64; o <<= 1) {
@@ -149,7 +166,7 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *wsum /*
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const uint32_t s = wsum[i];
         if (i < wave) base += s;
         tot += s;
@@ -159,16 +176,17 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *wsum /*
     return base + inc - v;
 }
 
-// in-place exclusive scan of cnt[0..n) (n <= 1024, multiple of... any), into base[]; 256 threads
+// exclusive scan of cnt[0..n) (n <= 1024) into base[]
+template <int NT>
 __device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, uint32_t n, uint32_t *wsum)
 {
-    const uint32_t per = (n + 255) / 256;
+    const uint32_t per = (n + NT - 1) / NT;
     const uint32_t b = threadIdx.x * per;
     uint32_t s = 0;
     for (uint32_t i = 0; i < per; ++i)
         if (b + i < n) s += cnt[b + i];
     uint32_t tot;
-    uint32_t ex = block_scan_256(s, wsum, &tot);
+    uint32_t ex = block_scan<NT>(s, wsum, &tot);
     for (uint32_t i = 0; i < per; ++i)
         if (b + i < n) {
             base[b + i] = ex;
@@ -179,17 +197,19 @@ __device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, ui
 
 // Picks the next reads [r, r + R) of a block's range whose keys fit `cap`
 // (R <= 256, at least 1 when the range is not empty) and builds the item
-// table: istart[i] = first item of read i, one item per 32-base word.
+// table: istart[i] = first item of read i, one item per octet that can end a k-mer.
 // kms = 4 * complete k-mers of read r+i (0 if not selected).
 struct RoundPlan {
     uint32_t n_reads;
     uint32_t n_items;
 };
 
+template <int NT>
 __device__ __forceinline__ RoundPlan plan_round(const ReadsView &rv, const uint32_t *__restrict__ kcnt,
                                                 const uint64_t *__restrict__ sel, uint64_t r, uint64_t r_end,
-                                                uint32_t cap, uint32_t *istart /* 257 */, uint32_t *rd_len /* 256 */,
-                                                uint64_t *rd_t0 /* 256 */, uint32_t *wsum, uint32_t *sh_n)
+                                                uint32_t key_cap, uint32_t item_cap, int k, uint32_t *istart /* NT+1 */,
+                                                uint32_t *rd_len /* NT */, uint64_t *rd_t0 /* NT */, uint32_t *wsum,
+                                                uint32_t *sh_n)
 {
     const uint64_t me = r + threadIdx.x;
     uint32_t keys = 0, items = 0, len = 0;
@@ -200,35 +220,34 @@ __device__ __forceinline__ RoundPlan plan_round(const ReadsView &rv, const uint3
         if (km) {
             read_extent(rv, me, t0, len);
             keys = 4 * km;
-            items = (len + 31) >> 5;
+            items = octets_of(len, k);
         }
     }
-    uint32_t tot;
-    const uint32_t kex = block_scan_256(keys, wsum, &tot);
-    // reads whose inclusive key prefix fits; a read past the range has keys = 0 and is cut below
-    const bool fits = (kex + keys <= cap) && (me < r_end);
+    uint32_t tot, itot;
+    const uint32_t kex = block_scan<NT>(keys, wsum, &tot);
+    uint32_t iex = block_scan<NT>(items, wsum, &itot);
+    // reads whose inclusive key / item prefixes fit (monotone in the thread index)
+    const bool fits = (me < r_end) && (kex + keys <= key_cap) && (iex + items <= item_cap);
     if (threadIdx.x == 0) *sh_n = 0;
     __syncthreads();
-    if (fits) atomicMax(sh_n, threadIdx.x + 1);   // prefix property: fits is monotone non-increasing
+    if (fits) atomicMax(sh_n, threadIdx.x + 1);
     __syncthreads();
     uint32_t R = *sh_n;
     if (R == 0 && r < r_end) R = 1;               // oversize read: the host never sends those here
     if (threadIdx.x >= R) items = 0;
-    uint32_t itot;
-    const uint32_t iex = block_scan_256(items, wsum, &itot);
     istart[threadIdx.x] = iex;
     rd_len[threadIdx.x] = len;
     rd_t0[threadIdx.x] = t0;
-    if (threadIdx.x == 0) istart[256] = itot;
+    if (threadIdx.x == R - 1) istart[NT] = iex + items;   // items of the round
     __syncthreads();
     RoundPlan p;
     p.n_reads = R;
-    p.n_items = itot;
+    p.n_items = istart[NT];
     return p;
 }
 
-// item id -> (read slot, word) by binary search in istart[0..R]
-__device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, uint32_t id, uint32_t &slot, uint32_t &w)
+// item id -> (read slot, octet) by binary search in istart[0..R]
+__device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, uint32_t id, int k, uint32_t &slot, uint32_t &w)
 {
     uint32_t lo = 0, hi = R;   // largest slot with istart[slot] <= id
     while (hi - lo > 1) {
@@ -237,36 +256,38 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
         else hi = mid;
     }
     slot = lo;
-    w = id - istart[lo];
+    w = id - istart[lo] + ((uint32_t) (k - 1) >> 3);
 }
 
 // ---------------------------------------------------------------------------
 // hist: bucket histogram of the chunk, buckets [b_lo, b_lo + n_b) in LDS
 // ---------------------------------------------------------------------------
 template <typename W>
-__global__ __launch_bounds__(256) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
-                                                        const uint64_t *__restrict__ sel, uint64_t first, uint64_t count,
-                                                        PartGeom g, uint32_t b_lo, uint32_t n_b,
-                                                        uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
+                                                            const uint64_t *__restrict__ sel, uint64_t first,
+                                                            uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
+                                                            uint32_t *__restrict__ hist)
 {
+    constexpr int NT = HIST_NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *h = smem;                          // n_b counters
-    uint32_t *istart = h + n_b;                  // 257
-    uint32_t *rd_len = istart + 260;             // 256
-    uint32_t *wsum = rd_len + 256;               // 4
-    uint32_t *sh_n = wsum + 4;                   // 1 (+3 pad)
-    uint64_t *rd_t0 = (uint64_t *) (sh_n + 4);   // 256
-    for (uint32_t i = threadIdx.x; i < n_b; i += 256) h[i] = 0;
+    uint32_t *h = smem;                            // n_b counters
+    uint32_t *istart = h + n_b;                    // NT + 4
+    uint32_t *rd_len = istart + NT + 4;            // NT
+    uint32_t *wsum = rd_len + NT;                  // 16
+    uint32_t *sh_n = wsum + 16;                    // 4
+    uint64_t *rd_t0 = (uint64_t *) (sh_n + 4);     // NT
+    for (uint32_t i = threadIdx.x; i < n_b; i += NT) h[i] = 0;
     __syncthreads();
     const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
     uint64_t r = first + blockIdx.x * per;
     const uint64_t r_end = min(first + count, r + per);
     while (r < r_end) {
-        const RoundPlan rp = plan_round(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, istart, rd_len, rd_t0, wsum, sh_n);
-        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
-            uint32_t slot, w;
-            item_lookup(istart, rp.n_reads, id, slot, w);
-            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
+        const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, 0xFFFFFFFFu, g.k, istart, rd_len,
+                                            rd_t0, wsum, sh_n);
+        for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
+            uint32_t slot, q;
+            item_lookup(istart, rp.n_reads, id, g.k, slot, q);
+            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, [&](uint32_t plane, W key) {
                 const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
                 const uint32_t rel = b - b_lo;
                 if (rel < n_b) atomicAdd(&h[rel], 1u);
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(256) void part_hist_kernel(ReadsView rv, const uint
         r += rp.n_reads;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_b; i += 256) {
+    for (uint32_t i = threadIdx.x; i < n_b; i += NT) {
         const uint32_t v = h[i];
         if (v) atomicAdd(&hist[b_lo + i], v);
     }
@@ -341,57 +362,114 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
 // ---------------------------------------------------------------------------
 // scatter1: reads -> keys -> 2^b1 coarse buckets (LDS counting sort per round)
 // payload = ((bucket & (2^b2 - 1)) << 19) | (key & TILE_MASK)
+// Every thread owns up to two octet items per round; for 32-bit keys the
+// (keya, keyb) pairs are computed once and kept in registers for both passes.
 // ---------------------------------------------------------------------------
 template <typename W>
-__global__ __launch_bounds__(256) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
-                                                            const uint64_t *__restrict__ sel, uint64_t first,
-                                                            uint64_t count, PartGeom g,
-                                                            unsigned long long *__restrict__ cursor1,
-                                                            uint32_t *__restrict__ out)
+__global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
+                                                              const uint64_t *__restrict__ sel, uint64_t first,
+                                                              uint64_t count, PartGeom g,
+                                                              unsigned long long *__restrict__ cursor1,
+                                                              uint32_t *__restrict__ out)
 {
+    constexpr int NT = S1_NT;
+    constexpr bool CACHE = sizeof(W) == 4;
+    using T = KeyTraits<W>;
     __shared__ uint32_t sorted[S1_KEYS];
     __shared__ uint32_t cnt[MAX_L1], base[MAX_L1], fill[MAX_L1];
     __shared__ unsigned long long gbase[MAX_L1];
-    __shared__ uint32_t istart[260], rd_len[256], wsum[4], sh_n[4];
-    __shared__ uint64_t rd_t0[256];
+    __shared__ uint32_t istart[NT + 4], rd_len[NT], wsum[16], sh_n[4];
+    __shared__ uint64_t rd_t0[NT];
     const uint32_t sub_mask = (1u << g.b2) - 1;
     const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
     uint64_t r = first + blockIdx.x * per;
     const uint64_t r_end = min(first + count, r + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const W mask = (g.k == T::BITS) ? ~(W) 0 : (((W) 1 << g.k) - 1);
+    const int sh = T::BITS - g.k;
     while (r < r_end) {
-        const RoundPlan rp = plan_round(rv, kcnt, sel, r, r_end, S1_KEYS, istart, rd_len, rd_t0, wsum, sh_n);
+        const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, S1_KEYS, S1_ITEMS, g.k, istart, rd_len, rd_t0,
+                                            wsum, sh_n);
         if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
         __syncthreads();
-        // pass A: count
-        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
-            uint32_t slot, w;
-            item_lookup(istart, rp.n_reads, id, slot, w);
-            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
-                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-                atomicAdd(&cnt[b >> g.b2], 1u);
-            });
+        // my items: id = tid and tid + NT
+        uint32_t cka[2][8], ckb[2][8], cvalid[2] = {0, 0};   // used when CACHE
+        uint32_t islot[2], iq[2];
+        bool ion[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t id = threadIdx.x + u * NT;
+            ion[u] = id < rp.n_items;
+            islot[u] = 0, iq[u] = 0;
+            if (ion[u]) item_lookup(istart, rp.n_reads, id, g.k, islot[u], iq[u]);
+        }
+        // pass A: keys, count per coarse bucket
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ion[u]) continue;
+            const uint32_t *p = rv.planes + 3 * rd_t0[islot[u]];
+            const uint32_t len = rd_len[islot[u]];
+            if (CACHE) {
+                const uint32_t w = iq[u] >> 2, j0 = (iq[u] & 3u) * 8u;
+                ItemWords<W> it;
+                it.load(p, w);
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; ++jj) {
+                    const uint32_t j = j0 + jj, pos = 32u * w + j;
+                    W wh = 0, wl = 0;
+                    const bool ok = (pos + 1u >= (uint32_t) g.k) && (pos < len) && it.window(j, g.k, mask, wh, wl);
+                    const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                    cka[u][jj] = (uint32_t) ka;
+                    ckb[u][jj] = (uint32_t) kb;
+                    if (ok) {
+                        cvalid[u] |= 1u << jj;
+                        const W kc = ka ^ kb, kd = ka | kb;
+                        atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (ka >> TILE_BITS)) >> g.b2], 1u);
+                        atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
+                        atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
+                        atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
+                    }
+                }
+            } else {
+                for_each_key<W>(p, len, iq[u], g.k, [&](uint32_t plane, W key) {
+                    const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+                    atomicAdd(&cnt[b >> g.b2], 1u);
+                });
+            }
         }
         __syncthreads();
-        lds_scan(cnt, base, g.nb1, wsum);
+        lds_scan<NT>(cnt, base, g.nb1, wsum);
         if (threadIdx.x < g.nb1) {
             const uint32_t c = cnt[threadIdx.x];
             gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
         }
-        // pass B: place (keys recomputed; only the counts have to agree with pass A)
-        for (uint32_t id = threadIdx.x; id < rp.n_items; id += 256) {
-            uint32_t slot, w;
-            item_lookup(istart, rp.n_reads, id, slot, w);
-            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], w, g.k, [&](uint32_t plane, W key) {
-                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-                const uint32_t c1 = b >> g.b2;
-                const uint32_t pos = base[c1] + atomicAdd(&fill[c1], 1u);
-                if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
-            });
+        // pass B: place
+        auto place = [&](uint32_t plane, W key) {
+            const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+            const uint32_t c1 = b >> g.b2;
+            const uint32_t pos = base[c1] + atomicAdd(&fill[c1], 1u);
+            if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
+        };
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ion[u]) continue;
+            if (CACHE) {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; ++jj) {
+                    if (!((cvalid[u] >> jj) & 1u)) continue;
+                    const W ka = cka[u][jj], kb = ckb[u][jj];
+                    place(0u, ka);
+                    place(1u, kb);
+                    place(2u, ka ^ kb);
+                    place(3u, ka | kb);
+                }
+            } else {
+                for_each_key<W>(rv.planes + 3 * rd_t0[islot[u]], rd_len[islot[u]], iq[u], g.k, place);
+            }
         }
         __syncthreads();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
-        for (uint32_t c1 = wave; c1 < g.nb1; c1 += 4) {
+        for (uint32_t c1 = wave; c1 < g.nb1; c1 += NT / 64) {
             const uint32_t n = cnt[c1], src = base[c1];
             const unsigned long long dst = gbase[c1];
             for (uint32_t i = lane; i < n; i += 64) out[dst + i] = sorted[src + i];
@@ -405,14 +483,15 @@ __global__ __launch_bounds__(256) void part_scatter1_kernel(ReadsView rv, const 
 // scatter2: coarse buckets -> final buckets.  Flat grid over bufA; a slab that
 // straddles coarse buckets is processed segment by segment.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                            const uint64_t *__restrict__ off, PartGeom g,
-                                                            unsigned long long *__restrict__ cursor2, uint64_t total)
+__global__ __launch_bounds__(S2_NT) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                              const uint64_t *__restrict__ off, PartGeom g,
+                                                              unsigned long long *__restrict__ cursor2, uint64_t total)
 {
+    constexpr int NT = S2_NT;
     __shared__ uint32_t sorted[S2_KEYS];
     __shared__ uint32_t cnt[MAX_SUB], base[MAX_SUB], fill[MAX_SUB];
     __shared__ unsigned long long gbase[MAX_SUB];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[16];
     const uint32_t nsub = 1u << g.b2;
     const uint64_t s0 = (uint64_t) blockIdx.x * S2_KEYS;
     if (s0 >= total) return;
@@ -435,31 +514,35 @@ __global__ __launch_bounds__(256) void part_scatter2_kernel(const uint32_t *__re
             continue;
         }
         const uint32_t n = (uint32_t) (seg_end - pos);
-        for (uint32_t i = threadIdx.x; i < nsub; i += 256) cnt[i] = 0, fill[i] = 0;
+        for (uint32_t i = threadIdx.x; i < nsub; i += NT) cnt[i] = 0, fill[i] = 0;
         __syncthreads();
         uint32_t key[S2_PER_THREAD];
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
-            const uint32_t i = threadIdx.x + 256 * q;
+            const uint32_t i = threadIdx.x + NT * q;
             key[q] = i < n ? in[pos + i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+            const uint32_t i = threadIdx.x + NT * q;
             if (i < n) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
         }
         __syncthreads();
-        lds_scan(cnt, base, nsub, wsum);
-        for (uint32_t i = threadIdx.x; i < nsub; i += 256) {
+        lds_scan<NT>(cnt, base, nsub, wsum);
+        for (uint32_t i = threadIdx.x; i < nsub; i += NT) {
             const uint32_t c = cnt[i];
             gbase[i] = c ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], (unsigned long long) c) : 0ull;
         }
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
-            const uint32_t i = threadIdx.x + 256 * q;
+            const uint32_t i = threadIdx.x + NT * q;
             if (i < n) {
                 const uint32_t sb = key[q] >> TILE_BITS;
                 sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
             }
         }
         __syncthreads();
-        for (uint32_t sb = wave; sb < nsub; sb += 4) {
+        for (uint32_t sb = wave; sb < nsub; sb += NT / 64) {
             const uint32_t m = cnt[sb], src = base[sb];
             const unsigned long long dst = gbase[sb];
             for (uint32_t i = lane; i < m; i += 64) out[dst + i] = sorted[src + i];
@@ -496,9 +579,39 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
     uint4 *t4 = (uint4 *) tile;
     for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) t4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (uint64_t i = k0 + threadIdx.x; i < k1; i += 256) {
-        const uint32_t key = keys[i];
-        atomicOr(&tile[key >> 5], 1u << (key & 31u));
+    {
+        // head up to 16-byte alignment, then 4 keys per lane per load, 4 loads in flight
+        uint64_t a0 = (k0 + 3) & ~3ull;
+        if (a0 > k1) a0 = k1;
+        for (uint64_t i = k0 + threadIdx.x; i < a0; i += 256) {
+            const uint32_t key = keys[i];
+            atomicOr(&tile[key >> 5], 1u << (key & 31u));
+        }
+        const uint64_t nvec = (k1 - a0) >> 2;
+        const uint4 *kv = (const uint4 *) (keys + a0);
+        uint64_t v = threadIdx.x;
+        for (; v + 768 < nvec; v += 1024) {
+            const uint4 x0 = kv[v], x1 = kv[v + 256], x2 = kv[v + 512], x3 = kv[v + 768];
+            const uint4 xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                atomicOr(&tile[xs[u].x >> 5], 1u << (xs[u].x & 31u));
+                atomicOr(&tile[xs[u].y >> 5], 1u << (xs[u].y & 31u));
+                atomicOr(&tile[xs[u].z >> 5], 1u << (xs[u].z & 31u));
+                atomicOr(&tile[xs[u].w >> 5], 1u << (xs[u].w & 31u));
+            }
+        }
+        for (; v < nvec; v += 256) {
+            const uint4 x = kv[v];
+            atomicOr(&tile[x.x >> 5], 1u << (x.x & 31u));
+            atomicOr(&tile[x.y >> 5], 1u << (x.y & 31u));
+            atomicOr(&tile[x.z >> 5], 1u << (x.z & 31u));
+            atomicOr(&tile[x.w >> 5], 1u << (x.w & 31u));
+        }
+        for (uint64_t i = a0 + 4 * nvec + threadIdx.x; i < k1; i += 256) {
+            const uint32_t key = keys[i];
+            atomicOr(&tile[key >> 5], 1u << (key & 31u));
+        }
     }
     __syncthreads();
     // bucket b = (plane << plane_shift) | tile index: its words sit at b * TILE_WORDS of the 4-plane array
