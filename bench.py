@@ -88,15 +88,11 @@ def cpu_baseline(args, b0, o0, b1, o1):
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist     # gloo only: host-side barrier / max, no GPU work goes through torch
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from commet_amd import sharding
+    ranks = sharding.Ranks(backend="gloo")   # host-side barrier / MAX only; N=1 needs no torch at all
+    world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import commet_amd
     from commet_amd import synth
 
@@ -106,14 +102,11 @@ def main():
     b1, o1 = synth.synth_set(2 * rank + 1, n, L, base_set=2 * rank)
 
     ctx = commet_amd.Context(k=k, t=t, device=local_rank)
+    t_up = time.perf_counter()
     irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
     qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
     ctx.synchronize()
-
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+    upload_s = time.perf_counter() - t_up      # PCIe + packing of both sets (reported, never part of `value`)
 
     probes = None
     if not args.no_probe_count:
@@ -125,19 +118,16 @@ def main():
         ctx.index_and_search(irs, [qrs])
 
     acc = dict(index_kernel_ms=0.0, search_ms=0.0, zero_ms=0.0, index_launches=0, search_launches=0)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    last = {}
+
+    def step():
         tags, stats, info = ctx.index_and_search(irs, [qrs])
         for f in acc:
             acc[f] += info[f]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+        last["stats"], last["info"] = stats, info
+
+    elapsed = sharding.timed_region(ranks, ctx.synchronize, step, args.steps)
+    stats, info = last["stats"], last["info"]
 
     if rank == 0:
         steps = args.steps
@@ -176,7 +166,8 @@ def main():
                        "filter_zero_ms": round(acc["zero_ms"] / steps, 3),
                        "index_alg_GBps": round(idx_bytes_step / (idx_ms * 1e-3) / 1e9, 1) if idx_ms else None,
                        "search_alg_GBps": round(srch_bytes_step / (srch_ms * 1e-3) / 1e9, 1) if srch_bytes_step and srch_ms else None,
-                       "p_ref_probes": probes},
+                       "p_ref_probes": probes, "upload_and_pack_s": round(upload_s, 3),
+                       "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1)},
         }
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(args, b0, o0, b1, o1)
@@ -185,9 +176,7 @@ def main():
     irs.close()
     qrs.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""Build recipes (in-tree, no JIT cache): HIP library, host tools, CPU checker."""
+"""Build recipes (in-tree, no JIT cache): the HIP library and the C++ host tools."""
 import os
 import shutil
 import subprocess
@@ -78,16 +78,9 @@ def build_tools(force=False):
     return built
 
 
-def build_oracle():
-    """The CPU checker (test infrastructure): our C restatement and, when the
-    reference sources are present, the reference's own tools into oracle/_ref."""
-    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-
-
 def build_all(force=False):
     build_lib(force)
     build_tools(force)
-    build_oracle()
 
 
 if __name__ == "__main__":

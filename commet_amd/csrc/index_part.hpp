@@ -483,7 +483,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
 // scatter2: coarse buckets -> final buckets.  Flat grid over bufA; a slab that
 // straddles coarse buckets is processed segment by segment.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(S2_NT) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+__global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                               const uint64_t *__restrict__ off, PartGeom g,
                                                               unsigned long long *__restrict__ cursor2, uint64_t total)
 {
