@@ -86,6 +86,27 @@ def cpu_baseline(args, b0, o0, b1, o1):
         subprocess.run(["rm", "-rf", work])
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC profile of this very workload
+    (profiles/<dir>/traffic.json written by tools/pmc_summary.py next to the bench.json it was taken with).
+    PMC counters cannot be collected from inside the timed run; None when no matching profile exists."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        tj, bj = os.path.join(pdir, d, "traffic.json"), os.path.join(pdir, d, "bench.json")
+        if not (os.path.exists(tj) and os.path.exists(bj)):
+            continue
+        try:
+            if json.load(open(bj))["config"]["workload"] != workload:
+                continue
+            e = json.load(open(tj)).get(kernel)
+            if e and "hbm_bytes_per_launch" in e:
+                best = (e["hbm_bytes_per_launch"], f"profiles/{d}/traffic.json")
+        except Exception:
+            continue
+    return best
+
+
 def main():
     args = parse_args()
     from commet_amd import sharding
@@ -146,8 +167,12 @@ def main():
         else:
             name, kms, kbytes, launches = "search_kernel", srch_ms, srch_bytes_step, acc["search_launches"] / steps
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
+                    f"per GPU (BASELINE configs[1]), inputs resident in HBM")
+        tr = measured_traffic(workload, name)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr[0] if tr else None,
+                    "traffic_source": tr[1] if tr else None,
                     "launches_per_step": launches, "avg_launch_ms": round(kms / max(launches, 1), 3),
                     "algorithmic_bytes_per_launch": round(kbytes / max(launches, 1))}
         out = {
@@ -155,8 +180,7 @@ def main():
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32" if k <= 32 else "u64", "data": "synthetic",
-            "config": {"workload": f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
-                                   f"per GPU (BASELINE configs[1]), inputs resident in HBM",
+            "config": {"workload": workload,
                        "reads_per_set": n, "read_len": L, "k": k, "t": t, "jobs": world,
                        "parallelism": f"{world} independent (i,j) jobs, no collective"},
             "roofline": roofline,

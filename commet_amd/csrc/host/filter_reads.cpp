@@ -1,0 +1,171 @@
+// filter_reads — per-read length / #non-ACGT / Shannon-index filter producing a
+// `.bv`, drop-in for Commet's tool (reference: src/filter_reads.cpp:48-306).
+// Commet.py runs it on every input file when no filter bvs are given
+// (Commet.py:103-121, 557-562).  O(bases) streaming over the mapped file.
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <ctime>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "bv_file.hpp"
+#include "fasta_source.hpp"
+
+using namespace commet_host;
+
+static const std::string version = "2.1";
+
+static void print_usage()
+{
+    std::cout << "\nfilter_reads v" << version << "\n";
+    std::cout << "Usage:\n\t./filter_reads <input_file> [options]\n";
+    std::cout << "Mandatory:\n";
+    std::cout << "\t<input_file>\t: file containing reads, in fasta or fastq format, gzipped or not\n";
+    std::cout << "Options:\n";
+    std::cout << "\t -o string\t: file where the boolean vector will be written [default=input_file.bv]\n";
+    std::cout << "\t -l int\t\t: minimal length a read should have to be kept. [default=0]\n";
+    std::cout << "\t -n int\t\t: maximal number of Ns a read should contain to be kept. [default=any]\n";
+    std::cout << "\t -e float\t: minimal Shannon index a read should have to be kept. [default=0]\n";
+    std::cout << "\t -m int\t\t: maximum number of selected reads [default=all]\n";
+    std::cout << "\t -c string\t: the given string will be written in the header of the output file. [default=command line]\n";
+    std::cout << "\t -h\t\t: prints this help\n";
+    std::cout << "\t -v\t\t: prints the version number.\n\n";
+}
+
+// per-read statistics gathered while scanning a record's lines
+struct ReadStats {
+    uint64_t len = 0;
+    uint64_t cnt[5] = {0, 0, 0, 0, 0};   // A C G T other (case-folded, filter_reads.cpp:277-295)
+    uint64_t non_acgt = 0;               // Alphabet::is_in == false (filter_reads.cpp:249-259)
+    void add(const char *s, size_t n)
+    {
+        len += n;
+        for (size_t i = 0; i < n; ++i) {
+            switch (s[i]) {
+            case 'A': case 'a': ++cnt[0]; break;
+            case 'C': case 'c': ++cnt[1]; break;
+            case 'G': case 'g': ++cnt[2]; break;
+            case 'T': case 't': ++cnt[3]; break;
+            default: ++cnt[4]; ++non_acgt;
+            }
+        }
+    }
+    // filter_reads.cpp:265-306, same float / double mix
+    float shannon() const
+    {
+        float index = 0;
+        for (int i = 0; i < 5; ++i) {
+            const float f = (float) cnt[i] / (float) len;
+            if (f != 0) index += f * log(f) / log(2);
+        }
+        return fabs(index);
+    }
+};
+
+int main(int argc, char **argv)
+{
+    const clock_t begin_time = clock();
+    std::string in_name, out_name;
+    int min_size = 0, max_N = INT_MAX;
+    float min_shannon = 0.0;
+    std::stringstream comment;
+    long max_reads = -1, nb_selected = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string flag = argv[i];
+        auto arg = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (flag.empty() || flag[0] != '-') {
+            if (in_name.empty()) in_name = flag;
+            else if (out_name.empty()) out_name = flag;
+            else std::cout << "The mandatory files are already set, unknown file " << flag << " -> ignore\n";
+        } else if (flag == "-o") out_name = arg();
+        else if (flag == "-l") min_size = atoi(arg());
+        else if (flag == "-n") max_N = atoi(arg());
+        else if (flag == "-m") max_reads = atoi(arg());
+        else if (flag == "-e") min_shannon = (float) atof(arg());
+        else if (flag == "-c") comment << arg() << "\n";
+        else if (flag == "-h") { print_usage(); return 0; }
+        else if (flag == "-v") { std::cout << "\nfilter_reads version " << version << "\n"; return 0; }
+        else {
+            std::cerr << "Unknown option " << flag << "\n";
+            print_usage();
+            return 1;
+        }
+    }
+    if (in_name.empty()) {
+        std::cerr << "Error: An input file name is needed -> exit\n";
+        print_usage();
+        return 0;
+    }
+    std::string output_message;
+    if (out_name.empty()) {
+        output_message = "No output file name given, results will be written in " + in_name + ".bv\n";
+        out_name = in_name + ".bv";
+    }
+    MappedFile mf;
+    if (!mf.open_file(in_name)) {
+        std::cerr << "Cannot open file " << in_name << " -> quit\n";
+        return 1;
+    }
+    if (!mf.size() || mf.data()[0] != '>') {
+        std::cerr << "Unknown format: " << in_name << " -> quit\n";
+        std::cerr << "(this build reads plain FASTA only)\n";
+        return 1;
+    }
+    comment << "----------------\n";
+    comment << "Reference file\n";
+    const size_t slash = in_name.rfind("/");
+    if (slash > 0 && slash < in_name.size()) comment << "  " << in_name.substr(slash + 1) << "\n";
+    else comment << "  " << in_name << "\n";
+    comment << "Filter Options\n";
+    comment << "  min read size     : " << min_size << "\n";
+    if (max_N == INT_MAX) comment << "  max number of N   : infinite\n";
+    else comment << "  max number of N   : " << max_N << "\n";
+    comment << "  min shannon index : " << min_shannon << "\n";
+
+    const char *d = mf.data();
+    const size_t n = mf.size();
+    BitVector bv;
+    bv.init_true(count_fasta_records(d, n));
+    if (max_reads == -1) max_reads = (long) bv.size;
+    long rm_length = 0, rm_N = 0, rm_shannon = 0;
+    uint64_t pos = 0;          // current_read_pos
+    size_t i = 0;
+    bool stopped_by_empty = false;
+    while (i < n && nb_selected < max_reads) {
+        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
+        size_t j = nl ? (size_t) (nl - d) + 1 : n;
+        ReadStats st;
+        while (j < n && d[j] != '>') {
+            nl = (const char *) memchr(d + j, '\n', n - j);
+            const size_t e = nl ? (size_t) (nl - d) : n;
+            st.add(d + j, e - j);
+            j = nl ? e + 1 : n;
+        }
+        i = j;
+        if (st.len == 0) {     // empty sequence == end-of-file sentinel of the reference iterator
+            stopped_by_empty = true;
+            break;
+        }
+        if ((int) st.len < min_size) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_length; }
+        else if ((long) st.non_acgt > (long) max_N) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_N; }
+        else if (st.shannon() < min_shannon) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_shannon; }
+        else ++nb_selected;
+        ++pos;                 // the look-ahead get_next_read (filter_reads.cpp:200)
+    }
+    (void) stopped_by_empty;
+    if (nb_selected >= max_reads)   // untag_last_reads: everything from the look-ahead read on
+        for (uint64_t r = pos; r < bv.size; ++r) bv.bytes[r >> 3] &= (uint8_t) ~(1u << (r & 7));
+    bv.comment = comment.str();
+    if (!write_bv(out_name, bv)) return 1;
+
+    std::cout << "Length filter [" << min_size << "]: " << rm_length << " reads removed\n";
+    if (max_N == INT_MAX) std::cout << "Number of N filter [infinite]: " << rm_N << " reads removed\n";
+    else std::cout << "Number of N filter [" << max_N << "]: " << rm_N << " reads removed\n";
+    std::cout << "Shannon filter [" << min_shannon << "]: " << rm_shannon << " reads removed\n";
+    std::cout << "Number of selected reads = " << nb_selected << "\n";
+    if (!output_message.empty()) std::cout << output_message;
+    std::cout << "Total  time : " << float(clock() - begin_time) / CLOCKS_PER_SEC << " s\n";
+    return 0;
+}

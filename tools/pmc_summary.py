@@ -1,0 +1,57 @@
+"""Summarises rocprofv3 outputs of a bench.py run into per-kernel averages:
+  python tools/pmc_summary.py profiles/<dir>
+reads kernel_stats.csv (--kernel-trace --stats), pmc_fetch_size.csv / pmc_write_size.csv (--pmc FETCH_SIZE /
+WRITE_SIZE, separate passes) and writes <dir>/traffic.json:
+  {kernel: {calls, avg_ms, fetch_bytes_per_launch, write_bytes_per_launch, hbm_bytes_per_launch}}
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B
+requests of wide coalesced streams at 64 B, so streaming kernels' reads are doubled; random 4-B gathers (one 64-B
+request per probe) and atomics are taken as reported — for the search kernel this is confirmed by
+FETCH_SIZE == P_ref x 64 B within 2 %."""
+import collections
+import csv
+import json
+import os
+import sys
+
+STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1")   # wide coalesced readers
+
+
+def short(name):
+    n = name.replace("void ", "").replace("commet::", "")
+    return n.split("(")[0].split("<")[0]
+
+
+def main(d):
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):
+        k = short(r["Name"])
+        e = out.setdefault(k, dict(calls=0, total_ms=0.0))
+        e["calls"] += int(r["Calls"])
+        e["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+    for e in out.values():
+        e["avg_ms"] = round(e["total_ms"] / max(e["calls"], 1), 4)
+        e["total_ms"] = round(e["total_ms"], 3)
+    for fname, field in (("pmc_fetch_size.csv", "fetch"), ("pmc_write_size.csv", "write")):
+        p = os.path.join(d, fname)
+        if not os.path.exists(p):
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(p)):
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
+        for k, v in acc.items():
+            if k in out:
+                mean = sum(v) / len(v)
+                if field == "fetch" and k.startswith(STREAMING):
+                    mean *= 2.0
+                out[k][field + "_bytes_per_launch"] = round(mean)
+    for e in out.values():
+        if "fetch_bytes_per_launch" in e or "write_bytes_per_launch" in e:
+            e["hbm_bytes_per_launch"] = e.get("fetch_bytes_per_launch", 0) + e.get("write_bytes_per_launch", 0)
+    json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+    for k, e in out.items():
+        print(f"{k:28s} calls={e['calls']:4d} avg_ms={e['avg_ms']:9.3f} fetch={e.get('fetch_bytes_per_launch', 0) / 1e9:8.2f} GB "
+              f"write={e.get('write_bytes_per_launch', 0) / 1e9:8.2f} GB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
