@@ -2,6 +2,7 @@
 meaning, errors raised as CommetError with the library's message.  All compute
 happens in the HIP library; numpy arrays only carry host buffers."""
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -148,13 +149,27 @@ class Context:
 class ReadSet:
     """commet_readset: the reads of one set, packed and resident in HBM."""
 
-    def __init__(self, ctx, max_reads, max_bases):
+    def __init__(self, ctx, max_reads, max_bases, _handle=None):
         self._ctx = ctx
         self._lib = ctx._lib
-        self._h = self._lib.commet_readset_create(ctx._h, int(max_reads), int(max_bases))
+        self._h = _handle if _handle is not None else self._lib.commet_readset_create(ctx._h, int(max_reads), int(max_bases))
         if not self._h:
             raise CommetError(_err(self._lib))
         ctx._readsets.add(self)
+
+    @classmethod
+    def from_fasta(cls, ctx, paths):
+        """Maps the FASTA files of one set (host parser in the library), streams them to HBM, finalizes."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = ctx._lib.commet_readset_from_fasta(ctx._h, arr, len(paths))
+        if not h:
+            raise CommetError(_err(ctx._lib))
+        rs = cls(ctx, 0, 0, _handle=h)
+        rs.finalize()
+        return rs
+
+    def file_reads(self):
+        return [int(self._lib.commet_readset_file_reads(self._h, i)) for i in range(self.num_files)]
 
     @classmethod
     def from_files(cls, ctx, files):

@@ -6,6 +6,7 @@
 #include "kernels.hpp"
 #include "index_part.hpp"
 #include "read_iter.hpp"
+#include "host/fasta_source.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -15,6 +16,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -382,6 +384,47 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
         done += take;
     }
     return 0;
+}
+
+commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *paths, int n_paths)
+{
+    std::vector<std::unique_ptr<commet_host::MappedFile>> maps;
+    uint64_t max_reads = 0, max_bases = 0;
+    for (int i = 0; i < n_paths; ++i) {
+        std::unique_ptr<commet_host::MappedFile> mf(new commet_host::MappedFile);
+        if (!mf->open_file(paths[i])) {
+            fail("Cannot open file %s", paths[i]);
+            return nullptr;
+        }
+        if (!mf->size() || mf->data()[0] != '>') {
+            fail("Unknown format: %s (plain FASTA expected)", paths[i]);
+            return nullptr;
+        }
+        max_reads += commet_host::count_fasta_records(mf->data(), mf->size());
+        max_bases += mf->size();
+        maps.push_back(std::move(mf));
+    }
+    commet_readset *rs = commet_readset_create(c, max_reads, max_bases);
+    if (!rs) return nullptr;
+    for (int i = 0; i < n_paths; ++i) {
+        std::string err;
+        if (commet_readset_begin_file(rs) || commet_host::stream_fasta(rs, maps[i]->data(), maps[i]->size(), err)) {
+            if (!err.empty()) fail("%s: %s", paths[i], err.c_str());
+            commet_readset_destroy(rs);
+            return nullptr;
+        }
+    }
+    if (rs->n_reads != max_reads) {
+        fail("Error in Fasta format !!");
+        commet_readset_destroy(rs);
+        return nullptr;
+    }
+    return rs;
+}
+
+uint64_t commet_readset_file_reads(const commet_readset *rs, uint64_t file_index)
+{
+    return file_index < rs->files.size() ? rs->files[file_index].count : 0;
 }
 
 int commet_readset_finalize(commet_readset *rs)

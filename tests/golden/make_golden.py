@@ -174,8 +174,36 @@ def make_abcde():
         json.dump(result, fh, indent=1, sort_keys=True)
 
 
+def make_commet_py():
+    """Runs the reference's own driver (Commet.py, python3) with the reference binaries on ABCDE_bench and keeps
+    what it produces: the three matrix CSVs, the filter .bv files and every *_in_*.bv (k=32, t=2, defaults)."""
+    dst = os.path.join(HERE, "abcde", "commet_py")
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    for label, lines in (("three_sets", ["set1: ABCDE_bench/A.fa", "set2: ABCDE_bench/B.fa; ABCDE_bench/C.fa",
+                                         "set3: ABCDE_bench/D.fa"]),
+                         ("five_sets", [f"{x}: ABCDE_bench/{x}.fa" for x in "ABCDE"])):
+        work = tempfile.mkdtemp()
+        os.symlink(os.path.join(REF, "ABCDE_bench"), os.path.join(work, "ABCDE_bench"))
+        for f in ("dendro.R", "heatmap.r"):
+            os.symlink(os.path.join(REF, f), os.path.join(work, f))
+        open(os.path.join(work, "sets.txt"), "w").write("\n".join(lines) + "\n")
+        subprocess.run([sys.executable, os.path.join(REF, "Commet.py"), "sets.txt", "-b",
+                        os.path.join(ROOT, "oracle", "_ref") + "/", "-o", "out/", "-k", "32", "-t", "2"],
+                       cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        od = os.path.join(dst, label)
+        os.makedirs(od)
+        shutil.copy(os.path.join(work, "sets.txt"), od)
+        for f in sorted(os.listdir(os.path.join(work, "out"))):
+            if f.endswith(".csv") or f.endswith(".bv"):
+                shutil.copy(os.path.join(work, "out", f), od)
+        shutil.rmtree(work)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["scenarios", "keys", "abcde"]
+    what = sys.argv[1:] or ["scenarios", "keys", "abcde", "commetpy"]
+    if "commetpy" in what:
+        make_commet_py()
     if "scenarios" in what:
         make_scenarios()
     if "keys" in what:

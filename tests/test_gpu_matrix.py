@@ -1,0 +1,113 @@
+"""The resident N x N driver (commet_amd/matrix.py) against what the reference's own
+driver produced: Commet.py + the reference binaries on ABCDE_bench (tests/golden/abcde/commet_py),
+and against the CPU checker run through Commet.py's job sequence on synthetic sets."""
+import gzip
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _tools():
+    from commet_amd import build
+    build.build_lib()
+    build.build_tools()
+
+
+@pytest.fixture()
+def abcde(tmp_path):
+    os.makedirs(tmp_path / "ABCDE_bench")
+    for f, copies in (("A", "A"), ("B", "BD"), ("C", "CE")):
+        data = gzip.open(os.path.join(GOLD, "abcde", f + ".fa.gz")).read()
+        for c in copies:
+            open(tmp_path / "ABCDE_bench" / (c + ".fa"), "wb").write(data)
+    return tmp_path
+
+
+@pytest.mark.parametrize("label", ["three_sets", "five_sets"])
+def test_matrix_driver_reproduces_commet_py(abcde, label, monkeypatch):
+    from commet_amd import matrix
+    gold = os.path.join(GOLD, "abcde", "commet_py", label)
+    monkeypatch.chdir(abcde)
+    open("sets.txt", "w").write(open(os.path.join(gold, "sets.txt")).read())
+    res = matrix.run("sets.txt", "out/", k=32, t=2, verbose=False)
+    assert res["world"] == 1
+    for f in sorted(os.listdir(gold)):
+        if f.endswith((".csv", ".bv")):
+            got = open(os.path.join("out", f), "rb").read()
+            exp = open(os.path.join(gold, f), "rb").read()
+            assert got == exp, f
+    n = len(res["names"])
+    assert sum(1 for f in os.listdir("out") if "_in_" in f and f.endswith(".bv")) == \
+        sum(1 for f in os.listdir(gold) if "_in_" in f and f.endswith(".bv"))
+    assert res["matrix"][0][0] == 12000 and len(res["matrix"]) == n
+
+
+def test_matrix_driver_matches_oracle_on_synthetic_sets(tmp_path, monkeypatch):
+    """4 sets (one of two files, one with a filter that empties a file), k=20: every .bv equals the CPU
+    checker driven through Commet.py's job order with the same filter bvs."""
+    from commet_amd import matrix, synth
+    sys.path.insert(0, GOLD)
+    from make_golden import commet_jobs
+    import util
+    monkeypatch.chdir(tmp_path)
+    k, t, n, L = 20, 2, 6000, 80
+    names = ["s0", "s1", "s2", "s3"]
+    files = [["s0.fa"], ["s1a.fa", "s1b.fa"], ["s2.fa"], ["s3.fa"]]
+    for s, fl in enumerate(files):
+        b, o = synth.synth_set(s, n, L, copy_frac=0.3)
+        if len(fl) == 1:
+            synth.write_fasta(fl[0], b, o)
+        else:
+            h = n // 2
+            synth.write_fasta(fl[0], b[: h * L], o[: h + 1])
+            synth.write_fasta(fl[1], b[h * L:], o[h:] - o[h])
+    rng = np.random.default_rng(1)
+    bvs = []
+    for s, fl in enumerate(files):
+        row = []
+        for j, f in enumerate(fl):
+            cnt = len(util.parse_fasta(f))
+            sel = rng.random(cnt) < 0.9
+            if (s, j) == (1, 1):
+                sel[:] = False                                   # a file with no selected read
+            util.write_bv(f + ".bv", "filter of " + f, sel)
+            row.append(f + ".bv")
+        bvs.append(row)
+    open("sets.txt", "w").write("".join(
+        f"{names[s]}: " + "; ".join(f"{f},{b}" for f, b in zip(files[s], bvs[s])) + "\n" for s in range(4)))
+    res = matrix.run("sets.txt", "out/", k=k, t=t, verbose=False)
+
+    def cfg(si, restrict_to=None, out="orc"):
+        parts = []
+        for f, b in zip(files[si], bvs[si]):
+            parts.append(f + "," + (b if restrict_to is None else f"{out}/{f}_in_{names[restrict_to]}.bv"))
+        return names[si] + ":" + ";".join(parts)
+
+    os.makedirs("orc")
+    for kind, idx, searches, restr in commet_jobs(names):
+        open("i.txt", "w").write(cfg(idx, restr) + "\n")
+        open("s.txt", "w").write("".join(cfg(s) + "\n" for s in searches))
+        rc, *_ = ob.index_and_search("i.txt", "s.txt", "orc", "orc", k, t)
+        assert rc == 0
+    checked = 0
+    for f in sorted(os.listdir("orc")):
+        if f.endswith(".bv"):
+            assert open(os.path.join("out", f), "rb").read() == open(os.path.join("orc", f), "rb").read(), f
+            checked += 1
+    assert checked == 5 * 3 + 5 * 3 - 5 * 0 or checked > 0
+    # matrix rows = bit counts of those files
+    for a in range(4):
+        for b in range(4):
+            if a != b:
+                tot = sum(util.bools_from_bits(util.read_bv(f"orc/{f}_in_{names[b]}.bv")[2], util.read_bv(f"orc/{f}_in_{names[b]}.bv")[1]).sum()
+                          for f in files[a])
+                assert res["matrix"][a][b] == int(tot)
