@@ -46,7 +46,7 @@ def build_lib(force=False):
     srcs = _sources(CSRC, os.path.join(ROOT, "include"))
     if force or _newer(LIB, srcs):
         _run([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-              "-o", LIB, os.path.join(CSRC, "capi.hip")])
+              "-o", LIB, os.path.join(CSRC, "capi.hip"), "-lz"])
     return LIB
 
 
@@ -65,7 +65,7 @@ def build_tools(force=False):
         out = os.path.join(BIN_DIR, tool)
         if force or _newer(out, srcs + [LIB]):
             _run([hipcc(), "-O2", "-std=c++17", "-Wall", "-o", out, src, "-L" + PKG, "-lcommet_hip",
-                  "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
+                  "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lz"])
         built.append(out)
     for tool in ("bvop", "filter_reads"):
         src = os.path.join(host, tool + ".cpp")
@@ -73,7 +73,7 @@ def build_tools(force=False):
             continue
         out = os.path.join(BIN_DIR, tool)
         if force or _newer(out, srcs):
-            _run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", out, src])
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", out, src, "-lz"])
         built.append(out)
     return built
 

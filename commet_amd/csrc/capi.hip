@@ -388,19 +388,21 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
 
 commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *paths, int n_paths)
 {
-    std::vector<std::unique_ptr<commet_host::MappedFile>> maps;
+    std::vector<std::unique_ptr<commet_host::ReadFileData>> maps;
+    std::vector<uint64_t> nrec;
     uint64_t max_reads = 0, max_bases = 0;
     for (int i = 0; i < n_paths; ++i) {
-        std::unique_ptr<commet_host::MappedFile> mf(new commet_host::MappedFile);
+        std::unique_ptr<commet_host::ReadFileData> mf(new commet_host::ReadFileData);
         if (!mf->open_file(paths[i])) {
             fail("Cannot open file %s", paths[i]);
             return nullptr;
         }
-        if (!mf->size() || mf->data()[0] != '>') {
-            fail("Unknown format: %s (plain FASTA expected)", paths[i]);
+        if (mf->format() == commet_host::ReadFormat::Unknown) {
+            fail("Unknown format: %s", paths[i]);
             return nullptr;
         }
-        max_reads += commet_host::count_fasta_records(mf->data(), mf->size());
+        nrec.push_back(commet_host::count_records(mf->format(), mf->data(), mf->size()));
+        max_reads += nrec.back();
         max_bases += mf->size();
         maps.push_back(std::move(mf));
     }
@@ -408,7 +410,8 @@ commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *path
     if (!rs) return nullptr;
     for (int i = 0; i < n_paths; ++i) {
         std::string err;
-        if (commet_readset_begin_file(rs) || commet_host::stream_fasta(rs, maps[i]->data(), maps[i]->size(), err)) {
+        if (commet_readset_begin_file(rs) ||
+            commet_host::stream_records(rs, maps[i]->format(), maps[i]->data(), maps[i]->size(), nrec[i], err)) {
             if (!err.empty()) fail("%s: %s", paths[i], err.c_str());
             commet_readset_destroy(rs);
             return nullptr;

@@ -103,14 +103,13 @@ int main(int argc, char **argv)
         output_message = "No output file name given, results will be written in " + in_name + ".bv\n";
         out_name = in_name + ".bv";
     }
-    MappedFile mf;
+    ReadFileData mf;
     if (!mf.open_file(in_name)) {
         std::cerr << "Cannot open file " << in_name << " -> quit\n";
         return 1;
     }
-    if (!mf.size() || mf.data()[0] != '>') {
+    if (mf.format() == ReadFormat::Unknown) {
         std::cerr << "Unknown format: " << in_name << " -> quit\n";
-        std::cerr << "(this build reads plain FASTA only)\n";
         return 1;
     }
     comment << "----------------\n";
@@ -127,34 +126,45 @@ int main(int argc, char **argv)
     const char *d = mf.data();
     const size_t n = mf.size();
     BitVector bv;
-    bv.init_true(count_fasta_records(d, n));
+    bv.init_true(count_records(mf.format(), d, n));
     if (max_reads == -1) max_reads = (long) bv.size;
     long rm_length = 0, rm_N = 0, rm_shannon = 0;
     uint64_t pos = 0;          // current_read_pos
-    size_t i = 0;
-    bool stopped_by_empty = false;
-    while (i < n && nb_selected < max_reads) {
-        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
-        size_t j = nl ? (size_t) (nl - d) + 1 : n;
-        ReadStats st;
-        while (j < n && d[j] != '>') {
-            nl = (const char *) memchr(d + j, '\n', n - j);
-            const size_t e = nl ? (size_t) (nl - d) : n;
-            st.add(d + j, e - j);
-            j = nl ? e + 1 : n;
-        }
-        i = j;
-        if (st.len == 0) {     // empty sequence == end-of-file sentinel of the reference iterator
-            stopped_by_empty = true;
-            break;
+    bool stopped = false;      // the reference iterator stops at an empty sequence / at the -m cap
+    auto judge = [&](const ReadStats &st) {
+        if (stopped) return;
+        if (nb_selected >= max_reads || st.len == 0) {   // loop condition of filter_reads.cpp:186
+            stopped = true;
+            return;
         }
         if ((int) st.len < min_size) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_length; }
         else if ((long) st.non_acgt > (long) max_N) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_N; }
         else if (st.shannon() < min_shannon) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_shannon; }
         else ++nb_selected;
         ++pos;                 // the look-ahead get_next_read (filter_reads.cpp:200)
+    };
+    if (mf.format() == ReadFormat::Fastq) {
+        for_each_fastq_record(d, n, bv.size, [&](const char *s, size_t len) {
+            ReadStats st;
+            st.add(s, len);
+            judge(st);
+        });
+    } else {
+        size_t i = 0;
+        while (i < n && !stopped) {
+            const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
+            size_t j = nl ? (size_t) (nl - d) + 1 : n;
+            ReadStats st;
+            while (j < n && d[j] != '>') {
+                nl = (const char *) memchr(d + j, '\n', n - j);
+                const size_t e = nl ? (size_t) (nl - d) : n;
+                st.add(d + j, e - j);
+                j = nl ? e + 1 : n;
+            }
+            i = j;
+            judge(st);
+        }
     }
-    (void) stopped_by_empty;
     if (nb_selected >= max_reads)   // untag_last_reads: everything from the look-ahead read on
         for (uint64_t r = pos; r < bv.size; ++r) bv.bytes[r >> 3] &= (uint8_t) ~(1u << (r & 7));
     bv.comment = comment.str();

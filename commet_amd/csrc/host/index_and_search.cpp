@@ -4,7 +4,7 @@
 // stdout banners, same OUT/<file>_in_<set>.bv bytes and LOG/<s>_in_<i>.log
 // format, so Commet.py (Commet.py:197,220,233) can call it unchanged.
 //
-// Host side = this file: argv, set-configs, FASTA -> pinned staging batches
+// Host side = this file: argv, set-configs, FASTA / FASTQ (plain or gzip) -> pinned staging batches
 // (fasta_source.hpp), filter / output .bv files (bv_file.hpp).  Everything
 // between "reads are resident" and "tag bits are back" runs in the library.
 //
@@ -81,12 +81,12 @@ struct LoadedSet {
 static void load_set(commet_ctx *ctx, const std::string &nickname, const std::vector<SetEntry> &entries, LoadedSet &out)
 {
     out.nickname = nickname;
-    std::vector<std::unique_ptr<MappedFile>> maps;
+    std::vector<std::unique_ptr<ReadFileData>> maps;
     uint64_t max_reads = 0, max_bases = 0;
     for (const SetEntry &en : entries) {
         if (en.bv.empty()) std::cout << "open " << en.file << "\n";
         else std::cout << "open " << en.file << "," << en.bv << "\n";
-        std::unique_ptr<MappedFile> mf(new MappedFile);
+        std::unique_ptr<ReadFileData> mf(new ReadFileData);
         if (!mf->open_file(en.file)) {
             if (en.bv.empty()) {
                 std::cerr << "Cannot open file file " << en.file << " -> ignore\n";   // file_manager.h:121-123
@@ -96,16 +96,13 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
             std::cerr << "Cannot open file " << en.file << " -> ignore\n";            // file_manager.h:177-180
             continue;
         }
-        const char first = mf->size() ? mf->data()[0] : '\0';
-        if (first != '>') {
-            // '@' = FASTQ, anything else = gzip in the reference (file_manager.h:132-157)
+        if (mf->format() == ReadFormat::Unknown) {   // neither '>' nor '@', plain or gzipped (file_manager.h:154-156)
             std::cerr << "Unknown format: " << en.file << " -> ignore\n";
-            std::cerr << "(this build reads plain FASTA only)\n";
             exit(1);
         }
         LoadedFile lf;
         lf.name = en.file;
-        lf.nb_reads = count_fasta_records(mf->data(), mf->size());
+        lf.nb_reads = count_records(mf->format(), mf->data(), mf->size());
         if (en.bv.empty()) lf.filter.init_true(lf.nb_reads);
         else {
             if (!read_bv(en.bv, lf.filter)) exit(1);
@@ -127,7 +124,8 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     }
     for (size_t i = 0; i < out.files.size(); ++i) {
         std::string err;
-        if (commet_readset_begin_file(out.rs) || stream_fasta(out.rs, maps[i]->data(), maps[i]->size(), err)) {
+        if (commet_readset_begin_file(out.rs) ||
+            stream_records(out.rs, maps[i]->format(), maps[i]->data(), maps[i]->size(), out.files[i].nb_reads, err)) {
             std::cerr << "Error: " << (err.empty() ? commet_last_error() : err.c_str()) << "\n";
             exit(1);
         }
@@ -138,7 +136,7 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     }
     out.n_reads = commet_readset_num_reads(out.rs);
     if (out.n_reads != max_reads) {
-        std::cerr << "Error in Fasta format !!\n";   // fasta_file.h:158-161
+        std::cerr << "Error in Fasta format !!\n";   // fasta_file.h:158-161 (record count and records disagree)
         exit(1);
     }
     // set-wide select bits = the per-file filters, concatenated

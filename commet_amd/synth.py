@@ -65,3 +65,19 @@ def write_fasta(path, bases, offsets, width=0, lowercase_every=0):
                     fh.write(s[j:j + width] + b"\n")
             else:
                 fh.write(s + b"\n")
+
+
+def write_fasta_fast(path, bases, n_reads, read_len, digits=9):
+    """Vectorised writer for fixed-length sets: header '>%0<digits>d', one sequence line."""
+    rec = 1 + digits + 1 + read_len + 1
+    buf = np.empty((n_reads, rec), dtype=np.uint8)
+    buf[:, 0] = ord(">")
+    idx = np.arange(n_reads, dtype=np.int64)
+    for d in range(digits):
+        buf[:, digits - d] = (idx % 10 + ord("0")).astype(np.uint8)
+        idx //= 10
+    buf[:, 1 + digits] = ord("\n")
+    buf[:, 2 + digits:2 + digits + read_len] = np.asarray(bases, dtype=np.uint8).reshape(n_reads, read_len)
+    buf[:, -1] = ord("\n")
+    with open(path, "wb") as fh:
+        fh.write(buf.tobytes())

@@ -78,11 +78,12 @@ int             commet_readset_stage_commit(commet_readset *rs, uint64_t n_reads
 /* Convenience: copies (bases, offsets[n_reads+1]) through the staging buffers. */
 int             commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets,
                                       uint64_t n_reads);
-/* Host ingest of a whole set: maps the plain-FASTA files (one per file of the set, in
- * order), counts their records, creates the read set and streams every record
- * through the pinned staging buffers (records as the reference reads them,
- * fasta_file.h:155-175).  Replaces FileManager::addFile + FastaFile for resident
- * sets (file_manager.h:117-171).  The set is NOT finalized.  NULL on error. */
+/* Host ingest of a whole set: opens the read files (FASTA or FASTQ, plain or gzip,
+ * sniffed like file_manager.h:125-157; one per file of the set, in order), counts
+ * their records, creates the read set and streams every record through the pinned
+ * staging buffers (records as the reference reads them, fasta_file.h:155-175,
+ * fastq_file.h:139-190).  Replaces FileManager::addFile + the ReadFile parsers for
+ * resident sets (file_manager.h:117-171).  The set is NOT finalized.  NULL on error. */
 commet_readset *commet_readset_from_fasta(commet_ctx *ctx, const char *const *paths, int n_paths);
 /* reads of file `file_index` of the set (all records, selected or not) */
 uint64_t        commet_readset_file_reads(const commet_readset *rs, uint64_t file_index);

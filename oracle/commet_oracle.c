@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
+#include <zlib.h>
 
 /* ======================================================================== */
 /* HashKey — include/hash_key.h                                             */
@@ -378,17 +379,95 @@ static void ok_file_rewind(ok_file *f)
     f->first_read = 1;
 }
 
-static int ok_file_parse(ok_file *f, const char *path)
+/* whole file in memory; gzip (or anything zlib passes through) when the first
+ * byte is neither '>' nor '@' (file_manager.h:125-157) */
+static char *slurp(const char *path, long *size_out)
 {
     FILE *fp = fopen(path, "rb");
-    if (!fp) return 1;
+    if (!fp) return NULL;
     fseek(fp, 0, SEEK_END);
     long fsz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
     char *buf = (char *) malloc((size_t) fsz + 1);
-    if (fread(buf, 1, (size_t) fsz, fp) != (size_t) fsz) { fclose(fp); free(buf); return 1; }
+    if (fread(buf, 1, (size_t) fsz, fp) != (size_t) fsz) { fclose(fp); free(buf); return NULL; }
     fclose(fp);
     buf[fsz] = 0;
+    if (fsz > 0 && (buf[0] == '>' || buf[0] == '@')) {
+        *size_out = fsz;
+        return buf;
+    }
+    free(buf);
+    gzFile g = gzopen(path, "r");
+    if (!g) return NULL;
+    size_t cap = 1 << 20, n = 0;
+    buf = (char *) malloc(cap + 1);
+    for (;;) {
+        if (cap - n < (1 << 16)) {
+            cap *= 2;
+            buf = (char *) realloc(buf, cap + 1);
+        }
+        int got = gzread(g, buf + n, (unsigned) (cap - n));
+        if (got <= 0) break;
+        n += (size_t) got;
+    }
+    gzclose(g);
+    buf[n] = 0;
+    *size_out = (long) n;
+    return buf;
+}
+
+/* FASTQ records (fastq_file.h:60-67, 139-190): #records = non-empty lines / 4;
+ * header (blank lines before it skipped), the next line verbatim = sequence,
+ * '+' line and quality line (blank lines before each skipped). */
+static int ok_file_parse_fastq(ok_file *f, char *buf, long fsz)
+{
+    uint64_t lines = 0;
+    for (long i = 0; i < fsz;) {
+        char *nl = (char *) memchr(buf + i, '\n', (size_t) (fsz - i));
+        long e = nl ? (nl - buf) : fsz;
+        if (e > i) lines++;
+        i = nl ? e + 1 : fsz;
+    }
+    uint64_t n = lines / 4;
+    f->nb_reads = n;
+    f->seqs = (char *) malloc((size_t) fsz + 1);
+    f->seq_off = (uint64_t *) calloc(n + 1, sizeof(uint64_t));
+    uint64_t w = 0;
+    long i = 0;
+    for (uint64_t r = 0; r < n; r++) {
+        long b, e;
+        int ok;
+#define NEXT_LINE() (i < fsz ? (b = i, e = (memchr(buf + i, '\n', (size_t) (fsz - i)) ? (char *) memchr(buf + i, '\n', (size_t) (fsz - i)) - buf : fsz), i = (e < fsz ? e + 1 : fsz), 1) : 0)
+        while ((ok = NEXT_LINE()) && e == b) {}
+        f->seq_off[r] = w;
+        if (!ok) { for (uint64_t q = r; q <= n; q++) f->seq_off[q] = w; return 0; }
+        if (NEXT_LINE()) {
+            memcpy(f->seqs + w, buf + b, (size_t) (e - b));
+            w += (uint64_t) (e - b);
+        }
+        while ((ok = NEXT_LINE()) && e == b) {}
+        if (ok) while ((ok = NEXT_LINE()) && e == b) {}
+#undef NEXT_LINE
+    }
+    f->seq_off[n] = w;
+    return 0;
+}
+
+static int ok_file_parse(ok_file *f, const char *path)
+{
+    long fsz = 0;
+    char *buf = slurp(path, &fsz);
+    if (!buf) return 1;
+    if (fsz > 0 && buf[0] == '@') {
+        int rc = ok_file_parse_fastq(f, buf, fsz);
+        free(buf);
+        return rc;
+    }
+    if (!(fsz > 0 && buf[0] == '>')) {
+        fprintf(stderr, "Unknown format: %s -> ignore\n", path);
+        free(buf);
+        return 1;
+    }
     /* pass 1: count records (lines starting with '>') */
     uint64_t n = 0;
     for (long i = 0; i < fsz;) {
@@ -404,11 +483,6 @@ static int ok_file_parse(ok_file *f, const char *path)
      * (fasta_file.h:155-175).  '\r' and any other byte stay in the sequence. */
     uint64_t r = 0, w = 0;
     long i = 0;
-    /* bytes before the first '>' line never belong to a record */
-    while (i < fsz && buf[i] != '>') {
-        char *nl = (char *) memchr(buf + i, '\n', (size_t) (fsz - i));
-        i = nl ? (nl - buf) + 1 : fsz;
-    }
     while (i < fsz) {
         /* header */
         char *nl = (char *) memchr(buf + i, '\n', (size_t) (fsz - i));
@@ -704,12 +778,7 @@ static int ok_fm_add_file(ok_fm *m, const char *fname, const char *bvname)
         fprintf(stderr, "Cannot open file %s -> ignore\n", fname);
         return bvname[0] ? 0 : 1;
     }
-    int c = fgetc(fp);
     fclose(fp);
-    if (c != '>') {
-        fprintf(stderr, "oracle: only plain FASTA is restated (%s)\n", fname);
-        return 1;
-    }
     m->files = (ok_file *) realloc(m->files, sizeof(ok_file) * (size_t) (m->nfiles + 1));
     ok_file *f = &m->files[m->nfiles];
     memset(f, 0, sizeof *f);

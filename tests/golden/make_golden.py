@@ -35,7 +35,8 @@ import numpy as np  # noqa: E402
 
 from scenarios import Scenario, run_tool  # noqa: E402
 
-SCENARIO_SEEDS = list(range(1000, 1016))
+SCENARIO_SEEDS = list(range(1000, 1024))
+MIXED_FORMAT_SEEDS = set(range(1016, 1024))     # FASTQ / gzip inputs
 
 
 def make_scenarios():
@@ -44,7 +45,8 @@ def make_scenarios():
     meta = {}
     for seed in SCENARIO_SEEDS:
         d = os.path.join(base, f"s{seed}")
-        scn = Scenario(d, seed, n_scale=0.6)
+        scn = Scenario(d, seed, n_scale=0.6, **({"formats": ("fa", "fq", "fa.gz", "fq.gz"), "crlf": False}
+                                               if seed in MIXED_FORMAT_SEEDS else {}))
         p = run_tool(REF_BIN, scn, "expected", "expected_log")
         assert p.returncode == 0, p.stderr
         lines = {}

@@ -10,7 +10,7 @@ import util
 
 
 class Scenario:
-    def __init__(self, d, seed, k=None, t=None, n_scale=1.0, allow_bv=True, allow_zero_bv=True, crlf=None):
+    def __init__(self, d, seed, k=None, t=None, n_scale=1.0, allow_bv=True, allow_zero_bv=True, crlf=None, formats=("fa",)):
         rng = np.random.default_rng(seed)
         self.dir = d
         self.k = int(k if k is not None else rng.choice([8, 10, 12, 13, 16, 20, 25]))
@@ -32,8 +32,9 @@ class Scenario:
                 # no empty sequences: the reference's behaviour on them is undefined
                 reads = [r if len(r) else b"A" for r in reads]
                 pool.extend(reads[: max(1, n // 2)])
-                fa = f"{name}_f{fi}.fa"          # relative: tools run with cwd = scenario dir
-                util.write_fasta(os.path.join(d, fa), reads, rng=rng, multiline=multiline, crlf=crlf)
+                fmt = formats[int(rng.integers(0, len(formats)))] if len(formats) > 1 else formats[0]
+                fa = f"{name}_f{fi}.{fmt}"       # relative: tools run with cwd = scenario dir
+                util.write_reads(os.path.join(d, fa), reads, fmt, rng=rng, multiline=multiline, crlf=crlf)
                 bv = None
                 sel = np.ones(n, dtype=bool)
                 if allow_bv and rng.random() < 0.5:
@@ -133,7 +134,7 @@ class GoldenScenario:
                     parts = item.strip(" ").split(",")
                     fa = parts[0].strip(" ")
                     bv = parts[1].strip(" ") if len(parts) > 1 else None
-                    reads = util.parse_fasta(os.path.join(self.dir, fa))
+                    reads = util.parse_reads(os.path.join(self.dir, fa))
                     if bv:
                         _, n, bits = util.read_bv(os.path.join(self.dir, bv))
                         sel = util.bools_from_bits(bits, n)

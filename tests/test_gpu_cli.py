@@ -42,9 +42,10 @@ def _strip_times(text):
     return re.sub(r"(Index  time|Search time|Total  time): .* s", r"\1: T s", text)
 
 
-@pytest.mark.parametrize("seed", range(2000, 2030))
+@pytest.mark.parametrize("seed", range(2000, 2050))
 def test_cli_matches_oracle_and_reference(tmp_path, seed):
-    scn = Scenario(str(tmp_path / "scn"), seed)
+    mixed = seed >= 2030        # FASTQ / gzip inputs, format chosen per file
+    scn = Scenario(str(tmp_path / "scn"), seed, **({"formats": ("fa", "fq", "fa.gz", "fq.gz"), "crlf": False} if mixed else {}))
     out_g, log_g = str(tmp_path / "out_gpu"), str(tmp_path / "log_gpu")
     out_o, log_o = str(tmp_path / "out_orc"), str(tmp_path / "log_orc")
     p = run_tool(TOOL, scn, out_g, log_g)

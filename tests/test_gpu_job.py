@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _load_set(commet, ctx, files, sdir):
-    batches = [util.to_batch(util.parse_fasta(os.path.join(sdir, fa))) for fa, _, _, _ in files]
+    batches = [util.to_batch(util.parse_reads(os.path.join(sdir, fa))) for fa, _, _, _ in files]
     rs = commet.ReadSet.from_files(ctx, batches)
     sel = np.concatenate([s for _, _, _, s in files]) if files else np.zeros(0, bool)
     has_bv = any(bv for _, bv, _, _ in files)

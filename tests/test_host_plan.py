@@ -62,7 +62,7 @@ def _scenario_index_inputs(scn):
     sel = np.concatenate([s for _, _, _, s in files]) if has_bv else None
     reads = [r for _, _, rr, _ in files for r in rr]
     # CRLF files keep the '\r' in the sequence: count k-mers on what the tools see
-    parsed = [r for fa, _, _, _ in files for r in util.parse_fasta(os.path.join(scn.dir, fa))]
+    parsed = [r for fa, _, _, _ in files for r in util.parse_reads(os.path.join(scn.dir, fa))]
     assert len(parsed) == len(reads)
     b, o = util.to_batch(parsed)
     return counts, sel, ob.kmer_counts(b, o, scn.k)

@@ -20,7 +20,7 @@ def _tools_built():
         os.makedirs(BIN, exist_ok=True)
         for tool in ("bvop", "filter_reads"):
             subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o",
-                            os.path.join(BIN, tool), os.path.join(ROOT, "commet_amd", "csrc", "host", tool + ".cpp")],
+                            os.path.join(BIN, tool), os.path.join(ROOT, "commet_amd", "csrc", "host", tool + ".cpp"), "-lz"],
                            check=True)
 
 

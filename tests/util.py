@@ -139,3 +139,56 @@ def parse_fasta(path):
     if cur is not None:
         reads.append(b"".join(cur))
     return reads
+
+
+def write_fastq(path, reads, crlf=False):
+    nl = b"\r\n" if crlf else b"\n"
+    with open(path, "wb") as fh:
+        for i, r in enumerate(reads):
+            fh.write(b"@r%d text" % i + nl + r + nl + b"+" + nl + b"I" * len(r) + nl)
+
+
+def write_reads(path, reads, fmt, rng=None, multiline=False, crlf=False):
+    """fmt: fa | fq | fa.gz | fq.gz"""
+    import gzip
+    import shutil
+    plain = path[:-3] + ".tmp" if fmt.endswith(".gz") else path
+    if fmt.startswith("fq"):
+        write_fastq(plain, reads, crlf=crlf)
+    else:
+        write_fasta(plain, reads, rng=rng, multiline=multiline, crlf=crlf)
+    if fmt.endswith(".gz"):
+        with open(plain, "rb") as fi, gzip.GzipFile(path, "wb", mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+        os.remove(plain)
+
+
+def parse_reads(path):
+    """sequences of a read file of any supported format, as the tools see them"""
+    import gzip
+    data = open(path, "rb").read()
+    if data[:2] == b"\x1f\x8b":
+        data = gzip.decompress(data)
+    if data[:1] == b"@":
+        lines = data.split(b"\n")
+        out, i = [], 0
+        n = sum(1 for ln in lines if ln) // 4
+        for _ in range(n):
+            while i < len(lines) and not lines[i]:
+                i += 1
+            i += 1
+            out.append(lines[i] if i < len(lines) else b"")
+            i += 1
+            while i < len(lines) and not lines[i]:
+                i += 1
+            i += 1
+            while i < len(lines) and not lines[i]:
+                i += 1
+            i += 1
+        return out
+    tmp = path + ".parse_tmp"
+    open(tmp, "wb").write(data)
+    try:
+        return parse_fasta(tmp)
+    finally:
+        os.remove(tmp)
