@@ -730,10 +730,14 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     }
     HIP_OK(hipSetDevice(c->device));
 
+    // an input filter that selects every read is no filter (Commet.py passes all-ones bvs when nothing was filtered)
+    if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
     // host plan: chunks of the index set, visited reads of each search set
     const uint64_t max_kmer = commet_max_kmer(c);
     const IndexPlan plan = plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
                                ? plan_index_fast(index_rs->h_kprefix, index_rs->n_reads, max_kmer)
+                           : (index_select && index_rs->empty_reads.empty())
+                               ? plan_index_select(index_rs->files, index_select, index_rs->h_kcnt.data(), index_rs->n_reads, max_kmer)
                                : plan_index(index_rs->files, index_select, index_rs->empty_reads, index_rs->h_kcnt.data(),
                                             index_rs->n_reads, max_kmer);
     std::vector<uint64_t> visited(n_search, 0);
@@ -742,7 +746,9 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     for (int s = 0; s < n_search; ++s) {
         const commet_readset *rs = search_rs[s];
         const uint8_t *ssel = search_select ? search_select[s] : nullptr;
+        if (ssel && all_ones(ssel, rs->n_reads)) ssel = nullptr;
         vis[s] = plan_fast_ok(rs->files, ssel, rs->empty_reads, 1) ? plan_search_fast(rs->n_reads, &visited[s])
+                 : (ssel && rs->empty_reads.empty())                ? plan_search_select(rs->files, ssel, rs->n_reads, &visited[s])
                                                                     : plan_search(rs->files, ssel, rs->empty_reads, rs->n_reads, &visited[s]);
         if (upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
         HIP_OK(hipMemsetAsync(rs->d_tags, 0, bitmap_words(rs->n_reads) * 8, c->stream));

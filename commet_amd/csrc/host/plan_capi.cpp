@@ -26,6 +26,8 @@ uint64_t commet_plan_index(const uint64_t *files, int n_files, const uint8_t *se
     if (fast && plan_fast_ok(fs, select, er, max_kmer)) {
         build_kmer_prefix(kcnt, n_reads, prefix);
         plan = plan_index_fast(prefix, n_reads, max_kmer);
+    } else if (fast && select && er.empty()) {
+        plan = plan_index_select(fs, select, kcnt, n_reads, max_kmer);
     } else {
         plan = plan_index(fs, select, er, kcnt, n_reads, max_kmer);
     }
@@ -52,6 +54,7 @@ uint64_t commet_plan_search(const uint64_t *files, int n_files, const uint8_t *s
     uint64_t n = 0;
     std::vector<uint8_t> bits;
     if (fast && plan_fast_ok(fs, select, er, 1)) bits = plan_search_fast(n_reads, &n);
+    else if (fast && select && er.empty()) bits = plan_search_select(fs, select, n_reads, &n);
     else bits = plan_search(fs, select, er, n_reads, &n);
     memcpy(visited_bits_out, bits.data(), bits.size());
     return n;

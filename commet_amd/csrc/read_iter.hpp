@@ -28,6 +28,54 @@ struct FileSpan {
 inline bool bit_at(const uint8_t *bits, uint64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
 inline void bit_on(uint8_t *bits, uint64_t i) { bits[i >> 3] |= (uint8_t) (1u << (i & 7)); }
 
+// number of set bits in [lo, hi)
+inline uint64_t count_bits(const uint8_t *bits, uint64_t lo, uint64_t hi)
+{
+    uint64_t n = 0;
+    while (lo < hi && (lo & 7)) n += bit_at(bits, lo++);
+    while (hi > lo && (hi & 7)) n += bit_at(bits, --hi);
+    for (uint64_t b = lo >> 3; b < (hi >> 3); ++b) n += (uint64_t) __builtin_popcount(bits[b]);
+    return n;
+}
+
+// true when bits [0, n) are all set
+inline bool all_ones(const uint8_t *bits, uint64_t n)
+{
+    const uint64_t full = n >> 3;
+    uint64_t b = 0;
+    for (; b + 8 <= full; b += 8) {
+        uint64_t w;
+        __builtin_memcpy(&w, bits + b, 8);
+        if (w != ~0ull) return false;
+    }
+    for (; b < full; ++b)
+        if (bits[b] != 0xFF) return false;
+    for (uint64_t i = full << 3; i < n; ++i)
+        if (!bit_at(bits, i)) return false;
+    return true;
+}
+
+// first set bit at or after `from`, below `end`; returns end if none
+inline uint64_t next_set_bit(const uint8_t *bits, uint64_t from, uint64_t end)
+{
+    while (from < end) {
+        const uint32_t byte = bits[from >> 3] >> (from & 7);
+        if (byte) {
+            const uint64_t r = from + (uint64_t) __builtin_ctz(byte);
+            return r < end ? r : end;
+        }
+        from = (from | 7) + 1;
+        // skip zero bytes quickly
+        while (from + 64 <= end && (from & 63) == 0) {
+            uint64_t w;
+            __builtin_memcpy(&w, bits + (from >> 3), 8);
+            if (w) break;
+            from += 64;
+        }
+    }
+    return end;
+}
+
 // One file: FastaFile's iterator state (fasta_file.h:132-183, 258-264).
 struct FileCursor {
     FileSpan span{0, 0};
@@ -56,12 +104,7 @@ public:
         for (const FileSpan &s : files) {
             FileCursor c;
             c.span = s;
-            if (!select) c.nb_valid = s.count;
-            else {
-                uint64_t n = 0;
-                for (uint64_t i = 0; i < s.count; ++i) n += bit_at(select, s.first + i);
-                c.nb_valid = n;
-            }
+            c.nb_valid = select ? count_bits(select, s.first, s.first + s.count) : s.count;
             files_.push_back(c);
         }
         current_file_ = files_.empty() ? -1 : 0;
@@ -114,9 +157,8 @@ private:
         if (c.first_read) c.first_read = false;
         else ++c.pos;
         if (c.cnt_valid < c.nb_valid) {
-            if (select_) {
-                while (c.pos < c.span.count && !bit_at(select_, c.span.first + c.pos)) ++c.pos;   // :143-152
-            }
+            if (select_)   // skip unselected reads (:143-152)
+                c.pos = next_set_bit(select_, c.span.first + c.pos, c.span.first + c.span.count) - c.span.first;
             if (c.pos < c.span.count) {
                 const uint64_t r = c.span.first + c.pos;
                 if (!empty_.empty() && is_empty_read(r)) return NONE;   // empty sequence == EOF sentinel (:178-182)
@@ -253,6 +295,165 @@ inline std::vector<uint8_t> plan_search_fast(uint64_t n_reads, uint64_t *n_visit
     for (uint64_t i = 0; i < n_reads / 8; ++i) bits[i] = 0xFF;
     for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i) bit_on(bits.data(), i);
     if (n_visited) *n_visited = n_reads;
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
+// Plans with an input filter but no empty sequence: the iterator reduces to
+// "next set bit of the current file", plus one end-marker when a file with no
+// selected read is entered from the previous file (a leading such file is
+// skipped silently), plus the final end-marker.  Same results as SetIterator,
+// without its per-read bookkeeping (tests/test_host_plan.py).
+// ---------------------------------------------------------------------------
+class SelectedIterator {
+public:
+    static constexpr uint64_t NONE = ~0ull;
+    SelectedIterator(const std::vector<FileSpan> &files, const uint8_t *select) : files_(files), select_(select)
+    {
+        nb_valid_.reserve(files.size());
+        for (const FileSpan &f : files) {
+            nb_valid_.push_back(count_bits(select, f.first, f.first + f.count));
+            total_ += nb_valid_.back();
+        }
+        if (!files_.empty()) {
+            pos_ = files_[0].first;
+            end_ = files_[0].first + files_[0].count;
+        }
+    }
+    uint64_t total_valid() const { return total_; }
+    const std::vector<uint64_t> &nb_valid() const { return nb_valid_; }
+    inline uint64_t next()
+    {
+        for (;;) {
+            if (cf_ >= files_.size()) return NONE;
+            if (pos_ < end_) {
+                const uint64_t r = next_set_bit(select_, pos_, end_);
+                if (r < end_) {
+                    pos_ = r + 1;
+                    return r;
+                }
+                pos_ = end_;
+            }
+            ++cf_;                                    // current file exhausted
+            if (cf_ >= files_.size()) return NONE;    // end of the set
+            pos_ = files_[cf_].first;
+            end_ = pos_ + files_[cf_].count;
+            if (nb_valid_[cf_] == 0) {                // entering a file with nothing selected ends the pass / chunk
+                pos_ = end_;
+                return NONE;
+            }
+        }
+    }
+
+private:
+    const std::vector<FileSpan> &files_;
+    const uint8_t *select_;
+    std::vector<uint64_t> nb_valid_;
+    uint64_t total_ = 0;
+    size_t cf_ = 0;
+    uint64_t pos_ = 0, end_ = 0;
+};
+
+// Event-driven form of the two nested loops of main() / index_reads: the stream of
+// fetches (selected reads in order, an end-marker when a file with nothing selected
+// is entered, the final end-marker) is generated 64 select bits at a time.
+inline IndexPlan plan_index_select(const std::vector<FileSpan> &files, const uint8_t *select, const uint32_t *kcnt,
+                                   uint64_t n_reads, uint64_t max_kmer)
+{
+    IndexPlan plan;
+    plan.indexed_bits.assign(n_reads / 8 + 1, 0);
+    uint8_t *bits = plan.indexed_bits.data();
+    std::vector<uint64_t> nb_valid;
+    uint64_t to_index = 0;
+    for (const FileSpan &f : files) {
+        nb_valid.push_back(count_bits(select, f.first, f.first + f.count));
+        to_index += nb_valid.back();
+    }
+    uint64_t seen = 0;
+    bool in_chunk = false, stop = false;
+    Chunk ch;
+    auto close_chunk = [&]() {
+        plan.indexed_reads += ch.n_reads;
+        plan.kmers += ch.kmers;
+        plan.chunks.push_back(ch);
+        ch = Chunk();
+        in_chunk = false;
+    };
+    // one fetch of the iterator: r = read number or NONE
+    auto fetch = [&](uint64_t r) {
+        if (!in_chunk) {                      // outer loop test, then the first fetch of index_reads
+            if (seen >= to_index) {
+                stop = true;
+                return;
+            }
+            in_chunk = true;
+        }
+        ++seen;
+        if (r != SetIterator::NONE && ch.kmers < max_kmer) {
+            if (ch.n_reads == 0) ch.first = r;
+            ch.last = r;
+            ++ch.n_reads;
+            ch.kmers += kcnt[r];
+            bit_on(bits, r);
+        } else {
+            close_chunk();                    // r (if a read) is the dropped look-ahead
+        }
+    };
+    for (size_t fi = 0; fi < files.size() && !stop; ++fi) {
+        const uint64_t lo = files[fi].first, hi = lo + files[fi].count;
+        if (nb_valid[fi] == 0) {
+            if (fi >= 1) fetch(SetIterator::NONE);   // entering a file with nothing selected
+            continue;
+        }
+        uint64_t a = lo;
+        while (a < hi && !stop) {
+            // up to 64 select bits starting at a (unaligned tail handled by the mask)
+            const uint64_t nb = std::min<uint64_t>(64 - (a & 7), hi - a);
+            uint64_t w = 0;
+            const uint64_t byte0 = a >> 3, nbytes = ((a & 7) + nb + 7) >> 3;
+            __builtin_memcpy(&w, select + byte0, nbytes > 8 ? 8 : nbytes);
+            w >>= (a & 7);
+            if (nb < 64) w &= (1ull << nb) - 1;
+            while (w && !stop) {
+                const uint64_t r = a + (uint64_t) __builtin_ctzll(w);
+                w &= w - 1;
+                fetch(r);
+            }
+            a += nb;
+        }
+    }
+    if (!stop) {
+        // the final end-marker(s): index_reads keeps being called while seen < total (never more than once here)
+        while (!stop && (in_chunk || seen < to_index)) fetch(SetIterator::NONE);
+    }
+    return plan;
+}
+
+// visited = selected reads of file 0 and of the following files up to (not including) the first file with no
+// selected read; whole byte ranges are copied, file edges bit by bit
+inline std::vector<uint8_t> plan_search_select(const std::vector<FileSpan> &files, const uint8_t *select, uint64_t n_reads,
+                                               uint64_t *n_visited)
+{
+    std::vector<uint8_t> bits(n_reads / 8 + 1, 0);
+    uint64_t n = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        const uint64_t lo = files[i].first, hi = lo + files[i].count;
+        const uint64_t nv = count_bits(select, lo, hi);
+        if (i >= 1 && nv == 0) break;
+        n += nv;
+        uint64_t a = lo;
+        while (a < hi && (a & 7)) {
+            if (bit_at(select, a)) bit_on(bits.data(), a);
+            ++a;
+        }
+        uint64_t b = hi;
+        while (b > a && (b & 7)) {
+            --b;
+            if (bit_at(select, b)) bit_on(bits.data(), b);
+        }
+        if (b > a) __builtin_memcpy(bits.data() + (a >> 3), select + (a >> 3), (b - a) >> 3);
+    }
+    if (n_visited) *n_visited = n;
     return bits;
 }
 

@@ -137,3 +137,35 @@ def test_search_plan_stops_at_empty_selection(plan):
     assert nv == 6 and v.tolist() == [False] * 3 + [True] * 6
     nv, v = visited([3, 3, 3], None, fast=True)
     assert nv == 9 and v.all()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_selected_plans_equal_generic_plans(plan, seed):
+    """input-filter fast paths (SelectedIterator / plan_search_select) vs the reference-shaped SetIterator"""
+    rng = np.random.default_rng(1000 + seed)
+    nfiles = int(rng.integers(1, 6))
+    counts = [int(rng.integers(1, 300)) for _ in range(nfiles)]
+    n = sum(counts)
+    kcnt = rng.integers(0, 90, size=n).astype(np.uint32)
+    sel = rng.random(n) < rng.uniform(0.05, 0.95)
+    pos = 0
+    for c in counts:                       # some files with nothing selected, at every position
+        if rng.random() < 0.35:
+            sel[pos:pos + c] = False
+        pos += c
+    for max_kmer in (0, 1, 50, 900, 10 ** 9):
+        a = plan_index(plan, counts, sel, kcnt, max_kmer, fast=False)
+        b = plan_index(plan, counts, sel, kcnt, max_kmer, fast=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (seed, max_kmer)
+    files = np.zeros(2 * nfiles, dtype=np.uint64)
+    pos = 0
+    for i, c in enumerate(counts):
+        files[2 * i], files[2 * i + 1] = pos, c
+        pos += c
+    s = util.bits_from_bools(sel)
+    out = []
+    for fast in (0, 1):
+        bits = np.zeros(n // 8 + 1, dtype=np.uint8)
+        nv = plan.commet_plan_search(_p(files), nfiles, _p(s), None, 0, n, fast, _p(bits))
+        out.append((nv, bits.copy()))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
