@@ -209,11 +209,6 @@ int main(int argc, char **argv)
         }
         ++arg_pos;
     }
-    if (full) {
-        std::cerr << "Error: the -f (full comparison) mode is not provided by this build\n";
-        return 1;
-    }
-
     ensure_dir(log_path);
     ensure_dir(out_path);
 
@@ -237,10 +232,11 @@ int main(int argc, char **argv)
     load_set(ctx, index_sets.begin()->first, index_sets.begin()->second, index_set);
 
     if (!read_sets(search_file_list, search_sets)) exit(1);
-    std::vector<LoadedSet> searches(search_sets.size());
+    // -f: only the first search set is opened (index_and_search.cpp:231-233)
+    std::vector<LoadedSet> searches(full && !search_sets.empty() ? 1 : search_sets.size());
     {
         size_t s = 0;
-        for (SetMap::iterator it = search_sets.begin(); it != search_sets.end(); ++it, ++s)
+        for (SetMap::iterator it = search_sets.begin(); it != search_sets.end() && s < searches.size(); ++it, ++s)
             load_set(ctx, it->first, it->second, searches[s]);
     }
     if (searches.empty()) {
@@ -306,20 +302,78 @@ int main(int argc, char **argv)
         log_file.close();
     }
 
-    // save_bv (index_and_search.cpp:397-399, file_manager.h:245-252)
-    for (int s = 0; s < ns; ++s) {
+    // FileManager::save_bv (file_manager.h:245-252): one .bv per file of `set`, bits taken from set-wide tags
+    auto save_bv = [&](const LoadedSet &set, const std::vector<uint8_t> &set_tags, const std::string &suffix) {
         uint64_t pos = 0;
-        for (const LoadedFile &lf : searches[s].files) {
+        for (const LoadedFile &lf : set.files) {
             BitVector bv;
             bv.init_false(lf.nb_reads);
             for (uint64_t i = 0; i < lf.nb_reads; ++i)
-                if ((tags[s][(pos + i) >> 3] >> ((pos + i) & 7)) & 1) bv.set(i);
+                if ((set_tags[(pos + i) >> 3] >> ((pos + i) & 7)) & 1) bv.set(i);
             pos += lf.nb_reads;
             const std::string base = lf.name.substr(lf.name.rfind("/") + 1);
-            bv.comment = lf.name + " in " + index_set.nickname;
-            if (!write_bv(out_path + "/" + base + "_in_" + index_set.nickname + ".bv", bv)) exit(1);
+            bv.comment = lf.name + " in " + suffix;
+            if (!write_bv(out_path + "/" + base + "_in_" + suffix + ".bv", bv)) exit(1);
         }
+    };
+
+    if (full) {
+        // Full comparison on the first search set (index_and_search.cpp:304-391): A = index set, B = search set.
+        //   pass 1 (above)  B in A                                   -> T1
+        //   pass 2          A in (B restricted to T1)                -> T2, written as <A files>_in_<B>.bv
+        //   pass 3          (B restricted to T1) in (A restricted to T2) -> written as <B files>_in_<A>.bv
+        LoadedSet &A = index_set, &B = searches[0];
+        auto popcount = [](const std::vector<uint8_t> &bits, uint64_t n) {
+            uint64_t c = 0;
+            for (uint64_t i = 0; i < n; ++i) c += (bits[i >> 3] >> (i & 7)) & 1;
+            return c;
+        };
+        const uint64_t nb_reads_A = popcount(A.select, A.n_reads), nb_reads_B = popcount(B.select, B.n_reads);
+        const std::vector<uint8_t> T1 = tags[0];
+        auto one_pass = [&](const LoadedSet &idx, const uint8_t *idx_sel, const LoadedSet &srch, const uint8_t *srch_sel,
+                            std::vector<uint8_t> &out_tags, const std::string &banner, const std::string &log_name,
+                            uint64_t denom, bool save_now, const std::string &save_suffix) {
+            std::ofstream log_file(log_name.c_str());
+            if (!log_file.good()) {
+                std::cerr << "Cannot open log file " << log_name << " -> exit\n";
+                exit(1);
+            }
+            std::cout << "\n------------------------------------------------------------------\n";
+            std::cout << banner << "\n";
+            std::cout << "------------------------------------------------------------------\n";
+            const auto t0 = std::chrono::steady_clock::now();
+            const commet_readset *q = srch.rs;
+            out_tags.assign(srch.n_reads / 8 + 1, 0);
+            uint8_t *tp = out_tags.data();
+            commet_pair_stats st;
+            commet_job_info inf;
+            if (commet_index_and_search(ctx, idx.rs, idx_sel, 1, &q, &srch_sel, &tp, &st, &inf)) {
+                std::cerr << "Error: " << commet_last_error() << "\n";
+                exit(1);
+            }
+            if (save_now) save_bv(srch, out_tags, save_suffix);
+            const float tot = (float) std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (std::ostream *os : {(std::ostream *) &std::cout, (std::ostream *) &log_file}) {
+                *os << "Index  time: " << (float) (inf.index_ms / 1000.0) << " s\n";
+                *os << "Search time: " << (float) (st.search_ms / 1000.0) << " s\n";
+                *os << "Total  time: " << tot << " s\n";
+                *os << "[indexed " << st.indexed << ", searched " << st.searched << ", shared " << st.shared << "]\n"
+                    << 100 * (float) st.shared / (float) denom << "%\n";
+            }
+        };
+        std::vector<uint8_t> T2, T3;
+        one_pass(B, T1.data(), A, A.select.data(), T2,
+                 "finding reads from {" + A.nickname + "} present in {raw {" + B.nickname + "} present in raw {" + A.nickname + "}}",
+                 log_path + "/" + A.nickname + "_in_" + B.nickname + ".log", nb_reads_A, true, B.nickname);
+        one_pass(A, T2.data(), B, T1.data(), T3,
+                 "finding reads from {" + B.nickname + "} present in {raw {" + A.nickname + "} present in {raw {" + B.nickname +
+                     "} present in raw {" + A.nickname + "}}}",
+                 log_path + "/" + B.nickname + "_in_" + A.nickname + ".log", nb_reads_B, true, A.nickname);
+        tags[0] = T3;
     }
+
+    // save_bv (index_and_search.cpp:397-399)
+    for (int s = 0; s < ns; ++s) save_bv(searches[s], tags[s], index_set.nickname);
 
     for (LoadedSet &ls : searches) commet_readset_destroy(ls.rs);
     commet_readset_destroy(index_set.rs);

@@ -37,6 +37,7 @@ from scenarios import Scenario, run_tool  # noqa: E402
 
 SCENARIO_SEEDS = list(range(1000, 1024))
 MIXED_FORMAT_SEEDS = set(range(1016, 1024))     # FASTQ / gzip inputs
+FULL_MODE_SEEDS = set(range(1000, 1024, 2))     # also run with -f
 
 
 def make_scenarios():
@@ -55,6 +56,15 @@ def make_scenarios():
         shutil.rmtree(os.path.join(d, "expected_log"))
         with open(os.path.join(d, "expected", "log_lines.json"), "w") as fh:
             json.dump(lines, fh, indent=1, sort_keys=True)
+        if seed in FULL_MODE_SEEDS:      # the -f (full comparison) mode of the reference, SURVEY 8f-4
+            p = run_tool(REF_BIN, scn, "expected_full", "expected_full_log", extra_args=["-f"])
+            assert p.returncode == 0, p.stderr
+            lines = {}
+            for f in sorted(os.listdir(os.path.join(d, "expected_full_log"))):
+                lines[f] = open(os.path.join(d, "expected_full_log", f)).read().strip().split("\n")[3:]
+            shutil.rmtree(os.path.join(d, "expected_full_log"))
+            with open(os.path.join(d, "expected_full", "log_lines.json"), "w") as fh:
+                json.dump(lines, fh, indent=1, sort_keys=True)
         meta[f"s{seed}"] = dict(seed=seed, k=scn.k, t=scn.t, index=scn.index_name, search=scn.search_names)
     with open(os.path.join(base, "index.json"), "w") as fh:
         json.dump(meta, fh, indent=1, sort_keys=True)

@@ -75,14 +75,14 @@ class Scenario:
         return bvs, logs
 
 
-def run_tool(tool, scn, out, log, extra_env=None):
+def run_tool(tool, scn, out, log, extra_env=None, extra_args=()):
     """runs an index_and_search-compatible CLI inside the scenario dir"""
     env = dict(os.environ)
     if extra_env:
         env.update(extra_env)
     import subprocess
     return subprocess.run([tool, "-i", scn.index_cfg, "-s", scn.search_cfg, "-o", out, "-l", log,
-                           "-k", str(scn.k), "-t", str(scn.t)], cwd=scn.dir, env=env,
+                           "-k", str(scn.k), "-t", str(scn.t)] + list(extra_args), cwd=scn.dir, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 

@@ -69,6 +69,41 @@ def test_cli_matches_oracle_and_reference(tmp_path, seed):
                 assert oct(os.stat(os.path.join(out_g, f)).st_mode & 0o777) == "0o600"
 
 
+def _full_mode_outputs(out_dir, log_dir):
+    bvs = {f: open(os.path.join(out_dir, f), "rb").read() for f in sorted(os.listdir(out_dir)) if f.endswith(".bv")}
+    logs = {f: open(os.path.join(log_dir, f)).read().strip().split("\n")[3:] for f in sorted(os.listdir(log_dir))
+            if f.endswith(".log")}
+    return bvs, logs
+
+
+@pytest.mark.parametrize("name", [n for n in GoldenScenario.names()
+                                  if os.path.isdir(os.path.join(GOLD, "scenarios", n, "expected_full"))])
+def test_cli_full_mode_reproduces_reference_golden(tmp_path, name):
+    """-f: three-pass symmetric comparison of the index set and the first search set (index_and_search.cpp:304-391)"""
+    scn = GoldenScenario(name)
+    out, log = str(tmp_path / "out"), str(tmp_path / "log")
+    p = run_tool(TOOL, scn, out, log, extra_args=["-f"])
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    exp_dir = os.path.join(scn.dir, "expected_full")
+    bvs, logs = _full_mode_outputs(out, log)
+    exp_bvs = {f: open(os.path.join(exp_dir, f), "rb").read() for f in sorted(os.listdir(exp_dir)) if f.endswith(".bv")}
+    assert bvs == exp_bvs
+    assert logs == json.load(open(os.path.join(exp_dir, "log_lines.json")))
+
+
+@pytest.mark.parametrize("seed", range(2100, 2115))
+def test_cli_full_mode_matches_reference_live(tmp_path, seed):
+    ref = ref_tool("index_and_search")
+    if not ref:
+        pytest.skip("oracle/_ref/index_and_search did not travel with the snapshot")
+    scn = Scenario(str(tmp_path / "scn"), seed)
+    p = run_tool(TOOL, scn, str(tmp_path / "og"), str(tmp_path / "lg"), extra_args=["-f"])
+    q = run_tool(ref, scn, str(tmp_path / "or"), str(tmp_path / "lr"), extra_args=["-f"])
+    assert p.returncode == q.returncode == 0, p.stderr.decode()[-500:]
+    assert _full_mode_outputs(str(tmp_path / "og"), str(tmp_path / "lg")) == _full_mode_outputs(str(tmp_path / "or"), str(tmp_path / "lr"))
+    assert _strip_times(q.stdout.decode()) == _strip_times(p.stdout.decode())
+
+
 def test_cli_flags_and_errors(tmp_path):
     r = subprocess.run([TOOL], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and b"Usage : ./index_and_search" in r.stderr
