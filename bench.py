@@ -122,7 +122,9 @@ def main():
     b0, o0 = synth.synth_set(2 * rank, n, L, base_set=2 * rank)
     b1, o1 = synth.synth_set(2 * rank + 1, n, L, base_set=2 * rank)
 
-    ctx = commet_amd.Context(k=k, t=t, device=local_rank)
+    # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
+    device = int(os.environ.get("COMMET_FORCE_DEVICE", local_rank))
+    ctx = commet_amd.Context(k=k, t=t, device=device)
     t_up = time.perf_counter()
     irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
     qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])

@@ -142,7 +142,7 @@ class Context:
 
     def membench(self, atomic, table_bytes, n_access):
         ms = C.c_double(0)
-        self._check(self._lib.commet_membench(self._h, int(bool(atomic)), int(table_bytes), int(n_access), C.byref(ms)))
+        self._check(self._lib.commet_membench(self._h, int(atomic), int(table_bytes), int(n_access), C.byref(ms)))
         return ms.value
 
 

@@ -955,12 +955,13 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
     HIP_OK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {   // rep 0 warms up
         HIP_OK(hipEventRecord(e0, c->stream));
-        if (atomic)
-            hipLaunchKernelGGL(membench_kernel<true>, dim3((unsigned) (threads / 256)), dim3(256), 0, c->stream, table,
-                               words - 1, iters, sink);
-        else
-            hipLaunchKernelGGL(membench_kernel<false>, dim3((unsigned) (threads / 256)), dim3(256), 0, c->stream, table,
-                               words - 1, iters, sink);
+        const dim3 g((unsigned) (threads / 256)), b(256);
+        switch (atomic) {
+        case 1: hipLaunchKernelGGL(membench_kernel<1>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        case 2: hipLaunchKernelGGL(membench_kernel<2>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        case 3: hipLaunchKernelGGL(membench_kernel<3>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        default: hipLaunchKernelGGL(membench_kernel<0>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        }
         HIP_OK(hipEventRecord(e1, c->stream));
     }
     HIP_OK(hipStreamSynchronize(c->stream));

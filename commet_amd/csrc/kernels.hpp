@@ -291,7 +291,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-template <bool ATOMIC>
+// MODE 0: plain 4-byte gather, 1: atomic OR, 2: non-temporal gather, 3: agent-scope (sc1, L1-bypassing) gather
+template <int MODE>
 __global__ __launch_bounds__(256) void membench_kernel(uint32_t *__restrict__ table, uint64_t word_mask, uint32_t iters,
                                                        uint32_t *__restrict__ sink)
 {
@@ -301,10 +302,12 @@ __global__ __launch_bounds__(256) void membench_kernel(uint32_t *__restrict__ ta
     for (uint32_t i = 0; i < iters; ++i) {
         s = splitmix64(s);
         const uint64_t idx = s & word_mask;
-        if (ATOMIC) (void) __hip_atomic_fetch_or(table + idx, 1u << (s >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 1) (void) __hip_atomic_fetch_or(table + idx, 1u << (s >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (MODE == 2) acc ^= __builtin_nontemporal_load(table + idx);
+        else if (MODE == 3) acc ^= __hip_atomic_load(table + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else acc ^= table[idx];
     }
-    if (!ATOMIC && acc == 0x12345678u) sink[0] = acc;   // keep the loads alive
+    if (MODE != 1 && acc == 0x12345678u) sink[0] = acc;   // keep the loads alive
 }
 
 }  // namespace commet

@@ -172,7 +172,8 @@ int commet_filter_export_reference(commet_ctx *ctx, uint8_t *out, uint64_t out_b
 int commet_last_kernel_ms(commet_ctx *ctx, double *index_ms, double *search_ms);
 /* Random 4-byte-gather / atomic-OR microbenchmarks over a table of
  * table_bytes (practical random-access ceilings): n_access
- * accesses, returns elapsed device ms in *ms. */
+ * accesses, returns elapsed device ms in *ms.  atomic: 0 plain gather, 1 atomic
+ * OR, 2 non-temporal gather, 3 agent-scope (L1-bypassing) gather. */
 int commet_membench(commet_ctx *ctx, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms);
 
 #ifdef __cplusplus
