@@ -908,7 +908,7 @@ int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_byt
     uint8_t *d_out = nullptr;
     HIP_OK(hipMalloc((void **) &d_out, nbytes));
     const uint64_t blocks = std::min<uint64_t>((nbytes + 255) / 256, 1u << 20);   // grid-stride beyond
-    hipLaunchKernelGGL(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), nbytes, d_out);
+    hipLaunchKernelGGL(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), c->k, nbytes, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, ui
         if (!it.window(j, k, mask, wh, wl)) continue;
         const W ka = T::brev(wh) >> sh;
         const W kb = T::brev(wl) >> sh;
-        f(0u, ka);
+        f(0u, psi_a<W>(ka, k));   // plane A is stored strand-paired (kernels.hpp)
         f(1u, kb);
         f(2u, ka ^ kb);
         f(3u, ka | kb);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
                     if (ok) {
                         cvalid[u] |= 1u << jj;
                         const W kc = ka ^ kb, kd = ka | kb;
-                        atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (ka >> TILE_BITS)) >> g.b2], 1u);
+                        atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (psi_a<W>(ka, g.k) >> TILE_BITS)) >> g.b2], 1u);
                         atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
                         atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
                         atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     if (!((cvalid[u] >> jj) & 1u)) continue;
                     const W ka = cka[u][jj], kb = ckb[u][jj];
-                    place(0u, ka);
+                    place(0u, psi_a<W>(ka, g.k));
                     place(1u, kb);
                     place(2u, ka ^ kb);
                     place(3u, ka | kb);

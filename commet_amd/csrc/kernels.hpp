@@ -72,6 +72,61 @@ __device__ __forceinline__ void set_bit(uint32_t *plane, W key)
 }
 
 // ---------------------------------------------------------------------------
+// Strand-paired layout of plane A.
+// The forward key of a window W is kf = bitreverse_k(W) and its reverse-complement
+// key is kr = ~W & mask, so kr = T(kf) with the involution T(x) = ~bitreverse_k(x).
+// A non-shared read probes plane A at BOTH kf and kr for every window (forward
+// pass, then reverse pass): the filter layout is free, so plane A stores
+// bit `key` at address psi(key), a bijection of [0, 2^k) with
+//                     psi(T(key)) = psi(key) ^ 1
+// (same 32-bit word, neighbouring bit).  One 4-byte load of the forward pass then
+// returns the reverse strand's lane-a bit as well, and the reverse pass needs no
+// plane-A traffic: ~half of the L2-missing requests of the search kernel go away.
+//
+// Construction (h = k/2): key = [H | m | L] with h-bit halves (m = middle bit, odd
+// k only).  T maps (H, m, L) to (g(L), ~m, g(H)), g(x) = ~bitreverse_h(x).  With
+// u = H, v = g(L), T is the swap (u, v) -> (v, u) (and m -> ~m).  s = u ^ v is
+// invariant.  For s != 0 let b = lowest set bit of s and pi_s the GF(2)-linear
+// bijection  y = u ^ (u_b ? s & ~(1<<b) : 0), then swap bits 0 and b of y:
+// pi_s(u ^ s) = pi_s(u) ^ 1.  Address = [s | m ^ (pi&1) | pi]  (T flips bit 0 only).
+// For s == 0 (u == v): even k: T(key) = key, address = [0 | u]; odd k: T flips m,
+// address = [0 | u | m].
+// ---------------------------------------------------------------------------
+template <typename W>
+__device__ __forceinline__ W psi_a(W key, int k, bool &self_paired)
+{
+    const int h = k >> 1;
+    const bool odd = k & 1;
+    const uint32_t hmask = (1u << h) - 1u;                     // h <= 19
+    const uint32_t L = (uint32_t) key & hmask;
+    const uint32_t m = odd ? (uint32_t) (key >> h) & 1u : 0u;
+    const uint32_t u = (uint32_t) (key >> (h + (odd ? 1 : 0))) & hmask;
+    const uint32_t v = (~(__brev(L) >> (32 - h))) & hmask;     // g(L); h >= 1 for k >= 2
+    const uint32_t s = u ^ v;
+    if (s == 0) {
+        self_paired = !odd;
+        return odd ? (W) ((u << 1) | m) : (W) u;
+    }
+    self_paired = false;
+    const uint32_t b = (uint32_t) __ffs((int) s) - 1u;
+    uint32_t y = u ^ (((u >> b) & 1u) ? (s & ~(1u << b)) : 0u);
+    const uint32_t d = ((y >> b) ^ y) & 1u;                    // swap bits 0 and b
+    y ^= d | (d << b);
+    if (odd) {
+        const uint32_t m2 = m ^ (y & 1u);
+        return ((W) s << (h + 1)) | ((W) m2 << h) | (W) y;
+    }
+    return ((W) s << h) | (W) y;
+}
+
+template <typename W>
+__device__ __forceinline__ W psi_a(W key, int k)
+{
+    bool sp;
+    return psi_a<W>(key, k, sp);
+}
+
+// ---------------------------------------------------------------------------
 // pack: ASCII -> {hi, lo, valid} planes, per-read complete-k-mer counts.
 // One lane per read.  Replaces the per-char work of Alphabet::is_in
 // (alphabet.h:44-58) and HashKey::add's base classes (hash_key.h:72-88).
@@ -149,7 +204,7 @@ __global__ __launch_bounds__(256) void index_kernel(ReadsView rv, FilterView f, 
                 if (run >= (uint32_t) k) {
                     const W ka = T::brev(wh) >> sh;
                     const W kb = T::brev(wl) >> sh;
-                    set_bit<W>(f.a, ka);
+                    set_bit<W>(f.a, k >= 2 ? psi_a<W>(ka, k) : ka);
                     set_bit<W>(f.b, kb);
                     set_bit<W>(f.c, ka ^ kb);
                     set_bit<W>(f.d, ka | kb);
@@ -172,6 +227,8 @@ __global__ __launch_bounds__(256) void index_kernel(ReadsView rv, FilterView f, 
 // a -> b -> c -> d (bloom_filter.h:124-131).  64 found flags leave the wave as
 // one __ballot word = 8 bytes of the BooleanVector.
 // ---------------------------------------------------------------------------
+constexpr uint32_t SEARCH_MASK_WORDS = 8;   // reverse-strand lane-a bits remembered for the first 256 bases of a read
+
 template <typename W, bool COUNT>
 __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f, int k, int t,
                                                      const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
@@ -180,6 +237,10 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
                                                      unsigned long long *__restrict__ probe_counter)
 {
     using T = KeyTraits<W>;
+    // per lane: lane-a bit of the reverse-complement key of every window probed in the forward pass, and which
+    // windows were probed; [word][thread] so that a wave's accesses are conflict-free
+    __shared__ uint32_t rc_bits[SEARCH_MASK_WORDS][256];
+    __shared__ uint32_t rc_known[SEARCH_MASK_WORDS][256];
     const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
@@ -190,8 +251,9 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
         if (tags) tagw = tags[word];
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    const bool paired = k >= 2;                 // plane A is stored strand-paired (psi_a)
     bool found = false;
-    uint32_t probes = 0;   // filter words loaded (COUNT builds only)
+    uint32_t probes = 0;   // filter words the REFERENCE control flow loads (COUNT builds only)
     if (active) {
         uint64_t t0;
         uint32_t len;
@@ -206,20 +268,40 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
             for (uint32_t w = 0; w * 32u < len && !found; ++w) {
                 const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
                 const uint32_t nb = min(32u, len - w * 32u);
+                uint32_t rcw = 0, knw = 0;
+                if (strand == 1 && w < SEARCH_MASK_WORDS) {
+                    rcw = rc_bits[w][threadIdx.x];
+                    knw = rc_known[w][threadIdx.x];
+                }
                 for (uint32_t j = 0; j < nb && !found; ++j) {
                     wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
                     wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
                     run = ((va >> j) & 1u) ? run + 1 : 0;
                     if (run >= (uint32_t) k) {
                         W ka, kb;
+                        bool hit;
                         if (strand == 0) {
                             ka = T::brev(wh) >> sh;
                             kb = T::brev(wl) >> sh;
+                            if (paired) {
+                                // one load: lane-a bit of this key and of its reverse-complement partner
+                                bool selfp;
+                                const W addr = psi_a<W>(ka, k, selfp);
+                                const uint32_t fw = f.a[addr >> 5];
+                                const uint32_t bit = (uint32_t) addr & 31u;
+                                hit = (fw >> bit) & 1u;
+                                const uint32_t rcb = selfp ? (uint32_t) hit : ((fw >> (bit ^ 1u)) & 1u);
+                                rcw |= rcb << j;
+                                knw |= 1u << j;
+                            } else {
+                                hit = test_bit<W>(f.a, ka);
+                            }
                         } else {
                             ka = ~wh & mask;
                             kb = ~wl & mask;
+                            if (paired && ((knw >> j) & 1u)) hit = (rcw >> j) & 1u;       // remembered from the forward pass
+                            else hit = test_bit<W>(f.a, paired ? psi_a<W>(ka, k) : ka);   // window skipped by the forward pass
                         }
-                        bool hit = test_bit<W>(f.a, ka);
                         if (COUNT) ++probes;
                         if (hit) {
                             hit = test_bit<W>(f.b, kb);
@@ -239,6 +321,10 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
                             if (seen >= t) found = true;
                         }
                     }
+                }
+                if (strand == 0 && w < SEARCH_MASK_WORDS) {
+                    rc_bits[w][threadIdx.x] = rcw;
+                    rc_known[w][threadIdx.x] = knw;
                 }
             }
         }
@@ -262,17 +348,17 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 // ---------------------------------------------------------------------------
 // filter -> reference byte layout (bloom_filter.h:63-70,114-117); tests only.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void export_reference_kernel(FilterView f, uint64_t nbytes, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void export_reference_kernel(FilterView f, int k, uint64_t nbytes, uint8_t *__restrict__ out)
 {
     const uint64_t stride = (uint64_t) gridDim.x * 256ull;
     for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < nbytes; i += stride) {
         const uint64_t k0 = 2 * i, k1 = 2 * i + 1;
         uint32_t b = 0;
-        b |= test_bit<uint64_t>(f.a, k0) << 7;
+        b |= test_bit<uint64_t>(f.a, k >= 2 ? psi_a<uint64_t>(k0, k) : k0) << 7;
         b |= test_bit<uint64_t>(f.b, k0) << 6;
         b |= test_bit<uint64_t>(f.c, k0) << 5;
         b |= test_bit<uint64_t>(f.d, k0) << 4;
-        b |= test_bit<uint64_t>(f.a, k1) << 3;
+        b |= test_bit<uint64_t>(f.a, k >= 2 ? psi_a<uint64_t>(k1, k) : k1) << 3;
         b |= test_bit<uint64_t>(f.b, k1) << 2;
         b |= test_bit<uint64_t>(f.c, k1) << 1;
         b |= test_bit<uint64_t>(f.d, k1);
