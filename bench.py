@@ -164,10 +164,15 @@ def main():
             srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR
         idx_ms = acc["index_kernel_ms"] / steps
         srch_ms = acc["search_ms"] / steps
-        if idx_ms >= srch_ms or srch_bytes_step is None:
+        # dominant KERNEL: the index phase of one chunk is a chain of >= 3 comparable streaming kernels (scatter1,
+        # scatter2, build; see profiles/), the search phase is one kernel per launch
+        idx_per_kernel = idx_ms / max(acc["index_launches"] / steps, 1) / 3.0
+        srch_per_kernel = srch_ms / max(acc["search_launches"] / steps, 1)
+        if srch_bytes_step is None or idx_per_kernel > srch_per_kernel:
             name, kms, kbytes, launches = "index_kernel", idx_ms, idx_bytes_step, acc["index_launches"] / steps
         else:
-            name, kms, kbytes, launches = "search_kernel", srch_ms, srch_bytes_step, acc["search_launches"] / steps
+            name = "search_group_kernel" if acc["search_launches"] / steps < info["n_chunks"] else "search_kernel"
+            kms, kbytes, launches = srch_ms, srch_bytes_step, acc["search_launches"] / steps
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
                     f"per GPU (BASELINE configs[1]), inputs resident in HBM")

@@ -83,13 +83,21 @@ struct commet_ctx {
     unsigned long long *part_cur1 = nullptr, *part_cur2 = nullptr;
     uint32_t part_nb = 0;
 
+    int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)
+    int cur_slot = 0;                 // slot the index / search launch helpers work on
+    uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
+    int il_stride = 0;
+    int chunk_group = 4;              // option: chunks searched per pass (1 = one pass per chunk)
+
+    uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
     FilterView view() const
     {
+        uint32_t *base = slot_ptr(cur_slot);
         FilterView f;
-        f.a = filter;
-        f.b = filter + plane_words;
-        f.c = filter + 2 * plane_words;
-        f.d = filter + 3 * plane_words;
+        f.a = base;
+        f.b = base + plane_words;
+        f.c = base + 2 * plane_words;
+        f.d = base + 3 * plane_words;
         return f;
     }
 };
@@ -200,6 +208,7 @@ void commet_destroy(commet_ctx *c)
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->filter) (void) hipFree(c->filter);
+    (void) hipFree(c->il_a);
     (void) hipFree(c->part_bufA);
     (void) hipFree(c->part_bufB);
     (void) hipFree(c->part_hist);
@@ -479,7 +488,7 @@ int commet_readset_kmer_counts(const commet_readset *rs, uint32_t *out)
 int commet_filter_reset(commet_ctx *c)
 {
     HIP_OK(hipSetDevice(c->device));
-    HIP_OK(hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream));
+    HIP_OK(hipMemsetAsync(c->slot_ptr(c->cur_slot), 0, c->filter_bytes, c->stream));
     return 0;
 }
 
@@ -594,7 +603,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
         hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), c->stream,
-                           c->part_bufB, c->part_off, c->part_wl, g, c->filter, additive ? 1 : 0);
+                           c->part_bufB, c->part_off, c->part_wl, g, c->slot_ptr(c->cur_slot), additive ? 1 : 0);
         HIP_OK(hipGetLastError());
     }
     return 0;
@@ -647,6 +656,89 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
     }
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+// makes `g` filter slots (+ the interleaved A planes with stride gs) available; slot contents are undefined after a grow
+int ensure_slots(commet_ctx *c, int g, int gs)
+{
+    if (c->n_slots < g) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        uint32_t *nf = nullptr;
+        hipError_t e = hipMalloc((void **) &nf, (size_t) g * c->filter_bytes);
+        if (e != hipSuccess) return fail("cannot allocate %d filter slots: %s", g, hipGetErrorString(e));
+        (void) hipFree(c->filter);
+        c->filter = nf;
+        c->n_slots = g;
+    }
+    if (c->il_stride < gs) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) hipFree(c->il_a);
+        c->il_a = nullptr;
+        c->il_stride = 0;
+        HIP_OK(hipMalloc((void **) &c->il_a, (size_t) gs * c->plane_words * sizeof(uint32_t)));
+        c->il_stride = gs;
+    }
+    return 0;
+}
+
+int launch_interleave(commet_ctx *c, int g, int gs)
+{
+    const uint64_t blocks = std::min<uint64_t>((c->plane_words + 255) / 256, 1u << 16);
+    if (gs == 2)
+        hipLaunchKernelGGL(interleave_a_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+                           c->plane_words, g, c->il_a);
+    else
+        hipLaunchKernelGGL(interleave_a_kernel<4>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+                           c->plane_words, g, c->il_a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename W, int GS>
+int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterGroupView &fg, uint32_t nw_max, const uint64_t *d_sel,
+                          uint64_t *d_tags, unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes)
+{
+    const dim3 g((unsigned) ((rs->n_reads + 255) / 256)), b(256);
+    const size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
+    if (d_probes) {
+        HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, c->t, nw_max, d_sel, d_tags,
+                           d_counters, cstride, d_probes);
+    } else {
+        HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, c->t, nw_max, d_sel, d_tags,
+                           d_counters, cstride, d_probes);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// one pass of rs over the `g` chunk filters in slots 0..g-1 (A planes already interleaved with stride gs)
+int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, const uint64_t *d_sel, uint64_t *d_tags,
+                        unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes)
+{
+    if (rs->n_reads == 0) return 0;
+    if ((rs->n_reads + 255) / 256 >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
+    FilterGroupView fg;
+    fg.il_a = c->il_a;
+    fg.slot0 = c->filter;
+    fg.slot_words = 4 * c->plane_words;
+    fg.plane_words = c->plane_words;
+    fg.g = g;
+    const uint32_t nw_max = (rs->max_len + 31) / 32;
+    if (c->k <= 32) {
+        if (gs == 2) return launch_search_group_t<uint32_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+        return launch_search_group_t<uint32_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+    }
+    if (gs == 2) return launch_search_group_t<uint64_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+    return launch_search_group_t<uint64_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+}
+
+bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
+{
+    // LDS masks: g chunks x 2 strands x ceil(max_len/32) words per lane, at most 64 KiB per workgroup
+    const uint64_t nw = ((uint64_t) rs->max_len + 31) / 32;
+    return c->k >= 2 && nw >= 1 && (uint64_t) g * 2 * nw * 256 * 4 <= (64u << 10);
 }
 
 }  // namespace
@@ -772,44 +864,81 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         evs.push_back(*e);
         return 0;
     };
-    const bool timed = (info != nullptr || stats != nullptr) && n_chunks * (uint64_t) (n_search + 2) <= 16384;
-    std::vector<hipEvent_t> e_idx0, e_zero, e_idx1;
+    const bool timed = (info != nullptr || stats != nullptr) && n_chunks * (uint64_t) (n_search + 4) <= 16384;
+    std::vector<hipEvent_t> e_idx0, e_idx1, e_zero0, e_zero1;
     std::vector<std::vector<hipEvent_t>> e_set(n_search);   // end of set s's search, per chunk
     uint64_t n_index_launches = 0, n_search_launches = 0;
     unsigned long long *d_probes = c->count_probes ? d_cnt + (n_cnt - 1) : nullptr;
 
     int rc = 0;
-    for (uint64_t ci = 0; ci < n_chunks && !rc; ++ci) {
-        const Chunk &ch = plan.chunks[ci];
-        hipEvent_t a = nullptr, z = nullptr, b = nullptr;
+    // chunks are taken in groups of up to `chunk_group`: their filters are built into separate slots and every
+    // search set is scanned ONCE per group (search_group_kernel) instead of once per chunk
+    int group_cap = (c->k >= 2) ? std::max(1, std::min(4, c->chunk_group)) : 1;
+    if (n_chunks < 2) group_cap = 1;
+    for (uint64_t ci = 0; ci < n_chunks && !rc;) {
+        int g = (int) std::min<uint64_t>((uint64_t) group_cap, n_chunks - ci);
+        const int gs = g <= 2 ? 2 : 4;
+        if (g > 1 && ensure_slots(c, g, gs)) {   // not enough memory for a group: one chunk at a time
+            g = 1;
+            group_cap = 1;
+        }
+        hipEvent_t a = nullptr, b = nullptr;
         if (timed) {
-            if (new_event(&a) || new_event(&z) || new_event(&b)) { rc = 1; break; }
+            if (new_event(&a) || new_event(&b)) { rc = 1; break; }
             (void) hipEventRecord(a, c->stream);
         }
-        if (commet_filter_reset(c)) { rc = 1; break; }                       // new BloomFilter per chunk
-        if (timed) (void) hipEventRecord(z, c->stream);
-        if (ch.n_reads) {
-            if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true)) { rc = 1; break; }
-            ++n_index_launches;
+        double zero_before = 0;
+        (void) zero_before;
+        for (int i = 0; i < g && !rc; ++i) {
+            const Chunk &ch = plan.chunks[ci + i];
+            c->cur_slot = i;
+            hipEvent_t z0 = nullptr, z1 = nullptr;
+            if (timed) {
+                if (new_event(&z0) || new_event(&z1)) { rc = 1; break; }
+                (void) hipEventRecord(z0, c->stream);
+            }
+            if (commet_filter_reset(c)) { rc = 1; break; }                   // new BloomFilter per chunk
+            if (timed) {
+                (void) hipEventRecord(z1, c->stream);
+                e_zero0.push_back(z0);
+                e_zero1.push_back(z1);
+            }
+            if (ch.n_reads) {
+                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true)) { rc = 1; break; }
+                ++n_index_launches;
+            }
         }
+        if (rc) break;
+        if (g > 1 && launch_interleave(c, g, gs)) { rc = 1; break; }
         if (timed) {
             (void) hipEventRecord(b, c->stream);
             e_idx0.push_back(a);
-            e_zero.push_back(z);
             e_idx1.push_back(b);
         }
-        for (int s = 0; s < n_search; ++s) {
+        for (int s = 0; s < n_search && !rc; ++s) {
             const commet_readset *rs = search_rs[s];
-            if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, d_cnt + 2 * (ci * n_search + s), d_probes)) { rc = 1; break; }
-            if (rs->n_reads) ++n_search_launches;
-            if (timed) {
+            unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
+            if (g > 1 && group_searchable(c, rs, g)) {
+                if (launch_search_group(c, rs, g, gs, rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
+                if (rs->n_reads) ++n_search_launches;
+            } else {
+                for (int i = 0; i < g && !rc; ++i) {
+                    c->cur_slot = i;
+                    if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
+                    if (rs->n_reads) ++n_search_launches;
+                }
+            }
+            if (timed && !rc) {
                 hipEvent_t d = nullptr;
                 if (new_event(&d)) { rc = 1; break; }
                 (void) hipEventRecord(d, c->stream);
                 e_set[s].push_back(d);
             }
         }
+        c->cur_slot = 0;
+        ci += (uint64_t) g;
     }
+    c->cur_slot = 0;
     if (!rc)
         if (hipMemcpyAsync(h_cnt.data(), d_cnt, n_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail("counter copy failed");
@@ -844,10 +973,13 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         }
         double idx_ms = 0, srch_ms = 0, zero_ms = 0;
         if (timed && !rc) {
+            for (size_t i = 0; i < e_zero0.size(); ++i) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e_zero0[i], e_zero1[i]) == hipSuccess) zero_ms += ms;
+            }
             for (size_t i = 0; i < e_idx0.size(); ++i) {
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, e_idx0[i], e_idx1[i]) == hipSuccess) idx_ms += ms;
-                if (hipEventElapsedTime(&ms, e_idx0[i], e_zero[i]) == hipSuccess) zero_ms += ms;
                 for (int s = 0; s < n_search; ++s) {
                     if (i >= e_set[s].size()) continue;
                     hipEvent_t prev = s == 0 ? e_idx1[i] : e_set[s - 1][i];
@@ -890,6 +1022,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "index_mode")) {        // 0 auto, 1 atomic kernel, 2 bucketed construction
         if (value < 0 || value > 2) return fail("index_mode must be 0, 1 or 2");
         c->index_mode = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "chunk_group")) {       // chunk filters searched per pass over a set (1 = reference order)
+        if (value < 1 || value > 4) return fail("chunk_group must be 1..4");
+        c->chunk_group = (int) value;
         return 0;
     }
     if (!strcmp(name, "part_min_kmers")) {    // auto mode: chunks with fewer k-mers use the atomic kernel

@@ -346,6 +346,196 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 }
 
 // ---------------------------------------------------------------------------
+// search against a GROUP of chunk filters in one pass over the reads.
+// The reference re-scans the search set once per index chunk (index_and_search.cpp:
+// 255-277); a read's result is found_1 | found_2 | ... with found_c depending on
+// chunk c's filter only.  With g <= GS chunk filters resident, their A planes are
+// word-interleaved (il_a[w * GS + i] = plane A word w of chunk i), so ONE vector
+// load yields the lane-a bits of a window for every chunk of the group and both
+// strands (psi_a).  Per lane: (1) gather the lane-a bits of all complete windows
+// into LDS masks, (2) replay the reference control flow chunk by chunk, strand by
+// strand, on the masks, probing planes B, C, D of that chunk only on lane-a hits.
+// counters: per chunk i of the group {scanned_i, found_i} at counters[i * cstride].
+// ---------------------------------------------------------------------------
+struct FilterGroupView {
+    const uint32_t *il_a;        // interleaved A planes, stride GS words
+    const uint32_t *slot0;       // first filter slot (4 planes); slot i at slot0 + i * slot_words
+    uint64_t        slot_words;  // words per slot (4 * plane_words)
+    uint64_t        plane_words;
+    int             g;           // chunks in the group (<= GS)
+};
+
+template <int GS> struct GroupWords;
+template <> struct GroupWords<2> {
+    uint32_t x[2];
+    __device__ __forceinline__ void load(const uint32_t *q)
+    {
+        const uint2 v = *(const uint2 *) q;
+        x[0] = v.x, x[1] = v.y;
+    }
+};
+template <> struct GroupWords<4> {
+    uint32_t x[4];
+    __device__ __forceinline__ void load(const uint32_t *q)
+    {
+        const uint4 v = *(const uint4 *) q;
+        x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+    }
+};
+
+template <typename W, int GS, bool COUNT>
+__global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterGroupView fg, int k, int t, uint32_t nw_max,
+                                                           const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
+                                                           unsigned long long *__restrict__ counters, uint32_t cstride,
+                                                           unsigned long long *__restrict__ probe_counter)
+{
+    using T = KeyTraits<W>;
+    extern __shared__ uint32_t gmask[];   // [chunk][strand][word][thread]
+    auto mask_at = [&](int i, int strand, uint32_t w) -> uint32_t & {
+        return gmask[(((uint32_t) i * 2u + (uint32_t) strand) * nw_max + w) * 256u + threadIdx.x];
+    };
+    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t word = r >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = (word << 6) < rv.n;
+    uint64_t selw = ~0ull, tagw = 0;
+    if (in_range) {
+        if (sel) selw = sel[word];
+        if (tags) tagw = tags[word];
+    }
+    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    bool found = false;
+    int found_chunk = -1;
+    uint32_t probes = 0;
+    if (active) {
+        uint64_t t0;
+        uint32_t len;
+        read_extent(rv, r, t0, len);
+        const uint32_t *p = rv.planes + 3 * t0;
+        const int sh = T::BITS - k;
+        const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+        // (1) gather: lane-a bits of every complete window, all chunks, both strands
+        {
+            W wh = 0;
+            uint32_t run = 0;
+            for (uint32_t w = 0; w * 32u < len; ++w) {
+                const uint32_t hi = p[3 * w], va = p[3 * w + 2];
+                const uint32_t nb = min(32u, len - w * 32u);
+                uint32_t fm[GS], rm[GS];
+#pragma unroll
+                for (int i = 0; i < GS; ++i) fm[i] = 0, rm[i] = 0;
+                for (uint32_t j = 0; j < nb; ++j) {
+                    wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                    run = ((va >> j) & 1u) ? run + 1 : 0;
+                    if (run >= (uint32_t) k) {
+                        bool selfp;
+                        const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
+                        GroupWords<GS> gw;
+                        gw.load(fg.il_a + (uint64_t) (addr >> 5) * GS);
+                        const uint32_t bit = (uint32_t) addr & 31u;
+#pragma unroll
+                        for (int i = 0; i < GS; ++i) {
+                            const uint32_t fb = (gw.x[i] >> bit) & 1u;
+                            const uint32_t rb = selfp ? fb : ((gw.x[i] >> (bit ^ 1u)) & 1u);
+                            fm[i] |= fb << j;
+                            rm[i] |= rb << j;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    mask_at(i, 0, w) = fm[i];
+                    mask_at(i, 1, w) = rm[i];
+                }
+            }
+        }
+        // (2) replay the reference control flow per chunk (search_reads.h:45-83)
+        for (int i = 0; i < fg.g && !found; ++i) {
+            const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
+            const uint32_t *pc = pb + fg.plane_words;
+            const uint32_t *pd = pc + fg.plane_words;
+            for (int strand = 0; strand < 2 && !found; ++strand) {
+                W wh = 0, wl = 0;
+                uint32_t run = 0;
+                int seen = 0;
+                for (uint32_t w = 0; w * 32u < len && !found; ++w) {
+                    const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
+                    const uint32_t nb = min(32u, len - w * 32u);
+                    const uint32_t am = mask_at(i, strand, w);
+                    for (uint32_t j = 0; j < nb && !found; ++j) {
+                        wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                        wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
+                        run = ((va >> j) & 1u) ? run + 1 : 0;
+                        if (run >= (uint32_t) k) {
+                            bool hit = (am >> j) & 1u;
+                            if (COUNT) ++probes;
+                            if (hit) {
+                                W ka, kb;
+                                if (strand == 0) {
+                                    ka = T::brev(wh) >> sh;
+                                    kb = T::brev(wl) >> sh;
+                                } else {
+                                    ka = ~wh & mask;
+                                    kb = ~wl & mask;
+                                }
+                                hit = test_bit<W>(pb, kb);
+                                if (COUNT) ++probes;
+                                if (hit) {
+                                    hit = test_bit<W>(pc, ka ^ kb);
+                                    if (COUNT) ++probes;
+                                    if (hit) {
+                                        hit = test_bit<W>(pd, ka | kb);
+                                        if (COUNT) ++probes;
+                                    }
+                                }
+                            }
+                            if (hit) {
+                                ++seen;
+                                run = 0;
+                                if (seen >= t) found = true;
+                            }
+                        }
+                    }
+                }
+            }
+            if (found) found_chunk = i;
+        }
+    }
+    const uint64_t fb = __ballot(found);
+    if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
+    if (counters) {
+        // chunk i: scanned = active reads not found in an earlier chunk of the group, found = found in chunk i
+        for (int i = 0; i < fg.g; ++i) {
+            const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
+            const uint64_t fd = __ballot(found_chunk == i);
+            if (lane == 0) {
+                if (sc) atomicAdd(&counters[(uint64_t) i * cstride + 0], (unsigned long long) __popcll(sc));
+                if (fd) atomicAdd(&counters[(uint64_t) i * cstride + 1], (unsigned long long) __popcll(fd));
+            }
+        }
+    }
+    if (COUNT && probe_counter) {
+        for (int o = 32; o > 0; o >>= 1) probes += __shfl_down(probes, o, 64);
+        if (lane == 0 && probes) atomicAdd(probe_counter, (unsigned long long) probes);
+    }
+}
+
+// il_a[w * GS + i] = plane A word w of filter slot i (0 for i >= g)
+template <int GS>
+__global__ __launch_bounds__(256) void interleave_a_kernel(const uint32_t *__restrict__ slot0, uint64_t slot_words,
+                                                           uint64_t plane_words, int g, uint32_t *__restrict__ il_a)
+{
+    const uint64_t stride = (uint64_t) gridDim.x * 256ull;
+    for (uint64_t w = blockIdx.x * 256ull + threadIdx.x; w < plane_words; w += stride) {
+        uint32_t x[GS];
+#pragma unroll
+        for (int i = 0; i < GS; ++i) x[i] = i < g ? slot0[(uint64_t) i * slot_words + w] : 0u;
+        if (GS == 2) *(uint2 *) (il_a + w * 2) = make_uint2(x[0], x[1]);
+        else *(uint4 *) (il_a + w * 4) = make_uint4(x[0], x[1 % GS], x[2 % GS], x[3 % GS]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // filter -> reference byte layout (bloom_filter.h:63-70,114-117); tests only.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void export_reference_kernel(FilterView f, int k, uint64_t nbytes, uint8_t *__restrict__ out)

@@ -37,6 +37,7 @@ def test_job_matches_oracle(tmp_path, seed, index_mode):
             ssel.append(s)
         ctx.set_option("count_probes", 1)
         ctx.set_option("index_mode", index_mode)
+        ctx.set_option("chunk_group", [4, 1, 2, 3][seed % 4])     # chunk filters searched per pass (1 = reference order)
         tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
         assert info["probes"] == sum(r["probes"] for r in res)        # P_ref: the reference's own probe count
         assert info["n_chunks"] == chunks
