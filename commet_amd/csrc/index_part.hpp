@@ -35,7 +35,7 @@ constexpr uint32_t TILE_MASK = (1u << TILE_BITS) - 1;
 constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 KiB
 constexpr int      S1_NT = 512;                             // scatter-1 workgroup size
 constexpr uint32_t S1_KEYS = 16384;                         // keys staged per scatter-1 round (64 KiB)
-constexpr uint32_t S1_ITEMS = 2 * S1_NT;                    // octet items per round (2 per thread, keys cached)
+constexpr uint32_t S1_ITEMS = S1_NT;                        // octet items per round: one per thread, keys cached
 constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
 constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
 constexpr uint32_t S2_PER_THREAD = S2_KEYS / S2_NT;
@@ -362,8 +362,9 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
 // ---------------------------------------------------------------------------
 // scatter1: reads -> keys -> 2^b1 coarse buckets (LDS counting sort per round)
 // payload = ((bucket & (2^b2 - 1)) << 19) | (key & TILE_MASK)
-// Every thread owns up to two octet items per round; for 32-bit keys the
-// (keya, keyb) pairs are computed once and kept in registers for both passes.
+// Every thread owns one octet item per round (rounds are cut at S1_NT items or S1_KEYS keys,
+// whichever comes first); for 32-bit keys the (keya, keyb) pairs are computed once and kept
+// in registers for both passes.
 // ---------------------------------------------------------------------------
 template <typename W>
 __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
@@ -392,12 +393,12 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
                                             wsum, sh_n);
         if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
         __syncthreads();
-        // my items: id = tid and tid + NT
-        uint32_t cka[2][8], ckb[2][8], cvalid[2] = {0, 0};   // used when CACHE
-        uint32_t islot[2], iq[2];
-        bool ion[2];
+        // my item: id = tid
+        uint32_t cka[1][8], ckb[1][8], cvalid[1] = {0};   // used when CACHE
+        uint32_t islot[1], iq[1];
+        bool ion[1];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 1; ++u) {
             const uint32_t id = threadIdx.x + u * NT;
             ion[u] = id < rp.n_items;
             islot[u] = 0, iq[u] = 0;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         }
         // pass A: keys, count per coarse bucket
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 1; ++u) {
             if (!ion[u]) continue;
             const uint32_t *p = rv.planes + 3 * rd_t0[islot[u]];
             const uint32_t len = rd_len[islot[u]];
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
             if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
         };
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 1; ++u) {
             if (!ion[u]) continue;
             if (CACHE) {
 #pragma unroll
