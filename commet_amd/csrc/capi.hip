@@ -16,7 +16,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <atomic>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -265,13 +269,6 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_sel, bw * 8);
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_tags, bw * 8);
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_found, bw * 8);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipHostMalloc((void **) &rs->st[i].h_bases, rs->stage_bases);
-        if (e == hipSuccess) e = hipHostMalloc((void **) &rs->st[i].h_offs, (rs->stage_reads + 1) * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc((void **) &rs->st[i].d_bases, rs->stage_bases);
-        if (e == hipSuccess) e = hipMalloc((void **) &rs->st[i].d_offs, (rs->stage_reads + 1) * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&rs->st[i].done, hipEventDisableTiming);
-    }
     if (e == hipSuccess) {
         const uint32_t mm[2] = {0xFFFFFFFFu, 0u};
         e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
@@ -324,6 +321,13 @@ int commet_readset_stage_acquire(commet_readset *rs, uint8_t **bases, uint64_t *
     if (rs->acquired) return fail("staging buffer already acquired");
     HIP_OK(hipSetDevice(rs->ctx->device));
     commet_readset::Stage &s = rs->st[rs->cur];
+    if (!s.h_bases) {   // staging buffers are created on first use (commet_readset_from_fasta has its own)
+        HIP_OK(hipHostMalloc((void **) &s.h_bases, rs->stage_bases));
+        HIP_OK(hipHostMalloc((void **) &s.h_offs, (rs->stage_reads + 1) * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void **) &s.d_bases, rs->stage_bases));
+        HIP_OK(hipMalloc((void **) &s.d_offs, (rs->stage_reads + 1) * sizeof(uint64_t)));
+        HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
     if (s.inflight) {
         HIP_OK(hipEventSynchronize(s.done));
         s.inflight = false;
@@ -395,11 +399,191 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- parallel host ingest (commet_readset_from_fasta) -------------------------------------------------------
+// A piece = a run of whole records of one file.  FASTA files are cut into pieces at lines starting with '>'
+// (a record boundary by the reference's own rule, fasta_file.h:61-68); FASTQ files stay one piece ('@' may also
+// start a quality line).  Pass A counts records and sequence bytes per piece (so that every piece knows its
+// set-wide read number and base offset), pass B parses the pieces into per-thread pinned staging buffers and
+// queues hipMemcpyAsync + the packing kernel at those explicit positions, in any order.
+struct Piece {
+    int file = 0;
+    commet_host::ReadFormat fmt = commet_host::ReadFormat::Fasta;
+    const char *d = nullptr;
+    size_t n = 0;
+    uint64_t n_reads = 0, n_bases = 0;     // pass A
+    uint64_t read0 = 0, base0 = 0;         // prefix
+};
+
+struct IngestStage {
+    uint8_t *h_bases = nullptr;
+    uint64_t *h_offs = nullptr;
+    uint8_t *d_bases = nullptr;
+    uint64_t *d_offs = nullptr;
+    hipEvent_t done = nullptr;
+    bool inflight = false;
+};
+
+constexpr uint64_t INGEST_STAGE_BASES = 16ull << 20;
+constexpr uint64_t INGEST_STAGE_READS = 1ull << 18;
+
+void count_piece(Piece &p)
+{
+    if (p.fmt == commet_host::ReadFormat::Fastq) {
+        p.n_reads = commet_host::count_fastq_records(p.d, p.n);
+        commet_host::for_each_fastq_record(p.d, p.n, p.n_reads, [&](const char *, size_t len) { p.n_bases += len; });
+        return;
+    }
+    const char *d = p.d;
+    const size_t n = p.n;
+    size_t i = 0;
+    while (i < n && d[i] != '>') {   // bytes before the first header line belong to no record
+        const char *nl = (const char *) memchr(d + i, '\n', n - i);
+        i = nl ? (size_t) (nl - d) + 1 : n;
+    }
+    while (i < n) {
+        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
+        size_t j = nl ? (size_t) (nl - d) + 1 : n;
+        ++p.n_reads;
+        while (j < n && d[j] != '>') {
+            nl = (const char *) memchr(d + j, '\n', n - j);
+            const size_t e = nl ? (size_t) (nl - d) : n;
+            p.n_bases += e - j;
+            j = nl ? e + 1 : n;
+        }
+        i = j;
+    }
+}
+
+struct IngestShared {
+    commet_readset *rs;
+    std::mutex mu;
+    std::string err;
+    std::atomic<bool> failed{false};
+};
+
+int commit_at(IngestShared &sh, IngestStage &st, uint64_t n, uint64_t read0, uint64_t base0)
+{
+    commet_readset *rs = sh.rs;
+    commet_ctx *c = rs->ctx;
+    const uint64_t nbases = st.h_offs[n];
+    for (uint64_t i = 0; i < n; ++i) {
+        if (st.h_offs[i + 1] - st.h_offs[i] > 0x7FFFFFFFull) return 1;
+        if (st.h_offs[i + 1] == st.h_offs[i]) {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            rs->empty_reads.push_back(read0 + i);
+        }
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return 1;
+    if (nbases && hipMemcpyAsync(st.d_bases, st.h_bases, nbases, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
+    if (hipMemcpyAsync(st.d_offs, st.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
+    const unsigned grid = (unsigned) ((n + 1 + 255) / 256);
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->stream, st.d_bases, st.d_offs, n, read0, base0, rs->d_planes,
+                       rs->d_goff, rs->d_kcnt, rs->d_lenmm, c->k);
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (hipEventRecord(st.done, c->stream) != hipSuccess) return 1;
+    st.inflight = true;
+    return 0;
+}
+
+// parses one piece into the worker's two staging buffers
+int ingest_piece(IngestShared &sh, const Piece &p, IngestStage st[2])
+{
+    int cur = 0;
+    uint64_t used = 0, nreads = 0, read_pos = p.read0, base_pos = p.base0;
+    bool have = false;
+    auto flush = [&]() -> int {
+        if (!have || nreads == 0) return 0;
+        if (commit_at(sh, st[cur], nreads, read_pos, base_pos)) return 1;
+        read_pos += nreads;
+        base_pos += used;
+        cur ^= 1;
+        have = false;
+        return 0;
+    };
+    auto begin = [&]() -> int {
+        if (st[cur].inflight) {
+            if (hipEventSynchronize(st[cur].done) != hipSuccess) return 1;
+            st[cur].inflight = false;
+        }
+        st[cur].h_offs[0] = 0;
+        used = 0;
+        nreads = 0;
+        have = true;
+        return 0;
+    };
+    auto add_read = [&](const char *const *segs, const size_t *lens, int nseg, size_t total) -> int {
+        if (total > INGEST_STAGE_BASES) return 2;
+        if (have && (nreads >= INGEST_STAGE_READS || used + total > INGEST_STAGE_BASES))
+            if (flush()) return 1;
+        if (!have && begin()) return 1;
+        for (int q = 0; q < nseg; ++q) {
+            memcpy(st[cur].h_bases + used, segs[q], lens[q]);
+            used += lens[q];
+        }
+        st[cur].h_offs[++nreads] = used;
+        return 0;
+    };
+    if (p.fmt == commet_host::ReadFormat::Fastq) {
+        int rc = 0;
+        commet_host::for_each_fastq_record(p.d, p.n, p.n_reads, [&](const char *s, size_t len) {
+            if (rc) return;
+            rc = add_read(&s, &len, 1, len);
+        });
+        if (rc) return rc;
+        return flush();
+    }
+    const char *d = p.d;
+    const size_t n = p.n;
+    size_t i = 0;
+    while (i < n && d[i] != '>') {
+        const char *nl = (const char *) memchr(d + i, '\n', n - i);
+        i = nl ? (size_t) (nl - d) + 1 : n;
+    }
+    std::vector<const char *> segs;
+    std::vector<size_t> lens;
+    while (i < n) {
+        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header line
+        size_t j = nl ? (size_t) (nl - d) + 1 : n;
+        segs.clear();
+        lens.clear();
+        size_t total = 0;
+        while (j < n && d[j] != '>') {
+            nl = (const char *) memchr(d + j, '\n', n - j);
+            const size_t e = nl ? (size_t) (nl - d) : n;
+            if (e > j) {
+                segs.push_back(d + j);
+                lens.push_back(e - j);
+                total += e - j;
+            }
+            j = nl ? e + 1 : n;
+        }
+        const int rc = add_read(segs.data(), lens.data(), (int) segs.size(), total);
+        if (rc) return rc;
+        i = j;
+    }
+    return flush();
+}
+
+int ingest_threads()
+{
+    const char *e = getenv("COMMET_INGEST_THREADS");
+    int t = e ? atoi(e) : 8;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && t > (int) hw) t = (int) hw;
+    return t < 1 ? 1 : t;
+}
+
+}  // namespace
+
+extern "C" {
+
 commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *paths, int n_paths)
 {
     std::vector<std::unique_ptr<commet_host::ReadFileData>> maps;
-    std::vector<uint64_t> nrec;
-    uint64_t max_reads = 0, max_bases = 0;
     for (int i = 0; i < n_paths; ++i) {
         std::unique_ptr<commet_host::ReadFileData> mf(new commet_host::ReadFileData);
         if (!mf->open_file(paths[i])) {
@@ -410,27 +594,117 @@ commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *path
             fail("Unknown format: %s", paths[i]);
             return nullptr;
         }
-        nrec.push_back(commet_host::count_records(mf->format(), mf->data(), mf->size()));
-        max_reads += nrec.back();
-        max_bases += mf->size();
         maps.push_back(std::move(mf));
     }
-    commet_readset *rs = commet_readset_create(c, max_reads, max_bases);
-    if (!rs) return nullptr;
-    for (int i = 0; i < n_paths; ++i) {
-        std::string err;
-        if (commet_readset_begin_file(rs) ||
-            commet_host::stream_records(rs, maps[i]->format(), maps[i]->data(), maps[i]->size(), nrec[i], err)) {
-            if (!err.empty()) fail("%s: %s", paths[i], err.c_str());
-            commet_readset_destroy(rs);
-            return nullptr;
+    const int T = ingest_threads();
+    // pieces
+    std::vector<Piece> pieces;
+    for (int f = 0; f < n_paths; ++f) {
+        const char *d = maps[f]->data();
+        const size_t n = maps[f]->size();
+        const int want = (maps[f]->format() == commet_host::ReadFormat::Fasta && n > (8u << 20)) ? T * 4 : 1;
+        size_t b = 0;
+        for (int q = 0; q < want && b < n; ++q) {
+            size_t e = (q == want - 1) ? n : std::min(n, (size_t) ((double) n * (q + 1) / want));
+            if (e < n) {   // advance to the next line that starts with '>'
+                const char *x = d + e;
+                for (;;) {
+                    const char *nl = (const char *) memchr(x, '\n', (size_t) (d + n - x));
+                    if (!nl || nl + 1 >= d + n) { e = n; break; }
+                    if (nl[1] == '>') { e = (size_t) (nl + 1 - d); break; }
+                    x = nl + 1;
+                }
+            }
+            if (e > b) {
+                Piece p;
+                p.file = f;
+                p.fmt = maps[f]->format();
+                p.d = d + b;
+                p.n = e - b;
+                pieces.push_back(p);
+            }
+            b = e;
         }
     }
-    if (rs->n_reads != max_reads) {
-        fail("Error in Fasta format !!");
+    auto run_parallel = [&](const std::function<void(size_t)> &fn) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        const int nt = (int) std::min<size_t>((size_t) T, pieces.size());
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                (void) t;
+                for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) fn(i);
+            });
+        for (std::thread &x : th) x.join();
+    };
+    // pass A: counts
+    run_parallel([&](size_t i) { count_piece(pieces[i]); });
+    uint64_t total_reads = 0, total_bases = 0;
+    std::vector<uint64_t> file_reads(n_paths, 0);
+    for (Piece &p : pieces) {
+        p.read0 = total_reads;
+        p.base0 = total_bases;
+        total_reads += p.n_reads;
+        total_bases += p.n_bases;
+        file_reads[p.file] += p.n_reads;
+    }
+    commet_readset *rs = commet_readset_create(c, total_reads, total_bases);
+    if (!rs) return nullptr;
+    {
+        uint64_t pos = 0;
+        for (int f = 0; f < n_paths; ++f) {
+            rs->files.push_back(FileSpan{pos, file_reads[f]});
+            pos += file_reads[f];
+        }
+    }
+    // pass B: parse + upload, T workers with two pinned staging buffers each
+    IngestShared sh;
+    sh.rs = rs;
+    const int nt = (int) std::min<size_t>((size_t) T, std::max<size_t>(pieces.size(), 1));
+    std::vector<IngestStage> stages((size_t) nt * 2);
+    bool ok = hipSetDevice(c->device) == hipSuccess;
+    for (IngestStage &st : stages) {
+        if (!ok) break;
+        ok = hipHostMalloc((void **) &st.h_bases, INGEST_STAGE_BASES) == hipSuccess &&
+             hipHostMalloc((void **) &st.h_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
+             hipMalloc((void **) &st.d_bases, INGEST_STAGE_BASES) == hipSuccess &&
+             hipMalloc((void **) &st.d_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
+             hipEventCreateWithFlags(&st.done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (ok) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                (void) hipSetDevice(c->device);
+                for (size_t i = next.fetch_add(1); i < pieces.size() && !sh.failed; i = next.fetch_add(1)) {
+                    const int rc = ingest_piece(sh, pieces[i], &stages[(size_t) t * 2]);
+                    if (rc) {
+                        std::lock_guard<std::mutex> lk(sh.mu);
+                        sh.err = rc == 2 ? "a read does not fit the staging buffer" : "upload failed";
+                        sh.failed = true;
+                    }
+                }
+            });
+        for (std::thread &x : th) x.join();
+        ok = !sh.failed;
+    }
+    (void) hipStreamSynchronize(c->stream);
+    for (IngestStage &st : stages) {
+        if (st.h_bases) (void) hipHostFree(st.h_bases);
+        if (st.h_offs) (void) hipHostFree(st.h_offs);
+        (void) hipFree(st.d_bases);
+        (void) hipFree(st.d_offs);
+        if (st.done) (void) hipEventDestroy(st.done);
+    }
+    if (!ok) {
+        fail("%s", sh.err.empty() ? "read set ingest failed" : sh.err.c_str());
         commet_readset_destroy(rs);
         return nullptr;
     }
+    rs->n_reads = total_reads;
+    rs->n_bases = total_bases;
+    std::sort(rs->empty_reads.begin(), rs->empty_reads.end());
     return rs;
 }
 

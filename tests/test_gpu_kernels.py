@@ -237,3 +237,37 @@ def test_bucketed_index_equals_atomic_index_large_k(commet, k):
         f = ob.Bloom(k)
         f.index(bases, offs)
         assert np.array_equal(out[1][3], f.bytes())
+
+
+def test_parallel_host_ingest_equals_batch_upload(commet, tmp_path, monkeypatch):
+    """commet_readset_from_fasta (multi-threaded parse, pieces uploaded out of order at explicit positions)
+    must give the same resident set as the in-order batch API: FASTA (multi-line, > 8 MB so that it is cut
+    into pieces), FASTQ and gzip files in one set."""
+    monkeypatch.setenv("COMMET_INGEST_THREADS", "3")
+    rng = np.random.default_rng(11)
+    big = util.random_reads(rng, 90000, 60, 140, n_rate=0.01)
+    big[1000] = b"ACGT" * 3                                  # short read
+    small = util.random_reads(rng, 3000, 20, 90, n_rate=0.02)
+    fq = util.random_reads(rng, 5000, 30, 120, n_rate=0.01)
+    paths = [str(tmp_path / "big.fa"), str(tmp_path / "small.fa.gz"), str(tmp_path / "x.fq"), str(tmp_path / "y.fq.gz")]
+    util.write_reads(paths[0], big, "fa", rng=rng, multiline=True)
+    util.write_reads(paths[1], small, "fa.gz", rng=rng, multiline=True)
+    util.write_reads(paths[2], fq, "fq")
+    util.write_reads(paths[3], fq[::-1], "fq.gz")
+    assert max(len(open(paths[0], "rb").read()), 0) > (8 << 20)
+    k, t = 25, 2
+    with commet.Context(k=k, t=t) as ctx:
+        a = commet.ReadSet.from_fasta(ctx, paths)
+        parsed = [util.parse_reads(p) for p in paths]
+        b = commet.ReadSet.from_files(ctx, [util.to_batch(r) for r in parsed])
+        assert a.file_reads() == b.file_reads() == [len(r) for r in parsed]
+        assert np.array_equal(a.kmer_counts(), b.kmer_counts())
+        idx = commet.ReadSet.from_files(ctx, [util.to_batch(big[:20000] + fq[:2000])])
+        ta, sa, _ = ctx.index_and_search(idx, [a])
+        tb, sb, _ = ctx.index_and_search(idx, [b])
+        assert np.array_equal(ta[0], tb[0]) and sa[0]["shared"] == sb[0]["shared"] > 20000
+        # and as an index set (chunk plan uses the per-read k-mer counts and the file spans)
+        q = commet.ReadSet.from_files(ctx, [util.to_batch(big[:5000])])
+        t1, s1, i1 = ctx.index_and_search(a, [q])
+        t2, s2, i2 = ctx.index_and_search(b, [q])
+        assert np.array_equal(t1[0], t2[0]) and i1["n_chunks"] == i2["n_chunks"] and i1["kmers_indexed"] == i2["kmers_indexed"]
