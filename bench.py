@@ -181,7 +181,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr[0] if tr else None,
                     "traffic_source": tr[1] if tr else None,
                     "launches_per_step": launches, "avg_launch_ms": round(kms / max(launches, 1), 3),
-                    "algorithmic_bytes_per_launch": round(kbytes / max(launches, 1))}
+                    "algorithmic_bytes_per_launch": round(kbytes / max(launches, 1)),
+                    "note": "algorithmic bytes = reference probes x 64-B sectors (SURVEY 8d); frac > 1 or traffic < algorithmic "
+                            "means one HBM request serves several reference probes (strand-paired, chunk-interleaved plane A)"}
         out = {
             "metric": "reads/sec searched (index_and_search, k=%d)" % k,
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,

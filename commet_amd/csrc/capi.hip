@@ -584,6 +584,8 @@ extern "C" {
 commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *paths, int n_paths)
 {
     std::vector<std::unique_ptr<commet_host::ReadFileData>> maps;
+    std::vector<const char *> data;
+    std::vector<uint64_t> sizes;
     for (int i = 0; i < n_paths; ++i) {
         std::unique_ptr<commet_host::ReadFileData> mf(new commet_host::ReadFileData);
         if (!mf->open_file(paths[i])) {
@@ -594,7 +596,31 @@ commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *path
             fail("Unknown format: %s", paths[i]);
             return nullptr;
         }
+        data.push_back(mf->data());
+        sizes.push_back(mf->size());
         maps.push_back(std::move(mf));
+    }
+    return commet_readset_from_buffers(c, data.data(), sizes.data(), n_paths);
+}
+
+commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *data, const uint64_t *sizes, int n_paths)
+{
+    struct Buf {
+        const char *d;
+        size_t n;
+        commet_host::ReadFormat fmt;
+        const char *data() const { return d; }
+        size_t size() const { return n; }
+        commet_host::ReadFormat format() const { return fmt; }
+    };
+    std::vector<std::unique_ptr<Buf>> maps;
+    for (int i = 0; i < n_paths; ++i) {
+        std::unique_ptr<Buf> b(new Buf{data[i], (size_t) sizes[i], commet_host::sniff_format(data[i], (size_t) sizes[i])});
+        if (b->fmt == commet_host::ReadFormat::Unknown) {
+            fail("Unknown format: file %d of the set is neither FASTA nor FASTQ text", i);
+            return nullptr;
+        }
+        maps.push_back(std::move(b));
     }
     const int T = ingest_threads();
     // pieces

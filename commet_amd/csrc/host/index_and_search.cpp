@@ -82,7 +82,7 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
 {
     out.nickname = nickname;
     std::vector<std::unique_ptr<ReadFileData>> maps;
-    uint64_t max_reads = 0, max_bases = 0;
+    std::vector<bool> bv_given;
     for (const SetEntry &en : entries) {
         if (en.bv.empty()) std::cout << "open " << en.file << "\n";
         else std::cout << "open " << en.file << "," << en.bv << "\n";
@@ -102,42 +102,39 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
         }
         LoadedFile lf;
         lf.name = en.file;
-        lf.nb_reads = count_records(mf->format(), mf->data(), mf->size());
-        if (en.bv.empty()) lf.filter.init_true(lf.nb_reads);
-        else {
+        if (!en.bv.empty()) {
             if (!read_bv(en.bv, lf.filter)) exit(1);
             out.any_bv = true;
-            if (lf.nb_reads != lf.filter.size) {   // fasta_file.h:108-111
-                std::cerr << "Number of reads in " << en.file << " and boolean vector size are not equal -> quit\n";
-                exit(1);
-            }
         }
-        max_reads += lf.nb_reads;
-        max_bases += mf->size();
         out.files.push_back(lf);
+        bv_given.push_back(!en.bv.empty());
         maps.push_back(std::move(mf));
     }
-    out.rs = commet_readset_create(ctx, max_reads, max_bases);
+    // parse + upload all files of the set (several host threads, pinned staging, hipMemcpyAsync + packing kernel)
+    std::vector<const char *> data;
+    std::vector<uint64_t> sizes;
+    for (const std::unique_ptr<ReadFileData> &mf : maps) {
+        data.push_back(mf->data());
+        sizes.push_back(mf->size());
+    }
+    out.rs = commet_readset_from_buffers(ctx, data.data(), sizes.data(), (int) maps.size());
     if (!out.rs) {
         std::cerr << "Error: " << commet_last_error() << "\n";
         exit(1);
-    }
-    for (size_t i = 0; i < out.files.size(); ++i) {
-        std::string err;
-        if (commet_readset_begin_file(out.rs) ||
-            stream_records(out.rs, maps[i]->format(), maps[i]->data(), maps[i]->size(), out.files[i].nb_reads, err)) {
-            std::cerr << "Error: " << (err.empty() ? commet_last_error() : err.c_str()) << "\n";
-            exit(1);
-        }
     }
     if (commet_readset_finalize(out.rs)) {
         std::cerr << "Error: " << commet_last_error() << "\n";
         exit(1);
     }
     out.n_reads = commet_readset_num_reads(out.rs);
-    if (out.n_reads != max_reads) {
-        std::cerr << "Error in Fasta format !!\n";   // fasta_file.h:158-161 (record count and records disagree)
-        exit(1);
+    for (size_t i = 0; i < out.files.size(); ++i) {
+        LoadedFile &lf = out.files[i];
+        lf.nb_reads = commet_readset_file_reads(out.rs, i);
+        if (!bv_given[i]) lf.filter.init_true(lf.nb_reads);
+        else if (lf.nb_reads != lf.filter.size) {   // fasta_file.h:108-111
+            std::cerr << "Number of reads in " << lf.name << " and boolean vector size are not equal -> quit\n";
+            exit(1);
+        }
     }
     // set-wide select bits = the per-file filters, concatenated
     out.select.assign(out.n_reads / 8 + 1, 0);

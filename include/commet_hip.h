@@ -85,6 +85,10 @@ int             commet_readset_append(commet_readset *rs, const uint8_t *bases, 
  * fastq_file.h:139-190).  Replaces FileManager::addFile + the ReadFile parsers for
  * resident sets (file_manager.h:117-171).  The set is NOT finalized.  NULL on error. */
 commet_readset *commet_readset_from_fasta(commet_ctx *ctx, const char *const *paths, int n_paths);
+/* Same, from file contents already in memory (plain FASTA / FASTQ text, one buffer per file of the set;
+ * the buffers must stay valid until the call returns).  Records are parsed by several host threads
+ * (COMMET_INGEST_THREADS, default 8) and uploaded out of order at their final positions. */
+commet_readset *commet_readset_from_buffers(commet_ctx *ctx, const char *const *data, const uint64_t *sizes, int n_files);
 /* reads of file `file_index` of the set (all records, selected or not) */
 uint64_t        commet_readset_file_reads(const commet_readset *rs, uint64_t file_index);
 /* Ends loading: waits for the uploads, fetches the per-read counts of complete

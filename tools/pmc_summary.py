@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1")   # wide coalesced readers
+STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1", "interleave_a")   # wide coalesced readers
 
 
 def short(name):
