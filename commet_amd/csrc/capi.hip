@@ -1,6 +1,8 @@
 // capi.hip — implementation of include/commet_hip.h on HIP (gfx950).
-// Host side: context, HBM residency of read sets, pinned double-buffered
-// ingest, the chunk loop of index_and_search on resident sets.
+// Host side: context (filter slots, scratch of the bucketed index build), HBM
+// residency of read sets, pinned multi-threaded ingest, exact chunk planning
+// (read_iter.hpp) and the chunk loop of index_and_search on resident sets
+// (chunks taken in groups, see search_group_kernel in kernels.hpp).
 #include "../../include/commet_hip.h"
 
 #include "kernels.hpp"
@@ -1187,8 +1189,6 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             if (new_event(&a) || new_event(&b)) { rc = 1; break; }
             (void) hipEventRecord(a, c->stream);
         }
-        double zero_before = 0;
-        (void) zero_before;
         for (int i = 0; i < g && !rc; ++i) {
             const Chunk &ch = plan.chunks[ci + i];
             c->cur_slot = i;

@@ -6,8 +6,11 @@
 //             for ACGTacgt.  Read r starts at triple index (goff[r] >> 5) + r,
 //             goff = cumulative base offsets (n+1 entries).
 //   filter  : four bit-planes A,B,C,D of 2^k bits each (plane p at words
-//             [p*plane_words, (p+1)*plane_words)), bit `key` of plane X =
-//             lane X of the reference filter at that key.
+//             [p*plane_words, (p+1)*plane_words) of a filter slot).  Bit `key`
+//             of planes B,C,D = lane b,c,d of the reference filter at that
+//             key; plane A holds lane a of `key` at bit psi_a(key) (strand-
+//             paired layout, below).  Up to 4 slots hold the filters of a
+//             group of chunks; their A planes are also kept word-interleaved.
 //   bitmaps : 64 reads per uint64 word, LSB-first (== BooleanVector bytes).
 //
 // Hash structure used everywhere below (hash_key.h:63-123):
