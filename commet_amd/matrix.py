@@ -158,7 +158,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
     # ---- residency: every rank holds every set (packed: 12 B per 32 bases) ----------------------------------
     t0 = time.perf_counter()
-    ctx = commet_amd.Context(k=k, t=t, device=ranks.local_rank)
+    # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU
+    ctx = commet_amd.Context(k=k, t=t, device=int(os.environ.get("COMMET_FORCE_DEVICE", ranks.local_rank)))
     sets = [commet_amd.ReadSet.from_fasta(ctx, fl) for fl in files]
     counts = [rs.file_reads() for rs in sets]
     sel = []

@@ -111,3 +111,21 @@ def test_matrix_driver_matches_oracle_on_synthetic_sets(tmp_path, monkeypatch):
                 tot = sum(util.bools_from_bits(util.read_bv(f"orc/{f}_in_{names[b]}.bv")[2], util.read_bv(f"orc/{f}_in_{names[b]}.bv")[1]).sum()
                           for f in files[a])
                 assert res["matrix"][a][b] == int(tot)
+
+
+def test_matrix_driver_two_ranks_share_the_pairs(abcde, monkeypatch):
+    """N > 1: two processes (torch.distributed.run, gloo) deal the pair chains between them, write their .bv
+    files side by side and rank 0 assembles the matrices.  Both ranks use GPU 0 here (COMMET_FORCE_DEVICE);
+    outputs must equal Commet.py's."""
+    import subprocess
+    gold = os.path.join(GOLD, "abcde", "commet_py", "five_sets")
+    monkeypatch.chdir(abcde)
+    open("sets.txt", "w").write(open(os.path.join(gold, "sets.txt")).read())
+    env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), "-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    for f in sorted(os.listdir(gold)):
+        if f.endswith((".csv", ".bv")):
+            assert open(os.path.join("out2", f), "rb").read() == open(os.path.join(gold, f), "rb").read(), f
