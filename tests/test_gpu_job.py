@@ -55,3 +55,49 @@ def test_job_matches_oracle(tmp_path, seed, index_mode):
                 pos += n
         for r in [irs] + srs:
             r.close()
+
+
+@pytest.mark.parametrize("k,t,chunk_group", [(20, 2, 4), (24, 3, 2), (33, 2, 4), (16, 2, 1)])
+def test_long_and_ragged_reads(tmp_path, k, t, chunk_group):
+    """reads far longer than the fast paths' limits (search masks cover 256 bases, chunk groups need <= 64 KiB of
+    masks, the bucketed index needs <= 4096 k-mers per read): every fallback must still match the CPU checker"""
+    import commet_amd as commet
+    rng = np.random.default_rng(k * 7 + t)
+    d = tmp_path / "long"
+    os.makedirs(d)
+    lens = [int(x) for x in rng.choice([40, 150, 257, 300, 1000, 4100, 6000], size=260)]
+    idx_reads = [util.random_reads(rng, 1, L, L, n_rate=0.002)[0] for L in lens]
+    q_src = idx_reads[:120]
+    q_reads = []
+    for i in range(400):
+        r = q_src[int(rng.integers(0, len(q_src)))]
+        a = int(rng.integers(0, max(1, len(r) - 30)))
+        piece = r[a:a + int(rng.integers(30, 2500))]
+        if i % 3 == 0:
+            piece = util.revcomp(piece)
+        if i % 5 == 0:
+            piece = util.mutate(rng, piece, 0.01)
+        q_reads.append(util.random_reads(rng, 1, 5, 400)[0] + piece if i % 2 else piece)
+    q_reads += util.random_reads(rng, 100, 20, 700)
+    util.write_fasta(str(d / "i.fa"), idx_reads, rng=rng, multiline=True)
+    util.write_fasta(str(d / "q.fa"), q_reads, rng=rng, multiline=True)
+    (d / "index.txt").write_text("I:i.fa\n")
+    (d / "search.txt").write_text("Q:q.fa\n")
+
+    class S:      # what run_oracle needs
+        dir, index_cfg, search_cfg = str(d), "index.txt", "search.txt"
+    S.k, S.t = k, t
+    rc, res, chunks, kmers = run_oracle(S, str(tmp_path / "o"), str(tmp_path / "l"))
+    assert rc == 0
+    with commet.Context(k=k, t=t) as ctx:
+        ctx.set_option("count_probes", 1)
+        ctx.set_option("chunk_group", chunk_group)
+        irs = commet.ReadSet.from_fasta(ctx, [str(d / "i.fa")])
+        qrs = commet.ReadSet.from_fasta(ctx, [str(d / "q.fa")])
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        assert info["probes"] == res[0]["probes"]
+        assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == (res[0]["indexed"], res[0]["searched"], res[0]["shared"])
+        _, n, bits = util.read_bv(str(tmp_path / "o" / "q.fa_in_I.bv"))
+        assert np.array_equal(util.bools_from_bits(tags[0], n), util.bools_from_bits(bits, n))
+        assert stats[0]["shared"] > 100
