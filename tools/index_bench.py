@@ -31,9 +31,13 @@ def main():
                 times.append(ctx.last_kernel_ms()[0])
             found, _, nf = ctx.search_reads(qs)
             res[mode] = (fed, nf, found)
+            if k <= 28:      # small enough to pull the whole filter back: bit-exact comparison of the two constructions
+                res[mode] = res[mode] + (ctx.export_filter_reference(),)
             print(f"mode={mode} kmers={fed} index_ms={['%.2f' % t for t in times]} -> {fed * 4 / min(times) / 1e6:.2f} G keys/s; found={nf}",
                   flush=True)
     assert res[1][0] == res[2][0] and res[1][1] == res[2][1] and np.array_equal(res[1][2], res[2][2]), "MISMATCH"
+    if len(res[1]) > 3:
+        assert np.array_equal(res[1][3], res[2][3]), "FILTER MISMATCH"
     print("modes agree")
 
 
