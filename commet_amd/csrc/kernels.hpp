@@ -264,22 +264,33 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
         const uint32_t *p = rv.planes + 3 * t0;
         const int sh = T::BITS - k;
         const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+        // Pruning (exact): a hit at window end q can still lead to t hits only if the remaining t-seen-1
+        // non-overlapping windows fit behind it, q + (t-seen-1)*k <= len-1.  Past that point the reference keeps
+        // probing but can no longer tag the read, so the scan of the strand stops (not in COUNT builds, which
+        // reproduce the reference's probe count).
+        const int last = (int) len - 1;
+        uint32_t mask_words = 0;   // words of rc_bits / rc_known the forward pass has written for this lane
         for (int strand = 0; strand < 2 && !found; ++strand) {
             W wh = 0, wl = 0;
             uint32_t run = 0;
             int seen = 0;
-            for (uint32_t w = 0; w * 32u < len && !found; ++w) {
+            bool dead = false;   // no room left for the missing hits on this strand
+            for (uint32_t w = 0; w * 32u < len && !found && !dead; ++w) {
                 const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
                 const uint32_t nb = min(32u, len - w * 32u);
                 uint32_t rcw = 0, knw = 0;
-                if (strand == 1 && w < SEARCH_MASK_WORDS) {
+                if (strand == 1 && w < mask_words) {
                     rcw = rc_bits[w][threadIdx.x];
                     knw = rc_known[w][threadIdx.x];
                 }
-                for (uint32_t j = 0; j < nb && !found; ++j) {
+                for (uint32_t j = 0; j < nb && !found && !dead; ++j) {
                     wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
                     wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
                     run = ((va >> j) & 1u) ? run + 1 : 0;
+                    if (!COUNT && (int) (32u * w + j) + (t - seen - 1) * k > last) {
+                        dead = true;
+                        break;
+                    }
                     if (run >= (uint32_t) k) {
                         W ka, kb;
                         bool hit;
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
                 if (strand == 0 && w < SEARCH_MASK_WORDS) {
                     rc_bits[w][threadIdx.x] = rcw;
                     rc_known[w][threadIdx.x] = knw;
+                    mask_words = w + 1;
                 }
             }
         }
@@ -417,13 +429,19 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
         const uint32_t *p = rv.planes + 3 * t0;
         const int sh = T::BITS - k;
         const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
-        // (1) gather: lane-a bits of every complete window, all chunks, both strands
+        // Pruning (exact, see search_kernel): with `seen` hits a window ending at q matters only if
+        // q + (t-seen-1)*k <= len-1.  The gather therefore covers the windows that can be a FIRST hit,
+        // q <= pe = len-1-(t-1)*k (all of them in COUNT builds); later windows are needed only after a real
+        // 4-lane hit and are then probed one by one in the replay.
+        const int last = (int) len - 1;
+        const int pe = COUNT ? last : last - (t - 1) * k;
+        // (1) gather: lane-a bits of the complete windows ending at or before pe, all chunks, both strands
         {
             W wh = 0;
             uint32_t run = 0;
-            for (uint32_t w = 0; w * 32u < len; ++w) {
+            for (uint32_t w = 0; w * 32u < len && (int) (w * 32u) <= pe; ++w) {
                 const uint32_t hi = p[3 * w], va = p[3 * w + 2];
-                const uint32_t nb = min(32u, len - w * 32u);
+                const uint32_t nb = min(min(32u, len - w * 32u), (uint32_t) (pe - (int) (w * 32u) + 1));
                 uint32_t fm[GS], rm[GS];
 #pragma unroll
                 for (int i = 0; i < GS; ++i) fm[i] = 0, rm[i] = 0;
@@ -461,26 +479,37 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                 W wh = 0, wl = 0;
                 uint32_t run = 0;
                 int seen = 0;
-                for (uint32_t w = 0; w * 32u < len && !found; ++w) {
+                bool dead = false;
+                for (uint32_t w = 0; w * 32u < len && !found && !dead; ++w) {
                     const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
                     const uint32_t nb = min(32u, len - w * 32u);
-                    const uint32_t am = mask_at(i, strand, w);
-                    for (uint32_t j = 0; j < nb && !found; ++j) {
+                    const uint32_t am = ((int) (w * 32u) <= pe) ? mask_at(i, strand, w) : 0u;
+                    for (uint32_t j = 0; j < nb && !found && !dead; ++j) {
                         wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
                         wl = (wl >> 1) | ((W) ((lo >> j) & 1u) << (k - 1));
                         run = ((va >> j) & 1u) ? run + 1 : 0;
+                        const int q = (int) (32u * w + j);
+                        if (!COUNT && q + (t - seen - 1) * k > last) {
+                            dead = true;
+                            break;
+                        }
                         if (run >= (uint32_t) k) {
-                            bool hit = (am >> j) & 1u;
+                            W ka, kb;
+                            if (strand == 0) {
+                                ka = T::brev(wh) >> sh;
+                                kb = T::brev(wl) >> sh;
+                            } else {
+                                ka = ~wh & mask;
+                                kb = ~wl & mask;
+                            }
+                            bool hit;
+                            if (q <= pe) hit = (am >> j) & 1u;          // gathered
+                            else {                                      // behind a real hit: probe chunk i's A plane
+                                const W addr = psi_a<W>(ka, k);
+                                hit = (fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> ((uint32_t) addr & 31u)) & 1u;
+                            }
                             if (COUNT) ++probes;
                             if (hit) {
-                                W ka, kb;
-                                if (strand == 0) {
-                                    ka = T::brev(wh) >> sh;
-                                    kb = T::brev(wl) >> sh;
-                                } else {
-                                    ka = ~wh & mask;
-                                    kb = ~wl & mask;
-                                }
                                 hit = test_bit<W>(pb, kb);
                                 if (COUNT) ++probes;
                                 if (hit) {

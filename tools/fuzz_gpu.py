@@ -1,0 +1,68 @@
+"""Extended randomised parity run (not part of the test-suite): job-level GPU results against the CPU checker
+on many scenarios of tests/scenarios.py, cycling through index modes, chunk-group sizes and input formats.
+  python tools/fuzz_gpu.py [first_seed] [count]"""
+import os
+import sys
+import tempfile
+import shutil
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import commet_amd  # noqa: E402
+import util  # noqa: E402
+from scenarios import Scenario, run_oracle  # noqa: E402
+
+
+def load_set(ctx, files, sdir):
+    rs = commet_amd.ReadSet.from_fasta(ctx, [os.path.join(sdir, fa) for fa, _, _, _ in files])
+    sel = np.concatenate([s for _, _, _, s in files]) if files else np.zeros(0, bool)
+    return rs, (util.bits_from_bools(sel) if any(bv for _, bv, _, _ in files) else None)
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    bad = 0
+    for seed in range(first, first + count):
+        d = tempfile.mkdtemp(prefix="fuzz")
+        try:
+            mode = seed % 3
+            k = None if mode != 2 else [20, 21, 24, 25, 28][seed % 5]
+            fmts = ("fa", "fq", "fa.gz", "fq.gz") if seed % 4 == 0 else ("fa",)
+            scn = Scenario(os.path.join(d, "s"), seed, k=k, n_scale=1.0 + (seed % 7), formats=fmts,
+                           crlf=False if len(fmts) > 1 else None)
+            rc, res, chunks, kmers = run_oracle(scn, os.path.join(d, "o"), os.path.join(d, "l"))
+            assert rc == 0
+            with commet_amd.Context(k=scn.k, t=scn.t) as ctx:
+                ctx.set_option("count_probes", 1)
+                ctx.set_option("index_mode", mode)
+                ctx.set_option("chunk_group", 1 + seed % 4)
+                irs, isel = load_set(ctx, scn.sets[scn.index_name], scn.dir)
+                names = sorted(scn.search_names)
+                loaded = [load_set(ctx, scn.sets[nme], scn.dir) for nme in names]
+                tags, stats, info = ctx.index_and_search(irs, [x[0] for x in loaded], isel, [x[1] for x in loaded])
+                ok = info["n_chunks"] == chunks and info["kmers_indexed"] == kmers and \
+                    info["probes"] == sum(r["probes"] for r in res)
+                by = {r["name"]: r for r in res}
+                for nme, tg, st in zip(names, tags, stats):
+                    o = by[nme]
+                    ok &= (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"])
+                    pos = 0
+                    for fa, _, reads, _ in scn.sets[nme]:
+                        _, n, bits = util.read_bv(os.path.join(d, "o", os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                        ok &= bool(np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)))
+                        pos += n
+            if not ok:
+                bad += 1
+                print("MISMATCH seed", seed, "k", scn.k, "t", scn.t, "mode", mode, flush=True)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    print(f"fuzz: {count} scenarios from seed {first}, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
