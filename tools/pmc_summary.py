@@ -18,7 +18,9 @@ STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1", "inter
 
 def short(name):
     n = name.replace("void ", "").replace("commet::", "")
-    return n.split("(")[0].split("<")[0]
+    base = n.split("(")[0].split("<")[0]
+    # the probe-counting instantiations (COUNT = true) only run in bench.py's untimed P_ref step
+    return base + "[count]" if ", true>(" in n else base
 
 
 def main(d):
