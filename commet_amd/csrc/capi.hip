@@ -80,6 +80,8 @@ struct commet_ctx {
     bool have_index_ev = false, have_search_ev = false;
     bool count_probes = false;
     int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
+    int part_debug = 0;               // timing ablations of scatter1 (wrong results), tools only
+    int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
     int s2_swizzle = 0;               // scatter2 slab order: 1 = XCD-contiguous (measured 5 % slower: off)
     uint64_t part_min_kmers = 8ull << 20;
     // workspace of the bucketed construction (index_part.hpp)
@@ -838,6 +840,12 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     if (count == 0 || kmers == 0) return 0;
     PartGeom g = make_geom(c->k);
     g.xcd_swizzle = c->s2_swizzle;
+    g.debug = c->part_debug;
+    if (c->part_b1 > 0 && c->part_b1 < g.nb_bits && c->part_b1 <= 8 && g.nb_bits - c->part_b1 <= 9) {
+        g.b1 = c->part_b1;
+        g.b2 = g.nb_bits - g.b1;
+        g.nb1 = 1u << g.b1;
+    }
     const uint64_t total = 4 * kmers;
     if (c->part_nb != g.nb) {
         (void) hipFree(c->part_hist); (void) hipFree(c->part_wl); (void) hipFree(c->part_off);
@@ -1329,6 +1337,14 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "chunk_group")) {       // chunk filters searched per pass over a set (1 = reference order)
         if (value < 1 || value > 4) return fail("chunk_group must be 1..4");
         c->chunk_group = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "part_debug")) {
+        c->part_debug = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "part_b1")) {
+        c->part_b1 = (int) value;
         return 0;
     }
     if (!strcmp(name, "s2_swizzle")) {

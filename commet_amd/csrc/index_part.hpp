@@ -53,6 +53,7 @@ struct PartGeom {
     uint32_t nb1;        // coarse buckets
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
     int      xcd_swizzle;   // scatter2: XCD-contiguous slab order (speed only)
+    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics, 8 no plan_round
 };
 
 inline PartGeom make_geom(int k)
@@ -67,6 +68,7 @@ inline PartGeom make_geom(int k)
     g.nb1 = 1u << g.b1;
     g.plane_shift = k - TILE_BITS;
     g.xcd_swizzle = 0;
+    g.debug = 0;
     return g;
 }
 
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
         __syncthreads();
         // my item: id = tid
-        uint32_t cka[1][8], ckb[1][8], cvalid[1] = {0};   // used when CACHE
+        uint32_t cka[1][8], ckb[1][8], cpa[1][8], crk[1][16], cvalid[1] = {0};   // used when CACHE: keys, psi(keya), ranks
         uint32_t islot[1], iq[1];
         bool ion[1];
 #pragma unroll
@@ -424,13 +426,20 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
                     const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
                     cka[u][jj] = (uint32_t) ka;
                     ckb[u][jj] = (uint32_t) kb;
+                    crk[u][2 * jj] = crk[u][2 * jj + 1] = 0;
                     if (ok) {
                         cvalid[u] |= 1u << jj;
                         const W kc = ka ^ kb, kd = ka | kb;
-                        atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (psi_a<W>(ka, g.k) >> TILE_BITS)) >> g.b2], 1u);
-                        atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
-                        atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
-                        atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
+                        const W pa = psi_a<W>(ka, g.k);
+                        cpa[u][jj] = (uint32_t) pa;
+                        if (g.debug & 4) continue;
+                        // the returned value is the key's rank inside its coarse bucket for this round (< S1_KEYS <= 2^16)
+                        const uint32_t r0 = atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (pa >> TILE_BITS)) >> g.b2], 1u);
+                        const uint32_t r1 = atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
+                        const uint32_t r2 = atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
+                        const uint32_t r3 = atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
+                        crk[u][2 * jj] = r0 | (r1 << 16);
+                        crk[u][2 * jj + 1] = r2 | (r3 << 16);
                     }
                 }
             } else {
@@ -444,9 +453,15 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         lds_scan<NT>(cnt, base, g.nb1, wsum);
         if (threadIdx.x < g.nb1) {
             const uint32_t c = cnt[threadIdx.x];
-            gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
+            if (g.debug & 16) gbase[threadIdx.x] = cursor1[threadIdx.x];   // timing only: no reservation
+            else gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
         }
-        // pass B: place
+        // pass B: place (32-bit keys: the rank returned by pass A's counter; otherwise a second counter)
+        auto place_ranked = [&](uint32_t plane, W key, uint32_t rank) {
+            const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+            const uint32_t pos = base[b >> g.b2] + rank;
+            if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
+        };
         auto place = [&](uint32_t plane, W key) {
             const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
             const uint32_t c1 = b >> g.b2;
@@ -455,16 +470,16 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         };
 #pragma unroll
         for (int u = 0; u < 1; ++u) {
-            if (!ion[u]) continue;
+            if (!ion[u] || (g.debug & 2)) continue;
             if (CACHE) {
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     if (!((cvalid[u] >> jj) & 1u)) continue;
                     const W ka = cka[u][jj], kb = ckb[u][jj];
-                    place(0u, psi_a<W>(ka, g.k));
-                    place(1u, kb);
-                    place(2u, ka ^ kb);
-                    place(3u, ka | kb);
+                    place_ranked(0u, (W) cpa[u][jj], crk[u][2 * jj] & 0xFFFFu);
+                    place_ranked(1u, kb, crk[u][2 * jj] >> 16);
+                    place_ranked(2u, ka ^ kb, crk[u][2 * jj + 1] & 0xFFFFu);
+                    place_ranked(3u, ka | kb, crk[u][2 * jj + 1] >> 16);
                 }
             } else {
                 for_each_key<W>(rv.planes + 3 * rd_t0[islot[u]], rd_len[islot[u]], iq[u], g.k, place);
@@ -472,6 +487,7 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         }
         __syncthreads();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
+        if (!(g.debug & 1))
         for (uint32_t c1 = wave; c1 < g.nb1; c1 += NT / 64) {
             const uint32_t n = cnt[c1], src = base[c1];
             const unsigned long long dst = gbase[c1];
