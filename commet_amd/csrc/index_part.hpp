@@ -199,6 +199,26 @@ __device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, ui
     __syncthreads();
 }
 
+// Copies one sorted run of n keys from LDS to out[dst ..) with 16-byte stores: the lanes g = 0..G-1 of a lane group
+// share the run; up to 3 keys before the first 16-byte boundary and up to 3 after the last whole vector go out as
+// single dwords.  Four runs per wave instruction (G = 16) quadruple the bytes per store instruction, which is what
+// the write-out phase is bound by (store issue, ~7 B/clk/CU with one dword per lane).
+__device__ __forceinline__ void write_run(uint32_t *__restrict__ out, unsigned long long dst, const uint32_t *sorted,
+                                          uint32_t src, uint32_t n, uint32_t g, uint32_t G)
+{
+    const uint32_t head = min(n, (uint32_t) ((4u - (uint32_t) (dst & 3ull)) & 3u));
+    if (g < head) out[dst + g] = sorted[src + g];
+    const uint32_t nvec = (n - head) >> 2;
+    const uint32_t s0 = src + head;
+    uint4 *o4 = (uint4 *) (out + dst + head);
+    for (uint32_t v = g; v < nvec; v += G) {
+        const uint32_t *q = sorted + s0 + 4 * v;
+        o4[v] = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    const uint32_t done = head + 4 * nvec;
+    if (g < n - done) out[dst + done + g] = sorted[src + done + g];
+}
+
 // Picks the next reads [r, r + R) of a block's range whose keys fit `cap`
 // (R <= 256, at least 1 when the range is not empty) and builds the item
 // table: istart[i] = first item of read i, one item per octet that can end a k-mer.
@@ -488,11 +508,8 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         __syncthreads();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
         if (!(g.debug & 1))
-        for (uint32_t c1 = wave; c1 < g.nb1; c1 += NT / 64) {
-            const uint32_t n = cnt[c1], src = base[c1];
-            const unsigned long long dst = gbase[c1];
-            for (uint32_t i = lane; i < n; i += 64) out[dst + i] = sorted[src + i];
-        }
+        for (uint32_t c1 = wave * 4 + (lane >> 4); c1 < g.nb1; c1 += (NT / 64) * 4)
+            write_run(out, gbase[c1], sorted, base[c1], cnt[c1], lane & 15u, 16u);
         __syncthreads();
         r += rp.n_reads;
     }
@@ -569,11 +586,8 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
             }
         }
         __syncthreads();
-        for (uint32_t sb = wave; sb < nsub; sb += NT / 64) {
-            const uint32_t m = cnt[sb], src = base[sb];
-            const unsigned long long dst = gbase[sb];
-            for (uint32_t i = lane; i < m; i += 64) out[dst + i] = sorted[src + i];
-        }
+        for (uint32_t sb = wave * 4 + (lane >> 4); sb < nsub; sb += (NT / 64) * 4)
+            write_run(out, gbase[sb], sorted, base[sb], cnt[sb], lane & 15u, 16u);
         __syncthreads();
         pos = seg_end;
         if (pos >= c_end) ++c1;
