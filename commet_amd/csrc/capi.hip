@@ -835,7 +835,7 @@ bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
 // filter must have been zeroed on the stream before.  kmers = exact number of
 // complete k-mers of the selected reads of [first, first+count).
 int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                             uint64_t kmers, bool additive)
+                             uint64_t kmers, bool additive, bool zero_fill)
 {
     if (count == 0 || kmers == 0) return 0;
     PartGeom g = make_geom(c->k);
@@ -887,8 +887,8 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             HIP_OK(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, c->part_off, c->part_cur1,
-                       c->part_cur2, c->part_wl);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, zero_fill ? 1 : 0, c->part_off,
+                       c->part_cur1, c->part_cur2, c->part_wl);
     HIP_OK(hipGetLastError());
     // scatter 1 (straight into the final buckets when there is a single level)
     uint32_t *level1_out = g.b2 ? c->part_bufA : c->part_bufB;
@@ -912,6 +912,10 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     {
         const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
         if (grid >= (1ull << 24)) return fail("build launch too large");
+        if (zero_fill) {   // no memset happened: clear the tiles that several workgroups OR into
+            hipLaunchKernelGGL(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, c->stream, c->part_wl, g, c->slot_ptr(c->cur_slot));
+            HIP_OK(hipGetLastError());
+        }
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
         hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), c->stream,
@@ -921,26 +925,36 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     return 0;
 }
 
-// kmers: exact complete-k-mer count of the launch when known (enables the bucketed path), else ~0
-int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false)
+// whether a launch of `kmers` complete k-mers takes the bucketed construction
+bool would_partition(const commet_ctx *c, const commet_readset *rs, uint64_t kmers)
 {
-    bool part = false;
+    if (kmers == ~0ull || kmers == 0) return false;
+    if (c->index_mode == 2) return partition_eligible(c, rs);
+    if (c->index_mode == 0) return partition_eligible(c, rs) && kmers >= c->part_min_kmers;
+    return false;
+}
+
+// kmers: exact complete-k-mer count of the launch when known (enables the bucketed path), else ~0.
+// fresh_filter: the filter holds nothing yet; filter_zeroed: the caller has zeroed it (if not, a bucketed build
+// zero-fills what it does not set; the atomic kernel always needs a zeroed filter).
+int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false, bool filter_zeroed = true)
+{
     if (c->index_mode == 2) {
         if (!partition_eligible(c, rs)) return fail("bucketed index construction needs 20 <= k <= 34 and reads of at most %u k-mers", S1_KEYS / 4);
         if (kmers == ~0ull) return fail("bucketed index construction needs the k-mer count of the launch");
-        part = true;
-    } else if (c->index_mode == 0) {
-        part = partition_eligible(c, rs) && kmers != ~0ull && kmers >= c->part_min_kmers;
     }
-    if (!part) return launch_index_atomic(c, rs, first, count, d_sel, d_fed);
+    if (!would_partition(c, rs, kmers)) {
+        if (!filter_zeroed) return fail("internal error: atomic index launch on a filter that was not zeroed");
+        return launch_index_atomic(c, rs, first, count, d_sel, d_fed);
+    }
     if (d_fed) {
         // the count is known exactly on the host
         const unsigned long long v = kmers;
         HIP_OK(hipMemcpyAsync(d_fed, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
-    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter);
+    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed);
 }
 
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
@@ -1207,14 +1221,16 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 if (new_event(&z0) || new_event(&z1)) { rc = 1; break; }
                 (void) hipEventRecord(z0, c->stream);
             }
-            if (commet_filter_reset(c)) { rc = 1; break; }                   // new BloomFilter per chunk
+            // new BloomFilter per chunk: zero it, unless the bucketed build is going to write every tile anyway
+            const bool self_zeroing = ch.n_reads && would_partition(c, index_rs, ch.kmers);
+            if (!self_zeroing && commet_filter_reset(c)) { rc = 1; break; }
             if (timed) {
                 (void) hipEventRecord(z1, c->stream);
                 e_zero0.push_back(z0);
                 e_zero1.push_back(z1);
             }
             if (ch.n_reads) {
-                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true)) { rc = 1; break; }
+                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing)) { rc = 1; break; }
                 ++n_index_launches;
             }
         }

@@ -330,7 +330,9 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
 // ---------------------------------------------------------------------------
 // scan: bucket offsets, cursors, build work list.  One block of 1024 threads.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ hist, PartGeom g,
+// fill_empty != 0: the filter was NOT zeroed beforehand, so empty buckets get a work item too (their tile is written
+// as zeros) and part_zero_split_kernel clears the tiles that several workgroups will OR into.
+__global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ hist, PartGeom g, int fill_empty,
                                                          uint64_t *__restrict__ off /* nb+1 */,
                                                          unsigned long long *__restrict__ cursor1 /* nb1 */,
                                                          unsigned long long *__restrict__ cursor2 /* nb */,
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
         if (b0 + i < g.nb) {
             const uint32_t c = hist[b0 + i];
             s += c;
-            wl += (c + BUILD_CAP - 1) / BUILD_CAP;   // empty buckets need no workgroup
+            wl += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;   // empty buckets: no workgroup unless they must be zero-filled
         }
     s_sum[threadIdx.x] = s;
     s_wl[threadIdx.x] = wl;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
             if ((b & ((1u << g.b2) - 1)) == 0) cursor1[b >> g.b2] = ex;
             wl_off[b] = wex;
             ex += c;
-            wex += (c + BUILD_CAP - 1) / BUILD_CAP;
+            wex += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;
         }
     if (threadIdx.x == 1023) {
         off[g.nb] = s_sum[1023];
@@ -592,6 +594,16 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
         pos = seg_end;
         if (pos >= c_end) ++c1;
     }
+}
+
+// zeroes the tiles of buckets that are split over several build workgroups (they merge with atomic ORs)
+__global__ __launch_bounds__(256) void part_zero_split_kernel(const uint32_t *__restrict__ wl_off, PartGeom g,
+                                                              uint32_t *__restrict__ filter)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= g.nb || wl_off[b + 1] - wl_off[b] <= 1) return;
+    uint4 *d4 = (uint4 *) (filter + (uint64_t) b * TILE_WORDS);
+    for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) d4[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
