@@ -97,6 +97,15 @@ struct commet_ctx {
     uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
     int il_stride = 0;
     int chunk_group = 4;              // option: chunks searched per pass (1 = one pass per chunk)
+    // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
+    struct IngestBuf {
+        uint8_t *h_bases = nullptr;
+        uint64_t *h_offs = nullptr;
+        uint8_t *d_bases = nullptr;
+        uint64_t *d_offs = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<IngestBuf> ingest_pool;
 
     uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
     FilterView view() const
@@ -217,6 +226,13 @@ void commet_destroy(commet_ctx *c)
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->filter) (void) hipFree(c->filter);
+    for (commet_ctx::IngestBuf &b : c->ingest_pool) {
+        if (b.h_bases) (void) hipHostFree(b.h_bases);
+        if (b.h_offs) (void) hipHostFree(b.h_offs);
+        (void) hipFree(b.d_bases);
+        (void) hipFree(b.d_offs);
+        if (b.done) (void) hipEventDestroy(b.done);
+    }
     (void) hipFree(c->il_a);
     (void) hipFree(c->part_bufA);
     (void) hipFree(c->part_bufB);
@@ -628,6 +644,13 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
         maps.push_back(std::move(b));
     }
     const int T = ingest_threads();
+    const bool verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    const auto tv0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (verbose)
+            fprintf(stderr, "[ingest] %-18s %8.1f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
+    };
     // pieces
     std::vector<Piece> pieces;
     for (int f = 0; f < n_paths; ++f) {
@@ -669,7 +692,9 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
         for (std::thread &x : th) x.join();
     };
     // pass A: counts
+    lap("split");
     run_parallel([&](size_t i) { count_piece(pieces[i]); });
+    lap("count");
     uint64_t total_reads = 0, total_bases = 0;
     std::vector<uint64_t> file_reads(n_paths, 0);
     for (Piece &p : pieces) {
@@ -688,20 +713,32 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
             pos += file_reads[f];
         }
     }
+    lap("readset_create");
     // pass B: parse + upload, T workers with two pinned staging buffers each
     IngestShared sh;
     sh.rs = rs;
     const int nt = (int) std::min<size_t>((size_t) T, std::max<size_t>(pieces.size(), 1));
     std::vector<IngestStage> stages((size_t) nt * 2);
     bool ok = hipSetDevice(c->device) == hipSuccess;
-    for (IngestStage &st : stages) {
-        if (!ok) break;
-        ok = hipHostMalloc((void **) &st.h_bases, INGEST_STAGE_BASES) == hipSuccess &&
-             hipHostMalloc((void **) &st.h_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
-             hipMalloc((void **) &st.d_bases, INGEST_STAGE_BASES) == hipSuccess &&
-             hipMalloc((void **) &st.d_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
-             hipEventCreateWithFlags(&st.done, hipEventDisableTiming) == hipSuccess;
+    while (ok && c->ingest_pool.size() < stages.size()) {   // grow the context's pool of staging buffers
+        commet_ctx::IngestBuf b;
+        ok = hipHostMalloc((void **) &b.h_bases, INGEST_STAGE_BASES) == hipSuccess &&
+             hipHostMalloc((void **) &b.h_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
+             hipMalloc((void **) &b.d_bases, INGEST_STAGE_BASES) == hipSuccess &&
+             hipMalloc((void **) &b.d_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
+             hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+        c->ingest_pool.push_back(b);
     }
+    for (size_t i = 0; ok && i < stages.size(); ++i) {
+        const commet_ctx::IngestBuf &b = c->ingest_pool[i];
+        stages[i].h_bases = b.h_bases;
+        stages[i].h_offs = b.h_offs;
+        stages[i].d_bases = b.d_bases;
+        stages[i].d_offs = b.d_offs;
+        stages[i].done = b.done;
+        stages[i].inflight = false;
+    }
+    lap("staging alloc");
     if (ok) {
         std::atomic<size_t> next{0};
         std::vector<std::thread> th;
@@ -720,14 +757,9 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
         for (std::thread &x : th) x.join();
         ok = !sh.failed;
     }
+    lap("parse+upload");
     (void) hipStreamSynchronize(c->stream);
-    for (IngestStage &st : stages) {
-        if (st.h_bases) (void) hipHostFree(st.h_bases);
-        if (st.h_offs) (void) hipHostFree(st.h_offs);
-        (void) hipFree(st.d_bases);
-        (void) hipFree(st.d_offs);
-        if (st.done) (void) hipEventDestroy(st.done);
-    }
+    lap("stream sync");
     if (!ok) {
         fail("%s", sh.err.empty() ? "read set ingest failed" : sh.err.c_str());
         commet_readset_destroy(rs);

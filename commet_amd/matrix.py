@@ -181,22 +181,32 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     mine = [pairs[c] for c in sharding.assign_chains(pairs, ranks.world, ranks.rank, cost)]
     shared = {}                    # (from set, in set) -> reads of `from` found in `in`
     reads_searched = 0
+    prof = dict(jobs=0, call_ms=0.0, device_ms=0.0)      # library calls: wall time vs device time
+
+    def _acc(inf):
+        prof["jobs"] += 1
+        prof["call_ms"] += inf["total_ms"]
+        prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
+
     t_jobs = time.perf_counter()
     for ref in sorted({p[0] for p in mine}):
         targets = [i for (r, i) in mine if r == ref]
         w0 = time.perf_counter()
         tags1, st1, inf1 = ctx.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
         reads_searched += sum(considered[i] for i in targets)
+        _acc(inf1)
         for i, T1 in zip(targets, tags1):
             # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
             tags2, st2, inf2 = ctx.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
             T2 = tags2[0]
+            _acc(inf2)
             for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
                 write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
             _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
             shared[(ref, i)] = st2[0]["shared"]
             # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
             tags3, st3, inf3 = ctx.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
+            _acc(inf3)
             for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
                 write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
             _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
@@ -223,7 +233,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     slowest = ranks.max_seconds(jobs_s)
     total_searched = ranks.sum_int(reads_searched)
     if result is not None:
-        result.update(load_s=load_s, jobs_s=slowest, reads_searched=total_searched, world=ranks.world,
+        result.update(load_s=load_s, jobs_s=slowest, reads_searched=total_searched, world=ranks.world, rank0_profile=prof,
                       reads_per_s=total_searched / slowest if slowest > 0 else 0.0)
         say(f"{total_searched} reads searched in {slowest:.3f} s on {ranks.world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s")
     for rs in sets:
