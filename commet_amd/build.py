@@ -67,7 +67,7 @@ def build_tools(force=False):
             _run([hipcc(), "-O2", "-std=c++17", "-Wall", "-o", out, src, "-L" + PKG, "-lcommet_hip",
                   "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lz"])
         built.append(out)
-    for tool in ("bvop", "filter_reads"):
+    for tool in ("bvop", "filter_reads", "extract_reads"):
         src = os.path.join(host, tool + ".cpp")
         if not os.path.exists(src):
             continue
