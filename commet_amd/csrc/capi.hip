@@ -82,6 +82,7 @@ struct commet_ctx {
     int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
     int part_debug = 0;               // timing ablations of scatter1 (wrong results), tools only
     int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
+    int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
     int s2_swizzle = 0;               // scatter2 slab order: 1 = XCD-contiguous (measured 5 % slower: off)
     uint64_t part_min_kmers = 8ull << 20;
     // workspace of the bucketed construction (index_part.hpp)
@@ -901,22 +902,23 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         c->part_cap_keys = cap;
     }
     const bool wide = c->k > 32;
+    // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
+    const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;
     HIP_OK(hipMemsetAsync(c->part_hist, 0, (g.nb + 1) * sizeof(uint32_t), c->stream));
     // hist
     {
         const unsigned grid = (unsigned) std::min<uint64_t>(256, (count + HIST_NT - 1) / HIST_NT);
+        const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true> : (const void *) part_hist_kernel<uint64_t, false>)
+                              : (uni ? (const void *) part_hist_kernel<uint32_t, true> : (const void *) part_hist_kernel<uint32_t, false>);
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
             const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
-            HIP_OK(hipFuncSetAttribute(wide ? (const void *) part_hist_kernel<uint64_t> : (const void *) part_hist_kernel<uint32_t>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            if (wide)
-                hipLaunchKernelGGL(part_hist_kernel<uint64_t>, dim3(grid), dim3(HIST_NT), lds, c->stream, rs->view(), rs->d_kcnt,
-                                   d_sel, first, count, g, b_lo, n_b, c->part_hist);
-            else
-                hipLaunchKernelGGL(part_hist_kernel<uint32_t>, dim3(grid), dim3(HIST_NT), lds, c->stream, rs->view(), rs->d_kcnt,
-                                   d_sel, first, count, g, b_lo, n_b, c->part_hist);
-            HIP_OK(hipGetLastError());
+            HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            ReadsView rv = rs->view();
+            const uint32_t *kc = rs->d_kcnt;
+            uint32_t *hist = c->part_hist;
+            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist};
+            HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, c->stream));
         }
     }
     hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, zero_fill ? 1 : 0, c->part_off,
@@ -926,13 +928,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     uint32_t *level1_out = g.b2 ? c->part_bufA : c->part_bufB;
     {
         const unsigned grid = (unsigned) std::min<uint64_t>(512, (count + 63) / 64);
-        if (wide)
-            hipLaunchKernelGGL(part_scatter1_kernel<uint64_t>, dim3(grid), dim3(S1_NT), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
-                               first, count, g, c->part_cur1, level1_out);
-        else
-            hipLaunchKernelGGL(part_scatter1_kernel<uint32_t>, dim3(grid), dim3(S1_NT), 0, c->stream, rs->view(), rs->d_kcnt, d_sel,
-                               first, count, g, c->part_cur1, level1_out);
-        HIP_OK(hipGetLastError());
+        const void *fn = wide ? (uni ? (const void *) part_scatter1_kernel<uint64_t, true> : (const void *) part_scatter1_kernel<uint64_t, false>)
+                              : (uni ? (const void *) part_scatter1_kernel<uint32_t, true> : (const void *) part_scatter1_kernel<uint32_t, false>);
+        ReadsView rv = rs->view();
+        const uint32_t *kc = rs->d_kcnt;
+        unsigned long long *cur1 = c->part_cur1;
+        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &cur1, &level1_out};
+        HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(S1_NT), args, 0, c->stream));
     }
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
@@ -1262,7 +1264,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 e_zero1.push_back(z1);
             }
             if (ch.n_reads) {
-                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing)) { rc = 1; break; }
+                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, plan.dense ? nullptr : index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing)) { rc = 1; break; }
                 ++n_index_launches;
             }
         }
@@ -1389,6 +1391,10 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "part_debug")) {
         c->part_debug = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "part_no_uni")) {
+        c->part_no_uni = value != 0;
         return 0;
     }
     if (!strcmp(name, "part_b1")) {

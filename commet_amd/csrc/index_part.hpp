@@ -286,7 +286,10 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
 // ---------------------------------------------------------------------------
 // hist: bucket histogram of the chunk, buckets [b_lo, b_lo + n_b) in LDS
 // ---------------------------------------------------------------------------
-template <typename W>
+// UNI: every read has rv.uniform_len bases and no selection bitmap applies.  Item i of a block's read range is then
+// octet (i % opr) of read (i / opr) — no round planning, no barriers in the loop (reads without a complete k-mer just
+// yield no key).
+template <typename W, bool UNI>
 __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                             const uint64_t *__restrict__ sel, uint64_t first,
                                                             uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
@@ -305,20 +308,35 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
     uint64_t r = first + blockIdx.x * per;
     const uint64_t r_end = min(first + count, r + per);
-    while (r < r_end) {
-        const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, 0xFFFFFFFFu, g.k, istart, rd_len,
-                                            rd_t0, wsum, sh_n);
-        for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
-            uint32_t slot, q;
-            item_lookup(istart, rp.n_reads, id, g.k, slot, q);
-            for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, [&](uint32_t plane, W key) {
-                const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-                const uint32_t rel = b - b_lo;
-                if (rel < n_b) atomicAdd(&h[rel], 1u);
-            });
+    auto add = [&](uint32_t plane, W key) {
+        const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+        const uint32_t rel = b - b_lo;
+        if (rel < n_b) atomicAdd(&h[rel], 1u);
+    };
+    if (UNI) {
+        const uint32_t L = rv.uniform_len;
+        const uint32_t opr = max(octets_of(L, g.k), 1u), q_first = (uint32_t) (g.k - 1) >> 3;
+        const uint64_t total = (r < r_end && L >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
+        uint64_t rd = r + threadIdx.x / opr;
+        uint32_t q = threadIdx.x % opr;
+        const uint32_t dpos = NT / opr, dq = NT % opr;
+        for (uint64_t id = threadIdx.x; id < total; id += NT) {
+            for_each_key<W>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
+            rd += dpos, q += dq;
+            if (q >= opr) q -= opr, ++rd;
         }
-        __syncthreads();
-        r += rp.n_reads;
+    } else {
+        while (r < r_end) {
+            const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, 0xFFFFFFFFu, g.k, istart, rd_len,
+                                                rd_t0, wsum, sh_n);
+            for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
+                uint32_t slot, q;
+                item_lookup(istart, rp.n_reads, id, g.k, slot, q);
+                for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
+            }
+            __syncthreads();
+            r += rp.n_reads;
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_b; i += NT) {
@@ -392,7 +410,9 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
 // whichever comes first); for 32-bit keys the (keya, keyb) pairs are computed once and kept
 // in registers for both passes.
 // ---------------------------------------------------------------------------
-template <typename W>
+// UNI (see part_hist_kernel): items come from arithmetic instead of plan_round, and the read words of the NEXT round's
+// item are loaded right after this round's keys are made, so their latency hides behind the sort and the write-out.
+template <typename W, bool UNI>
 __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                               const uint64_t *__restrict__ sel, uint64_t first,
                                                               uint64_t count, PartGeom g,
@@ -405,8 +425,8 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
     __shared__ uint32_t sorted[S1_KEYS];
     __shared__ uint32_t cnt[MAX_L1], base[MAX_L1], fill[MAX_L1];
     __shared__ unsigned long long gbase[MAX_L1];
-    __shared__ uint32_t istart[NT + 4], rd_len[NT], wsum[16], sh_n[4];
-    __shared__ uint64_t rd_t0[NT];
+    __shared__ uint32_t istart[UNI ? 4 : NT + 4], rd_len[UNI ? 1 : NT], wsum[16], sh_n[4];
+    __shared__ uint64_t rd_t0[UNI ? 1 : NT];
     const uint32_t sub_mask = (1u << g.b2) - 1;
     const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
     uint64_t r = first + blockIdx.x * per;
@@ -414,62 +434,83 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const W mask = (g.k == T::BITS) ? ~(W) 0 : (((W) 1 << g.k) - 1);
     const int sh = T::BITS - g.k;
-    while (r < r_end) {
-        const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, S1_KEYS, S1_ITEMS, g.k, istart, rd_len, rd_t0,
-                                            wsum, sh_n);
+    // UNI: this thread's item of the coming round = octet u_q + q_first of read u_rd
+    const uint32_t q_first = (uint32_t) (g.k - 1) >> 3;
+    const uint32_t opr = UNI ? max(octets_of(rv.uniform_len, g.k), 1u) : 1u;
+    const uint64_t u_total = (UNI && r < r_end && rv.uniform_len >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
+    const uint32_t u_dpos = NT / opr, u_dq = NT % opr;
+    uint64_t u_done = 0, u_rd = r + threadIdx.x / opr;
+    uint32_t u_q = threadIdx.x % opr;
+    auto uni_ptr = [&](uint64_t rd) { return rv.planes + 3 * (((rd * rv.uniform_len) >> 5) + rd); };
+    ItemWords<W> pre;
+    if (UNI && CACHE && threadIdx.x < u_total) pre.load(uni_ptr(u_rd), (u_q + q_first) >> 2);
+    while (UNI ? u_done < u_total : r < r_end) {
+        RoundPlan rp;
+        rp.n_reads = 0, rp.n_items = 0;
+        if (!UNI) rp = plan_round<NT>(rv, kcnt, sel, r, r_end, S1_KEYS, S1_ITEMS, g.k, istart, rd_len, rd_t0, wsum, sh_n);
         if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
         __syncthreads();
-        // my item: id = tid
-        uint32_t cka[1][8], ckb[1][8], cpa[1][8], crk[1][16], cvalid[1] = {0};   // used when CACHE: keys, psi(keya), ranks
-        uint32_t islot[1], iq[1];
-        bool ion[1];
-#pragma unroll
-        for (int u = 0; u < 1; ++u) {
-            const uint32_t id = threadIdx.x + u * NT;
-            ion[u] = id < rp.n_items;
-            islot[u] = 0, iq[u] = 0;
-            if (ion[u]) item_lookup(istart, rp.n_reads, id, g.k, islot[u], iq[u]);
+        // my item of the round
+        uint32_t cka[8], ckb[8], cpa[8], crk[16], cvalid = 0;   // used when CACHE: keys, psi(keya), ranks
+        bool ion;
+        uint32_t iq = 0, ilen = 0;
+        const uint32_t *ip = rv.planes;
+        if (UNI) {
+            ion = u_done + threadIdx.x < u_total;
+            iq = u_q + q_first, ilen = rv.uniform_len;
+            if (ion) ip = uni_ptr(u_rd);
+        } else {
+            ion = threadIdx.x < rp.n_items;
+            if (ion) {
+                uint32_t slot;
+                item_lookup(istart, rp.n_reads, threadIdx.x, g.k, slot, iq);
+                ip = rv.planes + 3 * rd_t0[slot];
+                ilen = rd_len[slot];
+            }
         }
         // pass A: keys, count per coarse bucket
-#pragma unroll
-        for (int u = 0; u < 1; ++u) {
-            if (!ion[u]) continue;
-            const uint32_t *p = rv.planes + 3 * rd_t0[islot[u]];
-            const uint32_t len = rd_len[islot[u]];
+        if (ion) {
             if (CACHE) {
-                const uint32_t w = iq[u] >> 2, j0 = (iq[u] & 3u) * 8u;
+                const uint32_t w = iq >> 2, j0 = (iq & 3u) * 8u;
                 ItemWords<W> it;
-                it.load(p, w);
+                if (UNI) it = pre;
+                else it.load(ip, w);
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     const uint32_t j = j0 + jj, pos = 32u * w + j;
                     W wh = 0, wl = 0;
-                    const bool ok = (pos + 1u >= (uint32_t) g.k) && (pos < len) && it.window(j, g.k, mask, wh, wl);
+                    const bool ok = (pos + 1u >= (uint32_t) g.k) && (pos < ilen) && it.window(j, g.k, mask, wh, wl);
                     const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
-                    cka[u][jj] = (uint32_t) ka;
-                    ckb[u][jj] = (uint32_t) kb;
-                    crk[u][2 * jj] = crk[u][2 * jj + 1] = 0;
+                    cka[jj] = (uint32_t) ka;
+                    ckb[jj] = (uint32_t) kb;
+                    crk[2 * jj] = crk[2 * jj + 1] = 0;
                     if (ok) {
-                        cvalid[u] |= 1u << jj;
+                        cvalid |= 1u << jj;
                         const W kc = ka ^ kb, kd = ka | kb;
                         const W pa = psi_a<W>(ka, g.k);
-                        cpa[u][jj] = (uint32_t) pa;
+                        cpa[jj] = (uint32_t) pa;
                         if (g.debug & 4) continue;
                         // the returned value is the key's rank inside its coarse bucket for this round (< S1_KEYS <= 2^16)
                         const uint32_t r0 = atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (pa >> TILE_BITS)) >> g.b2], 1u);
                         const uint32_t r1 = atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
                         const uint32_t r2 = atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
                         const uint32_t r3 = atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
-                        crk[u][2 * jj] = r0 | (r1 << 16);
-                        crk[u][2 * jj + 1] = r2 | (r3 << 16);
+                        crk[2 * jj] = r0 | (r1 << 16);
+                        crk[2 * jj + 1] = r2 | (r3 << 16);
                     }
                 }
             } else {
-                for_each_key<W>(p, len, iq[u], g.k, [&](uint32_t plane, W key) {
+                for_each_key<W>(ip, ilen, iq, g.k, [&](uint32_t plane, W key) {
                     const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
                     atomicAdd(&cnt[b >> g.b2], 1u);
                 });
             }
+        }
+        if (UNI) {   // next round's item; its words travel while this round is sorted and written
+            u_done += NT;
+            u_rd += u_dpos, u_q += u_dq;
+            if (u_q >= opr) u_q -= opr, ++u_rd;
+            if (CACHE && u_done + threadIdx.x < u_total) pre.load(uni_ptr(u_rd), (u_q + q_first) >> 2);
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, g.nb1, wsum);
@@ -490,21 +531,19 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
             const uint32_t pos = base[c1] + atomicAdd(&fill[c1], 1u);
             if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
         };
-#pragma unroll
-        for (int u = 0; u < 1; ++u) {
-            if (!ion[u] || (g.debug & 2)) continue;
+        if (ion && !(g.debug & 2)) {
             if (CACHE) {
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
-                    if (!((cvalid[u] >> jj) & 1u)) continue;
-                    const W ka = cka[u][jj], kb = ckb[u][jj];
-                    place_ranked(0u, (W) cpa[u][jj], crk[u][2 * jj] & 0xFFFFu);
-                    place_ranked(1u, kb, crk[u][2 * jj] >> 16);
-                    place_ranked(2u, ka ^ kb, crk[u][2 * jj + 1] & 0xFFFFu);
-                    place_ranked(3u, ka | kb, crk[u][2 * jj + 1] >> 16);
+                    if (!((cvalid >> jj) & 1u)) continue;
+                    const W ka = cka[jj], kb = ckb[jj];
+                    place_ranked(0u, (W) cpa[jj], crk[2 * jj] & 0xFFFFu);
+                    place_ranked(1u, kb, crk[2 * jj] >> 16);
+                    place_ranked(2u, ka ^ kb, crk[2 * jj + 1] & 0xFFFFu);
+                    place_ranked(3u, ka | kb, crk[2 * jj + 1] >> 16);
                 }
             } else {
-                for_each_key<W>(rv.planes + 3 * rd_t0[islot[u]], rd_len[islot[u]], iq[u], g.k, place);
+                for_each_key<W>(ip, ilen, iq, g.k, place);
             }
         }
         __syncthreads();

@@ -187,6 +187,7 @@ struct IndexPlan {
     std::vector<uint8_t> indexed_bits;   // reads actually fed to a filter (selected, not dropped)
     uint64_t             indexed_reads = 0;
     uint64_t             kmers = 0;
+    bool                 dense = false;  // every read of every chunk's [first, last] is indexed (no selection inside a chunk)
 };
 
 // The chunk loop of main() (index_and_search.cpp:255-263) + index_reads
@@ -265,6 +266,7 @@ inline void build_kmer_prefix(const uint32_t *kcnt, uint64_t n_reads, std::vecto
 inline IndexPlan plan_index_fast(const std::vector<uint64_t> &prefix, uint64_t n_reads, uint64_t max_kmer)
 {
     IndexPlan plan;
+    plan.dense = true;   // the dropped look-ahead reads lie between the chunks
     plan.indexed_bits.assign(n_reads / 8 + 1, 0);
     for (uint64_t i = 0; i < n_reads / 8; ++i) plan.indexed_bits[i] = 0xFF;
     for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i) bit_on(plan.indexed_bits.data(), i);

@@ -211,6 +211,44 @@ def test_bucketed_index_matches_oracle(commet, k):
         rs.close()
 
 
+@pytest.mark.parametrize("k,L", [(20, 20), (21, 100), (24, 37), (26, 150), (28, 64), (32, 100), (33, 101), (34, 250)])
+def test_bucketed_index_uniform_length_fast_path(commet, k, L):
+    """reads of one length and no selection take the arithmetic item path of hist / scatter1 (index_part.hpp, UNI):
+    same filter as the planned path, the atomic kernel and the oracle; ranges that start / end anywhere"""
+    rng = np.random.default_rng(1000 * k + L)
+    reads = util.random_reads(rng, 20000, L, L, n_rate=0.01)
+    reads[7] = b"N" * L                                     # no k-mer at all
+    reads[8] = b"A" * L
+    reads += [b"A" * L] * 700 + [(b"ACGT" * L)[:L]] * 500   # hot buckets
+    bases, offs = util.to_batch(reads)
+    q = util.related_reads(rng, reads[:4000], 6000, L, L, share=0.5)
+    qb, qo = util.to_batch(q)
+    out = []
+    for mode, no_uni in ((2, 0), (2, 1), (1, 0)):
+        with commet.Context(k=k, t=2) as ctx:
+            ctx.set_option("index_mode", mode)
+            ctx.set_option("part_no_uni", no_uni)
+            rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+            qs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+            ctx.filter_reset()
+            fed = ctx.index_reads(rs, 3, len(reads) - 1004)
+            fed += ctx.index_reads(rs, len(reads) - 1000, 1000)        # additive second call; reads 0-2 and one more skipped
+            found, _, nfound = ctx.search_reads(qs)
+            out.append((fed, nfound, found, ctx.export_filter_reference() if k <= 28 else None))
+    for o in out[1:]:
+        assert o[0] == out[0][0] and o[1] == out[0][1]
+        assert np.array_equal(o[2], out[0][2])
+        if k <= 28:
+            assert np.array_equal(o[3], out[0][3])
+    if k <= 28:
+        sel = np.ones(len(reads), dtype=bool)
+        sel[:3] = False
+        sel[len(reads) - 1001] = False
+        f = ob.Bloom(k)
+        assert f.index(bases, offs, util.bits_from_bools(sel)) == out[0][0]
+        assert np.array_equal(out[0][3], f.bytes())
+
+
 @pytest.mark.parametrize("k", [30, 32, 33])
 def test_bucketed_index_equals_atomic_index_large_k(commet, k):
     """two-level radix geometry (k >= 26) incl. 64-bit keys; skewed input makes split tiles"""

@@ -19,13 +19,14 @@ def main():
     b0, o0 = synth.synth_set(0, n, L)
     b1, o1 = synth.synth_set(1, 1_000_000, L)
     res = {}
-    for mode in (2, 1):
+    for mode in (2, 3, 1):          # 2 = bucketed, 3 = bucketed without the uniform-length fast path, 1 = atomic
         with commet_amd.Context(k=k, t=2) as ctx:
-            ctx.set_option("index_mode", mode)
+            ctx.set_option("index_mode", min(mode, 2))
+            ctx.set_option("part_no_uni", int(mode == 3))
             rs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
             qs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
             times = []
-            for it in range(4 if mode == 2 else 2):
+            for it in range(4 if mode != 1 else 2):
                 ctx.filter_reset()
                 fed = ctx.index_reads(rs)
                 times.append(ctx.last_kernel_ms()[0])
@@ -35,9 +36,10 @@ def main():
                 res[mode] = res[mode] + (ctx.export_filter_reference(),)
             print(f"mode={mode} kmers={fed} index_ms={['%.2f' % t for t in times]} -> {fed * 4 / min(times) / 1e6:.2f} G keys/s; found={nf}",
                   flush=True)
-    assert res[1][0] == res[2][0] and res[1][1] == res[2][1] and np.array_equal(res[1][2], res[2][2]), "MISMATCH"
-    if len(res[1]) > 3:
-        assert np.array_equal(res[1][3], res[2][3]), "FILTER MISMATCH"
+    for m in (2, 3):
+        assert res[1][0] == res[m][0] and res[1][1] == res[m][1] and np.array_equal(res[1][2], res[m][2]), "MISMATCH"
+        if len(res[1]) > 3:
+            assert np.array_equal(res[1][3], res[m][3]), "FILTER MISMATCH"
     print("modes agree")
 
 
