@@ -145,6 +145,11 @@ class Context:
         self._check(self._lib.commet_membench(self._h, int(atomic), int(table_bytes), int(n_access), C.byref(ms)))
         return ms.value
 
+    def ldsbench(self, mode, n_words, n_access):
+        ms = C.c_double(0)
+        self._check(self._lib.commet_ldsbench(self._h, int(mode), int(n_words), int(n_access), C.byref(ms)))
+        return ms.value
+
 
 class ReadSet:
     """commet_readset: the reads of one set, packed and resident in HBM."""

@@ -936,6 +936,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &cur1, &level1_out};
         HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(S1_NT), args, 0, c->stream));
     }
+    if (g.debug) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
@@ -1484,6 +1485,39 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
     (void) hipFree(table);
+    (void) hipFree(sink);
+    return 0;
+}
+
+int commet_ldsbench(commet_ctx *c, int mode, uint32_t n_words, uint64_t n_access, double *ms_out)
+{
+    HIP_OK(hipSetDevice(c->device));
+    if (n_words == 0 || (n_words & (n_words - 1)) || n_words > 32768) return fail("ldsbench: n_words must be a power of two <= 32768");
+    if (mode < 0 || mode > 5) return fail("ldsbench: mode 0..5");
+    uint32_t *sink = nullptr;
+    HIP_OK(hipMalloc((void **) &sink, 4));
+    const uint64_t threads = 512ull * 256 * 8;   // 8 workgroups of 512 per CU (LDS permitting)
+    const uint32_t iters = (uint32_t) std::max<uint64_t>(1, n_access / threads);
+    const size_t lds = (size_t) n_words * 4;
+    const void *fns[6] = {(const void *) ldsbench_kernel<0>, (const void *) ldsbench_kernel<1>, (const void *) ldsbench_kernel<2>,
+                          (const void *) ldsbench_kernel<3>, (const void *) ldsbench_kernel<4>, (const void *) ldsbench_kernel<5>};
+    HIP_OK(hipFuncSetAttribute(fns[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {   // rep 0 warms up
+        HIP_OK(hipEventRecord(e0, c->stream));
+        uint32_t it = iters;
+        void *args[] = {&n_words, &it, &sink};
+        HIP_OK(hipLaunchKernel(fns[mode], dim3((unsigned) (threads / 512)), dim3(512), args, lds, c->stream));
+        HIP_OK(hipEventRecord(e1, c->stream));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / ((double) iters * threads) * (double) n_access;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
     (void) hipFree(sink);
     return 0;
 }

@@ -184,6 +184,14 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *wsum /* NT/
 template <int NT>
 __device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, uint32_t n, uint32_t *wsum)
 {
+    if (n <= (uint32_t) NT) {   // one counter per thread
+        const uint32_t v = threadIdx.x < n ? cnt[threadIdx.x] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan<NT>(v, wsum, &tot);
+        if (threadIdx.x < n) base[threadIdx.x] = ex;
+        __syncthreads();
+        return;
+    }
     const uint32_t per = (n + NT - 1) / NT;
     const uint32_t b = threadIdx.x * per;
     uint32_t s = 0;
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
 // UNI (see part_hist_kernel): items come from arithmetic instead of plan_round, and the read words of the NEXT round's
 // item are loaded right after this round's keys are made, so their latency hides behind the sort and the write-out.
 template <typename W, bool UNI>
-__global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
+__global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                               const uint64_t *__restrict__ sel, uint64_t first,
                                                               uint64_t count, PartGeom g,
                                                               unsigned long long *__restrict__ cursor1,
@@ -434,6 +442,9 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const W mask = (g.k == T::BITS) ? ~(W) 0 : (((W) 1 << g.k) - 1);
     const int sh = T::BITS - g.k;
+    // coarse bucket of a key of plane p = p * nbp + (key >> sA); payload = the key's low sA bits
+    // (= ((bucket & sub_mask) << TILE_BITS) | (key & TILE_MASK), the final-bucket bits sit right above the tile bits)
+    const uint32_t sA = TILE_BITS + g.b2, nbp = g.nb1 >> 2, pay_mask = (1u << sA) - 1u;
     // UNI: this thread's item of the coming round = octet u_q + q_first of read u_rd
     const uint32_t q_first = (uint32_t) (g.k - 1) >> 3;
     const uint32_t opr = UNI ? max(octets_of(rv.uniform_len, g.k), 1u) : 1u;
@@ -475,26 +486,25 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
                 ItemWords<W> it;
                 if (UNI) it = pre;
                 else it.load(ip, w);
+                uint32_t *const cnt_b = cnt + nbp, *const cnt_c = cnt + 2 * nbp, *const cnt_d = cnt + 3 * nbp;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     const uint32_t j = j0 + jj, pos = 32u * w + j;
                     W wh = 0, wl = 0;
-                    const bool ok = (pos + 1u >= (uint32_t) g.k) && (pos < ilen) && it.window(j, g.k, mask, wh, wl);
+                    const bool ok = it.window(j, g.k, mask, wh, wl) && (pos + 1u >= (uint32_t) g.k) && (pos < ilen);
                     const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                    const W pa = psi_a<W>(ka, g.k);
                     cka[jj] = (uint32_t) ka;
                     ckb[jj] = (uint32_t) kb;
-                    crk[2 * jj] = crk[2 * jj + 1] = 0;
-                    if (ok) {
+                    cpa[jj] = (uint32_t) pa;
+                    if (ok && !(g.debug & 4)) {   // crk[] of other positions is never read
+
                         cvalid |= 1u << jj;
-                        const W kc = ka ^ kb, kd = ka | kb;
-                        const W pa = psi_a<W>(ka, g.k);
-                        cpa[jj] = (uint32_t) pa;
-                        if (g.debug & 4) continue;
                         // the returned value is the key's rank inside its coarse bucket for this round (< S1_KEYS <= 2^16)
-                        const uint32_t r0 = atomicAdd(&cnt[((0u << g.plane_shift) | (uint32_t) (pa >> TILE_BITS)) >> g.b2], 1u);
-                        const uint32_t r1 = atomicAdd(&cnt[((1u << g.plane_shift) | (uint32_t) (kb >> TILE_BITS)) >> g.b2], 1u);
-                        const uint32_t r2 = atomicAdd(&cnt[((2u << g.plane_shift) | (uint32_t) (kc >> TILE_BITS)) >> g.b2], 1u);
-                        const uint32_t r3 = atomicAdd(&cnt[((3u << g.plane_shift) | (uint32_t) (kd >> TILE_BITS)) >> g.b2], 1u);
+                        const uint32_t r0 = atomicAdd(cnt + (uint32_t) (pa >> sA), 1u);
+                        const uint32_t r1 = atomicAdd(cnt_b + (uint32_t) (kb >> sA), 1u);
+                        const uint32_t r2 = atomicAdd(cnt_c + (uint32_t) ((ka ^ kb) >> sA), 1u);
+                        const uint32_t r3 = atomicAdd(cnt_d + (uint32_t) ((ka | kb) >> sA), 1u);
                         crk[2 * jj] = r0 | (r1 << 16);
                         crk[2 * jj + 1] = r2 | (r3 << 16);
                     }
@@ -520,11 +530,6 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
             else gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
         }
         // pass B: place (32-bit keys: the rank returned by pass A's counter; otherwise a second counter)
-        auto place_ranked = [&](uint32_t plane, W key, uint32_t rank) {
-            const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-            const uint32_t pos = base[b >> g.b2] + rank;
-            if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
-        };
         auto place = [&](uint32_t plane, W key) {
             const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
             const uint32_t c1 = b >> g.b2;
@@ -533,14 +538,20 @@ __global__ __launch_bounds__(S1_NT) void part_scatter1_kernel(ReadsView rv, cons
         };
         if (ion && !(g.debug & 2)) {
             if (CACHE) {
+                const uint32_t *const base_b = base + nbp, *const base_c = base + 2 * nbp, *const base_d = base + 3 * nbp;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     if (!((cvalid >> jj) & 1u)) continue;
-                    const W ka = cka[jj], kb = ckb[jj];
-                    place_ranked(0u, (W) cpa[jj], crk[2 * jj] & 0xFFFFu);
-                    place_ranked(1u, kb, crk[2 * jj] >> 16);
-                    place_ranked(2u, ka ^ kb, crk[2 * jj + 1] & 0xFFFFu);
-                    place_ranked(3u, ka | kb, crk[2 * jj + 1] >> 16);
+                    const uint32_t ka = cka[jj], kb = ckb[jj], pa = cpa[jj], kc = ka ^ kb, kd = ka | kb;
+                    const uint32_t p0 = base[pa >> sA] + (crk[2 * jj] & 0xFFFFu);
+                    const uint32_t p1 = base_b[kb >> sA] + (crk[2 * jj] >> 16);
+                    const uint32_t p2 = base_c[kc >> sA] + (crk[2 * jj + 1] & 0xFFFFu);
+                    const uint32_t p3 = base_d[kd >> sA] + (crk[2 * jj + 1] >> 16);
+                    // p < S1_KEYS: a round holds at most S1_ITEMS * 32 = S1_KEYS keys
+                    sorted[p0] = pa & pay_mask;
+                    sorted[p1] = kb & pay_mask;
+                    sorted[p2] = kc & pay_mask;
+                    sorted[p3] = kd & pay_mask;
                 }
             } else {
                 for_each_key<W>(ip, ilen, iq, g.k, place);

@@ -98,6 +98,7 @@ __device__ __forceinline__ void set_bit(uint32_t *plane, W key)
 template <typename W>
 __device__ __forceinline__ W psi_a(W key, int k, bool &self_paired)
 {
+    // branch-free: for s == 0 the general formula with b = 0 gives y = u, i.e. [0 | u] (even k)
     const int h = k >> 1;
     const bool odd = k & 1;
     const uint32_t hmask = (1u << h) - 1u;                     // h <= 19
@@ -106,18 +107,16 @@ __device__ __forceinline__ W psi_a(W key, int k, bool &self_paired)
     const uint32_t u = (uint32_t) (key >> (h + (odd ? 1 : 0))) & hmask;
     const uint32_t v = (~(__brev(L) >> (32 - h))) & hmask;     // g(L); h >= 1 for k >= 2
     const uint32_t s = u ^ v;
-    if (s == 0) {
-        self_paired = !odd;
-        return odd ? (W) ((u << 1) | m) : (W) u;
-    }
-    self_paired = false;
-    const uint32_t b = (uint32_t) __ffs((int) s) - 1u;
-    uint32_t y = u ^ (((u >> b) & 1u) ? (s & ~(1u << b)) : 0u);
+    self_paired = (s == 0) && !odd;
+    const uint32_t b = s ? (uint32_t) __ffs((int) s) - 1u : 0u;
+    uint32_t y = u ^ ((0u - ((u >> b) & 1u)) & s & ~(1u << b));
     const uint32_t d = ((y >> b) ^ y) & 1u;                    // swap bits 0 and b
     y ^= d | (d << b);
     if (odd) {
         const uint32_t m2 = m ^ (y & 1u);
-        return ((W) s << (h + 1)) | ((W) m2 << h) | (W) y;
+        const W nz = ((W) s << (h + 1)) | ((W) m2 << h) | (W) y;
+        const W z = (W) ((u << 1) | m);
+        return s ? nz : z;
     }
     return ((W) s << h) | (W) y;
 }
@@ -616,6 +615,31 @@ __global__ __launch_bounds__(256) void membench_kernel(uint32_t *__restrict__ ta
         else acc ^= table[idx];
     }
     if (MODE != 1 && acc == 0x12345678u) sink[0] = acc;   // keep the loads alive
+}
+
+// LDS microbenchmark: what one CU's LDS pipeline does per cycle for this path's access shapes (index_part.hpp).
+// MODE 0: atomic add, no return; 1: atomic add, rank returned; 2: atomic OR, no return; 3: plain store; 4: plain load;
+// 5: atomic add with return, conflict-free addresses (lane-private counters).  Addresses: uniform over n_words.
+template <int MODE>
+__global__ __launch_bounds__(512) void ldsbench_kernel(uint32_t n_words, uint32_t iters, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds_tab[];
+    for (uint32_t i = threadIdx.x; i < n_words; i += 512) lds_tab[i] = 0;
+    __syncthreads();
+    uint32_t x = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    const uint32_t m = n_words - 1;   // power of two
+    for (uint32_t i = 0; i < iters; ++i) {
+        x ^= x << 13, x ^= x >> 17, x ^= x << 5;   // xorshift32
+        uint32_t a = (x >> 7) & m;
+        if (MODE == 5) a = ((a & ~63u) | (threadIdx.x & 63u)) & m;
+        if (MODE == 0) atomicAdd(&lds_tab[a], 1u);
+        else if (MODE == 1 || MODE == 5) acc += atomicAdd(&lds_tab[a], 1u);
+        else if (MODE == 2) atomicOr(&lds_tab[a], 1u << (x & 31u));
+        else if (MODE == 3) lds_tab[a] = x;
+        else acc += lds_tab[a];
+    }
+    __syncthreads();
+    if (acc == 0x12345678u || lds_tab[threadIdx.x & m] == 0xFFFFFFFFu) sink[0] = acc;
 }
 
 }  // namespace commet

@@ -179,6 +179,12 @@ int commet_last_kernel_ms(commet_ctx *ctx, double *index_ms, double *search_ms);
  * accesses, returns elapsed device ms in *ms.  atomic: 0 plain gather, 1 atomic
  * OR, 2 non-temporal gather, 3 agent-scope (L1-bypassing) gather. */
 int commet_membench(commet_ctx *ctx, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms);
+/* LDS microbenchmark (what bounds the bucketed index construction): n_access
+ * operations on uniformly random words of an n_words-word LDS table (power of
+ * two, <= 32768) per workgroup of 512.  mode 0 atomic add, 1 atomic add with
+ * the old value used (rank), 2 atomic OR, 3 store, 4 load, 5 as 1 but on
+ * lane-private words (no two lanes share an address). */
+int commet_ldsbench(commet_ctx *ctx, int mode, uint32_t n_words, uint64_t n_access, double *ms);
 
 #ifdef __cplusplus
 }
