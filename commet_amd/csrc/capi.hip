@@ -90,7 +90,8 @@ struct commet_ctx {
     uint64_t part_cap_keys = 0;
     uint32_t *part_hist = nullptr, *part_wl = nullptr;
     uint64_t *part_off = nullptr;
-    unsigned long long *part_cur1 = nullptr, *part_cur2 = nullptr;
+    unsigned long long *part_cur2 = nullptr, *part_blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
+    uint32_t *part_blockcnt = nullptr;                                    // keys per [scatter1 workgroup][coarse bucket]
     uint32_t part_nb = 0;
 
     int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)
@@ -240,7 +241,8 @@ void commet_destroy(commet_ctx *c)
     (void) hipFree(c->part_hist);
     (void) hipFree(c->part_wl);
     (void) hipFree(c->part_off);
-    (void) hipFree(c->part_cur1);
+    (void) hipFree(c->part_blockcnt);
+    (void) hipFree(c->part_blockoff);
     (void) hipFree(c->part_cur2);
     if (c->d_counters) (void) hipFree(c->d_counters);
     if (c->h_counters) (void) hipHostFree(c->h_counters);
@@ -882,12 +884,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     const uint64_t total = 4 * kmers;
     if (c->part_nb != g.nb) {
         (void) hipFree(c->part_hist); (void) hipFree(c->part_wl); (void) hipFree(c->part_off);
-        (void) hipFree(c->part_cur1); (void) hipFree(c->part_cur2);
-        c->part_hist = c->part_wl = nullptr; c->part_off = nullptr; c->part_cur1 = c->part_cur2 = nullptr;
+        (void) hipFree(c->part_cur2);
+        c->part_hist = c->part_wl = nullptr; c->part_off = nullptr; c->part_cur2 = nullptr;
         HIP_OK(hipMalloc((void **) &c->part_hist, (g.nb + 1) * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &c->part_wl, (g.nb + 1) * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &c->part_off, (g.nb + 1) * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void **) &c->part_cur1, MAX_L1 * sizeof(unsigned long long)));
+        if (!c->part_blockcnt) HIP_OK(hipMalloc((void **) &c->part_blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t)));
+        if (!c->part_blockoff) HIP_OK(hipMalloc((void **) &c->part_blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long)));
         HIP_OK(hipMalloc((void **) &c->part_cur2, g.nb * sizeof(unsigned long long)));
         c->part_nb = g.nb;
     }
@@ -905,9 +908,10 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
     const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;
     HIP_OK(hipMemsetAsync(c->part_hist, 0, (g.nb + 1) * sizeof(uint32_t), c->stream));
-    // hist
+    // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
+    const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
     {
-        const unsigned grid = (unsigned) std::min<uint64_t>(256, (count + HIST_NT - 1) / HIST_NT);
+        const unsigned grid = (grid1 + 1) / 2;
         const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true> : (const void *) part_hist_kernel<uint64_t, false>)
                               : (uni ? (const void *) part_hist_kernel<uint32_t, true> : (const void *) part_hist_kernel<uint32_t, false>);
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
@@ -916,25 +920,28 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             ReadsView rv = rs->view();
             const uint32_t *kc = rs->d_kcnt;
-            uint32_t *hist = c->part_hist;
-            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist};
+            uint32_t *hist = c->part_hist, *bcnt = c->part_blockcnt;
+            uint32_t nblk = grid1;
+            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt};
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, c->stream));
         }
     }
     hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, zero_fill ? 1 : 0, c->part_off,
-                       c->part_cur1, c->part_cur2, c->part_wl);
+                       c->part_cur2, c->part_wl);
+    HIP_OK(hipGetLastError());
+    hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, c->stream, c->part_blockcnt, c->part_off, g, grid1,
+                       c->part_blockoff);
     HIP_OK(hipGetLastError());
     // scatter 1 (straight into the final buckets when there is a single level)
     uint32_t *level1_out = g.b2 ? c->part_bufA : c->part_bufB;
     {
-        const unsigned grid = (unsigned) std::min<uint64_t>(512, (count + 63) / 64);
         const void *fn = wide ? (uni ? (const void *) part_scatter1_kernel<uint64_t, true> : (const void *) part_scatter1_kernel<uint64_t, false>)
                               : (uni ? (const void *) part_scatter1_kernel<uint32_t, true> : (const void *) part_scatter1_kernel<uint32_t, false>);
         ReadsView rv = rs->view();
         const uint32_t *kc = rs->d_kcnt;
-        unsigned long long *cur1 = c->part_cur1;
-        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &cur1, &level1_out};
-        HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(S1_NT), args, 0, c->stream));
+        const unsigned long long *boff = c->part_blockoff;
+        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
+        HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, c->stream));
     }
     if (g.debug) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
     if (g.b2) {

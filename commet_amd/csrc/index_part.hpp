@@ -44,6 +44,7 @@ constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build wo
 constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
 constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
 constexpr uint32_t MAX_L1 = 256;                            // 2^b1 upper bound
+constexpr uint32_t S1_GRID_MAX = 512;                       // scatter-1 workgroups (two per CU: 70 KiB of LDS each)
 
 struct PartGeom {
     int      k;
@@ -53,7 +54,7 @@ struct PartGeom {
     uint32_t nb1;        // coarse buckets
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
     int      xcd_swizzle;   // scatter2: XCD-contiguous slab order (speed only)
-    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics, 8 no plan_round
+    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics
 };
 
 inline PartGeom make_geom(int k)
@@ -297,11 +298,16 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
 // UNI: every read has rv.uniform_len bases and no selection bitmap applies.  Item i of a block's read range is then
 // octet (i % opr) of read (i / opr) — no round planning, no barriers in the loop (reads without a complete k-mer just
 // yield no key).
+// The read range is cut exactly like scatter1 cuts it (n_blk1 workgroups of per1 = ceil(count / n_blk1) reads); one
+// hist workgroup takes the ranges of scatter1 workgroups 2b and 2b+1 one after the other and also leaves their
+// coarse-bucket counts in blockcnt[j * nb1 + c]: scatter1 then knows where each of its runs goes without reserving
+// space with global atomics (their round trip used to sit in every round).
 template <typename W, bool UNI>
 __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                             const uint64_t *__restrict__ sel, uint64_t first,
                                                             uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
-                                                            uint32_t *__restrict__ hist)
+                                                            uint32_t *__restrict__ hist, uint32_t n_blk1,
+                                                            uint32_t *__restrict__ blockcnt)
 {
     constexpr int NT = HIST_NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -313,40 +319,53 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     uint64_t *rd_t0 = (uint64_t *) (sh_n + 4);     // NT
     for (uint32_t i = threadIdx.x; i < n_b; i += NT) h[i] = 0;
     __syncthreads();
-    const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
-    uint64_t r = first + blockIdx.x * per;
-    const uint64_t r_end = min(first + count, r + per);
+    const uint64_t per1 = (count + n_blk1 - 1) / n_blk1;
+    const uint32_t nsub = 1u << g.b2, c_lo = b_lo >> g.b2, n_c = n_b >> g.b2;   // coarse buckets of this pass
+    uint32_t prev = 0;   // thread c < n_c: keys of coarse bucket c_lo + c counted before this half
     auto add = [&](uint32_t plane, W key) {
         const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
         const uint32_t rel = b - b_lo;
         if (rel < n_b) atomicAdd(&h[rel], 1u);
     };
-    if (UNI) {
-        const uint32_t L = rv.uniform_len;
-        const uint32_t opr = max(octets_of(L, g.k), 1u), q_first = (uint32_t) (g.k - 1) >> 3;
-        const uint64_t total = (r < r_end && L >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
-        uint64_t rd = r + threadIdx.x / opr;
-        uint32_t q = threadIdx.x % opr;
-        const uint32_t dpos = NT / opr, dq = NT % opr;
-        for (uint64_t id = threadIdx.x; id < total; id += NT) {
-            for_each_key<W>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
-            rd += dpos, q += dq;
-            if (q >= opr) q -= opr, ++rd;
-        }
-    } else {
-        while (r < r_end) {
-            const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, 0xFFFFFFFFu, g.k, istart, rd_len,
-                                                rd_t0, wsum, sh_n);
-            for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
-                uint32_t slot, q;
-                item_lookup(istart, rp.n_reads, id, g.k, slot, q);
-                for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
+    for (uint32_t half = 0; half < 2; ++half) {
+        const uint64_t j = 2ull * blockIdx.x + half;
+        if (j >= n_blk1) break;   // uniform
+        uint64_t r = min(first + count, first + j * per1);
+        const uint64_t r_end = min(first + count, r + per1);
+        if (UNI) {
+            const uint32_t L = rv.uniform_len;
+            const uint32_t opr = max(octets_of(L, g.k), 1u), q_first = (uint32_t) (g.k - 1) >> 3;
+            const uint64_t total = (r < r_end && L >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
+            uint64_t rd = r + threadIdx.x / opr;
+            uint32_t q = threadIdx.x % opr;
+            const uint32_t dpos = NT / opr, dq = NT % opr;
+            for (uint64_t id = threadIdx.x; id < total; id += NT) {
+                for_each_key<W>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
+                rd += dpos, q += dq;
+                if (q >= opr) q -= opr, ++rd;
             }
-            __syncthreads();
-            r += rp.n_reads;
+        } else {
+            while (r < r_end) {
+                const RoundPlan rp = plan_round<NT>(rv, kcnt, sel, r, r_end, 0xFFFFFFFFu, 0xFFFFFFFFu, g.k, istart, rd_len,
+                                                    rd_t0, wsum, sh_n);
+                for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
+                    uint32_t slot, q;
+                    item_lookup(istart, rp.n_reads, id, g.k, slot, q);
+                    for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
+                }
+                __syncthreads();
+                r += rp.n_reads;
+            }
         }
+        __syncthreads();
+        if (threadIdx.x < n_c) {   // coarse bucket = nsub consecutive final buckets; rotated start: no bank conflicts
+            uint32_t sum = 0;
+            for (uint32_t i = 0; i < nsub; ++i) sum += h[(threadIdx.x << g.b2) + ((i + threadIdx.x) & (nsub - 1))];
+            blockcnt[j * g.nb1 + c_lo + threadIdx.x] = sum - prev;
+            prev = sum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_b; i += NT) {
         const uint32_t v = h[i];
         if (v) atomicAdd(&hist[b_lo + i], v);
@@ -360,7 +379,6 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
 // as zeros) and part_zero_split_kernel clears the tiles that several workgroups will OR into.
 __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ hist, PartGeom g, int fill_empty,
                                                          uint64_t *__restrict__ off /* nb+1 */,
-                                                         unsigned long long *__restrict__ cursor1 /* nb1 */,
                                                          unsigned long long *__restrict__ cursor2 /* nb */,
                                                          uint32_t *__restrict__ wl_off /* nb+1 */)
 {
@@ -400,7 +418,6 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
             const uint32_t c = hist[b];
             off[b] = ex;
             cursor2[b] = ex;
-            if ((b & ((1u << g.b2) - 1)) == 0) cursor1[b >> g.b2] = ex;
             wl_off[b] = wex;
             ex += c;
             wex += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;
@@ -409,6 +426,26 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
         off[g.nb] = s_sum[1023];
         wl_off[g.nb] = s_wl[1023];
     }
+}
+
+// blockoff[j * nb1 + c] = where scatter1 workgroup j starts writing in coarse bucket c
+//                        = off[c << b2] + keys of c counted for workgroups 0 .. j-1.   One workgroup per c.
+__global__ __launch_bounds__(512) void part_blockoff_kernel(const uint32_t *__restrict__ blockcnt,
+                                                            const uint64_t *__restrict__ off, PartGeom g, uint32_t n_blk1,
+                                                            unsigned long long *__restrict__ blockoff)
+{
+    __shared__ uint64_t s_sum[512];
+    const uint32_t c = blockIdx.x;
+    const uint64_t v = threadIdx.x < n_blk1 ? blockcnt[(uint64_t) threadIdx.x * g.nb1 + c] : 0;   // n_blk1 <= 512
+    s_sum[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < 512; o <<= 1) {
+        const uint64_t a = threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (threadIdx.x < n_blk1) blockoff[(uint64_t) threadIdx.x * g.nb1 + c] = off[(uint64_t) c << g.b2] + (s_sum[threadIdx.x] - v);
 }
 
 // ---------------------------------------------------------------------------
@@ -424,7 +461,7 @@ template <typename W, bool UNI>
 __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                               const uint64_t *__restrict__ sel, uint64_t first,
                                                               uint64_t count, PartGeom g,
-                                                              unsigned long long *__restrict__ cursor1,
+                                                              const unsigned long long *__restrict__ blockoff,
                                                               uint32_t *__restrict__ out)
 {
     constexpr int NT = S1_NT;
@@ -432,16 +469,17 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     using T = KeyTraits<W>;
     __shared__ uint32_t sorted[S1_KEYS];
     __shared__ uint32_t cnt[MAX_L1], base[MAX_L1], fill[MAX_L1];
-    __shared__ unsigned long long gbase[MAX_L1];
+    __shared__ unsigned long long gbase[MAX_L1], gcur[MAX_L1];   // this round's / the next round's output position per coarse bucket
     __shared__ uint32_t istart[UNI ? 4 : NT + 4], rd_len[UNI ? 1 : NT], wsum[16], sh_n[4];
     __shared__ uint64_t rd_t0[UNI ? 1 : NT];
     const uint32_t sub_mask = (1u << g.b2) - 1;
-    const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
-    uint64_t r = first + blockIdx.x * per;
+    const uint64_t per = (count + gridDim.x - 1) / gridDim.x;   // the cut part_hist_kernel counted with
+    uint64_t r = min(first + count, first + blockIdx.x * per);
     const uint64_t r_end = min(first + count, r + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const W mask = (g.k == T::BITS) ? ~(W) 0 : (((W) 1 << g.k) - 1);
     const int sh = T::BITS - g.k;
+    if (threadIdx.x < g.nb1) gcur[threadIdx.x] = blockoff[(uint64_t) blockIdx.x * g.nb1 + threadIdx.x];   // first use is behind a barrier
     // coarse bucket of a key of plane p = p * nbp + (key >> sA); payload = the key's low sA bits
     // (= ((bucket & sub_mask) << TILE_BITS) | (key & TILE_MASK), the final-bucket bits sit right above the tile bits)
     const uint32_t sA = TILE_BITS + g.b2, nbp = g.nb1 >> 2, pay_mask = (1u << sA) - 1u;
@@ -453,8 +491,28 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     uint64_t u_done = 0, u_rd = r + threadIdx.x / opr;
     uint32_t u_q = threadIdx.x % opr;
     auto uni_ptr = [&](uint64_t rd) { return rv.planes + 3 * (((rd * rv.uniform_len) >> 5) + rd); };
-    ItemWords<W> pre;
-    if (UNI && CACHE && threadIdx.x < u_total) pre.load(uni_ptr(u_rd), (u_q + q_first) >> 2);
+    // prefetched word triples w-1 and w of the coming item, RAW: no branch and no use between the loads and the claim
+    // below, so that they really stay in flight (triple w-1 is read as triple 0 when w == 0 and zeroed at use)
+    uint32_t pre[6] = {0, 0, 0, 0, 0, 0};
+    auto pre_load = [&](const uint32_t *p, uint32_t w) {
+        const uint32_t *q0 = p + 3 * (w ? w - 1 : 0), *q1 = p + 3 * w;
+        pre[0] = q0[0], pre[1] = q0[1], pre[2] = q0[2];
+        pre[3] = q1[0], pre[4] = q1[1], pre[5] = q1[2];
+    };
+    // vmcnt counts loads and stores in issue order, so a wait for these words that the compiler places behind the
+    // write-out would also wait for that round's stores to be acknowledged (their whole HBM latency, every round).
+    // Claiming the words right before the write-out costs nothing: the loads were issued half a round earlier and the
+    // only stores still in flight are the previous round's.
+    auto pre_claim = [&]() {
+        asm volatile("" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]));
+    };
+    // (threads without an item load the block's first triple instead: an unconditional load needs no register copies,
+    // which the compiler would otherwise park right behind the load together with a wait)
+    if (UNI && CACHE && u_total) {
+        const bool in = threadIdx.x < u_total;
+        pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
+        pre_claim();
+    }
     while (UNI ? u_done < u_total : r < r_end) {
         RoundPlan rp;
         rp.n_reads = 0, rp.n_items = 0;
@@ -484,8 +542,14 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             if (CACHE) {
                 const uint32_t w = iq >> 2, j0 = (iq & 3u) * 8u;
                 ItemWords<W> it;
-                if (UNI) it = pre;
-                else it.load(ip, w);
+                if (UNI) {
+                    if constexpr (CACHE) {
+                        it.hi[0] = w ? pre[0] : 0u, it.lo[0] = w ? pre[1] : 0u, it.va[0] = w ? pre[2] : 0u;
+                        it.hi[1] = pre[3], it.lo[1] = pre[4], it.va[1] = pre[5];
+                    }
+                } else {
+                    it.load(ip, w);
+                }
                 uint32_t *const cnt_b = cnt + nbp, *const cnt_c = cnt + 2 * nbp, *const cnt_d = cnt + 3 * nbp;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8; ++jj) {
@@ -520,14 +584,17 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             u_done += NT;
             u_rd += u_dpos, u_q += u_dq;
             if (u_q >= opr) u_q -= opr, ++u_rd;
-            if (CACHE && u_done + threadIdx.x < u_total) pre.load(uni_ptr(u_rd), (u_q + q_first) >> 2);
+            if (CACHE) {
+                const bool in = u_done + threadIdx.x < u_total;
+                pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
+            }
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, g.nb1, wsum);
-        if (threadIdx.x < g.nb1) {
-            const uint32_t c = cnt[threadIdx.x];
-            if (g.debug & 16) gbase[threadIdx.x] = cursor1[threadIdx.x];   // timing only: no reservation
-            else gbase[threadIdx.x] = c ? atomicAdd(&cursor1[threadIdx.x], (unsigned long long) c) : 0ull;
+        if (threadIdx.x < g.nb1) {   // exact positions: the hist pass counted this workgroup's keys per coarse bucket
+            const unsigned long long at = gcur[threadIdx.x];
+            gbase[threadIdx.x] = at;
+            gcur[threadIdx.x] = at + cnt[threadIdx.x];
         }
         // pass B: place (32-bit keys: the rank returned by pass A's counter; otherwise a second counter)
         auto place = [&](uint32_t plane, W key) {
@@ -558,6 +625,7 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             }
         }
         __syncthreads();
+        if (UNI && CACHE) pre_claim();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
         if (!(g.debug & 1))
         for (uint32_t c1 = wave * 4 + (lane >> 4); c1 < g.nb1; c1 += (NT / 64) * 4)
