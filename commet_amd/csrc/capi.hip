@@ -83,7 +83,7 @@ struct commet_ctx {
     int part_debug = 0;               // timing ablations of scatter1 (wrong results), tools only
     int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
     int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
-    int s2_swizzle = 0;               // scatter2 slab order: 1 = XCD-contiguous (measured 5 % slower: off)
+    int s2_swizzle = 128;             // scatter2 slab order: number of interleaved slab ranges (index_part.hpp), 0 = dispatch order
     uint64_t part_min_kmers = 8ull << 20;
     // workspace of the bucketed construction (index_part.hpp)
     uint32_t *part_bufA = nullptr, *part_bufB = nullptr;
@@ -912,8 +912,12 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
     {
         const unsigned grid = (grid1 + 1) / 2;
-        const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true> : (const void *) part_hist_kernel<uint64_t, false>)
-                              : (uni ? (const void *) part_hist_kernel<uint32_t, true> : (const void *) part_hist_kernel<uint32_t, false>);
+        const bool full = g.nb <= HIST_MAX_BUCKETS;
+        const void *fns[8] = {(const void *) part_hist_kernel<uint32_t, false, false>, (const void *) part_hist_kernel<uint32_t, false, true>,
+                              (const void *) part_hist_kernel<uint32_t, true, false>,  (const void *) part_hist_kernel<uint32_t, true, true>,
+                              (const void *) part_hist_kernel<uint64_t, false, false>, (const void *) part_hist_kernel<uint64_t, false, true>,
+                              (const void *) part_hist_kernel<uint64_t, true, false>,  (const void *) part_hist_kernel<uint64_t, true, true>};
+        const void *fn = fns[(wide ? 4 : 0) + (uni ? 2 : 0) + (full ? 1 : 0)];
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
             const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
@@ -1410,7 +1414,7 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         return 0;
     }
     if (!strcmp(name, "s2_swizzle")) {
-        c->s2_swizzle = value != 0;
+        c->s2_swizzle = (int) std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
         return 0;
     }
     if (!strcmp(name, "part_min_kmers")) {    // auto mode: chunks with fewer k-mers use the atomic kernel

@@ -53,7 +53,7 @@ struct PartGeom {
     uint32_t nb;         // buckets
     uint32_t nb1;        // coarse buckets
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
-    int      xcd_swizzle;   // scatter2: XCD-contiguous slab order (speed only)
+    int      xcd_swizzle;   // scatter2: slab order, number of interleaved slab ranges (speed only)
     int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics
 };
 
@@ -302,7 +302,8 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
 // hist workgroup takes the ranges of scatter1 workgroups 2b and 2b+1 one after the other and also leaves their
 // coarse-bucket counts in blockcnt[j * nb1 + c]: scatter1 then knows where each of its runs goes without reserving
 // space with global atomics (their round trip used to sit in every round).
-template <typename W, bool UNI>
+// FULL: the LDS histogram covers every bucket (b_lo == 0, n_b == nb; always the case for k <= 32): no range test.
+template <typename W, bool UNI, bool FULL>
 __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                             const uint64_t *__restrict__ sel, uint64_t first,
                                                             uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
@@ -323,9 +324,13 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     const uint32_t nsub = 1u << g.b2, c_lo = b_lo >> g.b2, n_c = n_b >> g.b2;   // coarse buckets of this pass
     uint32_t prev = 0;   // thread c < n_c: keys of coarse bucket c_lo + c counted before this half
     auto add = [&](uint32_t plane, W key) {
-        const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-        const uint32_t rel = b - b_lo;
-        if (rel < n_b) atomicAdd(&h[rel], 1u);
+        if (FULL) {
+            atomicAdd(h + (plane << g.plane_shift) + (uint32_t) (key >> TILE_BITS), 1u);
+        } else {
+            const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
+            const uint32_t rel = b - b_lo;
+            if (rel < n_b) atomicAdd(&h[rel], 1u);
+        }
     };
     for (uint32_t half = 0; half < 2; ++half) {
         const uint64_t j = 2ull * blockIdx.x + half;
@@ -649,14 +654,17 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
     __shared__ unsigned long long gbase[MAX_SUB];
     __shared__ uint32_t wsum[16];
     const uint32_t nsub = 1u << g.b2;
-    // Optional XCD-aware slab order (option "s2_swizzle"): workgroups b, b+8, b+16, ... share an L2; giving each XCD a
-    // contiguous range of slabs keeps all writers of a final bucket's region behind one L2, which then merges the
-    // partial lines at run boundaries (WRITE_SIZE overhead 23 % -> 16 %).  Measured 5 % SLOWER in an interleaved A/B
-    // (15.6 vs 14.8 ms per 4.7e8 k-mers: the cursor atomics of one coarse bucket then all come from one XCD at the
-    // same time), so the default keeps the dispatch order.  Placement never affects results.
-    // Bijective for any grid size: XCD x owns q (+1 if x < rem) consecutive slabs starting at x*q + min(x, rem).
-    const uint32_t q8 = gridDim.x / 8u, rem8 = gridDim.x % 8u, xcd = blockIdx.x % 8u;
-    const uint64_t slab = g.xcd_swizzle ? (uint64_t) xcd * q8 + min(xcd, rem8) + blockIdx.x / 8u : (uint64_t) blockIdx.x;
+    // Slab order (option "s2_swizzle" = G, 0 = dispatch order): workgroups b with equal b % G walk one of G contiguous
+    // ranges of slabs, so the workgroups that run at the same time work on G different places of bufA, i.e. on
+    // different coarse buckets, instead of all reserving space through the same 2^b2 cursors.  G = 8 is the
+    // XCD-contiguous order (all writers of a final bucket behind one L2).  Placement never affects results.
+    // Bijective for any grid size: range x owns q (+1 if x < rem) slabs starting at x*q + min(x, rem).
+    const uint32_t G = (uint32_t) g.xcd_swizzle;
+    uint64_t slab = blockIdx.x;
+    if (G > 1) {
+        const uint32_t q = gridDim.x / G, rem = gridDim.x % G, x = blockIdx.x % G;
+        slab = (uint64_t) x * q + min(x, rem) + blockIdx.x / G;
+    }
     const uint64_t s0 = slab * S2_KEYS;
     if (s0 >= total) return;
     const uint64_t s1 = min(total, s0 + S2_KEYS);

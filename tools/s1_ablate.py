@@ -34,6 +34,9 @@ def main():
         ctx.set_option("index_mode", 2)
         rs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
         for dbg in DEBUGS:
+            if "S2_SWIZZLE" in os.environ:      # sweep scatter2's slab order instead of scatter1's ablations
+                ctx.set_option("s2_swizzle", dbg)
+                dbg = 0
             ctx.set_option("part_debug", dbg)
             for _ in range(REP):
                 ctx.filter_reset()
