@@ -1467,6 +1467,31 @@ int commet_last_kernel_ms(commet_ctx *c, double *index_ms, double *search_ms)
 int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms_out)
 {
     HIP_OK(hipSetDevice(c->device));
+    if (atomic == 4 || atomic == 5) {   // streaming ceilings: 4 = device-to-device copy of table_bytes, 5 = fill
+        uint8_t *a = nullptr, *b = nullptr;
+        HIP_OK(hipMalloc((void **) &a, table_bytes));
+        HIP_OK(hipMalloc((void **) &b, table_bytes));
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipMemsetAsync(a, 1, table_bytes, c->stream));
+        HIP_OK(hipMemsetAsync(b, 2, table_bytes, c->stream));
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_OK(hipEventRecord(e0, c->stream));
+            if (atomic == 4) HIP_OK(hipMemcpyAsync(b, a, table_bytes, hipMemcpyDeviceToDevice, c->stream));
+            else HIP_OK(hipMemsetAsync(b, 3, table_bytes, c->stream));
+            HIP_OK(hipEventRecord(e1, c->stream));
+        }
+        HIP_OK(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms_out) *ms_out = ms;
+        (void) hipEventDestroy(e0);
+        (void) hipEventDestroy(e1);
+        (void) hipFree(a);
+        (void) hipFree(b);
+        return 0;
+    }
     uint64_t words = 1;
     while (words * 2 * 4 <= table_bytes) words *= 2;   // power of two words
     uint32_t *table = nullptr, *sink = nullptr;

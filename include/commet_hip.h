@@ -177,7 +177,8 @@ int commet_last_kernel_ms(commet_ctx *ctx, double *index_ms, double *search_ms);
 /* Random 4-byte-gather / atomic-OR microbenchmarks over a table of
  * table_bytes (practical random-access ceilings): n_access
  * accesses, returns elapsed device ms in *ms.  atomic: 0 plain gather, 1 atomic
- * OR, 2 non-temporal gather, 3 agent-scope (L1-bypassing) gather. */
+ * OR, 2 non-temporal gather, 3 agent-scope (L1-bypassing) gather; 4 / 5 time a
+ * device-to-device copy / a fill of table_bytes instead (streaming ceilings). */
 int commet_membench(commet_ctx *ctx, int atomic, uint64_t table_bytes, uint64_t n_access, double *ms);
 /* LDS microbenchmark (what bounds the bucketed index construction): n_access
  * operations on uniformly random words of an n_words-word LDS table (power of
