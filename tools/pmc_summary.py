@@ -20,7 +20,7 @@ def short(name):
     n = name.replace("void ", "").replace("commet::", "")
     base = n.split("(")[0].split("<")[0]
     # the probe-counting instantiations (COUNT = true) only run in bench.py's untimed P_ref step
-    return base + "[count]" if ", true>(" in n else base
+    return base + "[count]" if base.startswith("search") and ", true>(" in n else base
 
 
 def main(d):
