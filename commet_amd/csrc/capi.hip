@@ -1183,6 +1183,15 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                             uint8_t *const *tags_out, commet_pair_stats *stats, commet_job_info *info)
 {
     const auto wall0 = std::chrono::steady_clock::now();
+    // host-side phase times of the call (COMMET_JOB_VERBOSE: one line per call on stderr)
+    static const bool job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
+    auto lap_t = wall0;
+    double ph_plan = 0, ph_upload = 0, ph_launch = 0, ph_wait = 0;
+    auto lap = [&](double &acc) {
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double, std::milli>(now - lap_t).count();
+        lap_t = now;
+    };
     if (!index_rs->finalized) return fail("index read set not finalized");
     if (index_rs->ctx != c) return fail("index read set belongs to another context");
     for (int s = 0; s < n_search; ++s) {
@@ -1198,7 +1207,22 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
     // host plan: chunks of the index set, visited reads of each search set
     const uint64_t max_kmer = commet_max_kmer(c);
-    const IndexPlan plan = plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
+    // a selection whose k-mers (summed on the device, where kcnt lives) fit one chunk needs no per-read planning
+    bool single = false;
+    uint64_t sel_kmers = 0;
+    if (max_kmer && index_rs->n_reads && plan_single_ok(index_rs->files, index_select, index_rs->empty_reads)) {
+        if (upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
+        HIP_OK(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(sum_selected_kcnt_kernel, dim3(1024), dim3(256), 0, c->stream, index_rs->d_kcnt, index_rs->d_sel,
+                           index_rs->n_reads, c->d_counters);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        sel_kmers = c->h_counters[0];
+        single = sel_kmers < max_kmer;
+    }
+    const IndexPlan plan = single ? plan_index_single(index_select, index_rs->n_reads, sel_kmers)
+                           : plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
                                ? plan_index_fast(index_rs->h_kprefix, index_rs->n_reads, max_kmer)
                            : (index_select && index_rs->empty_reads.empty())
                                ? plan_index_select(index_rs->files, index_select, index_rs->h_kcnt.data(), index_rs->n_reads, max_kmer)
@@ -1206,7 +1230,9 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                                             index_rs->n_reads, max_kmer);
     std::vector<uint64_t> visited(n_search, 0);
     std::vector<std::vector<uint8_t>> vis(n_search);
+    lap(ph_plan);
     if (upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
+    lap(ph_upload);
     for (int s = 0; s < n_search; ++s) {
         const commet_readset *rs = search_rs[s];
         const uint8_t *ssel = search_select ? search_select[s] : nullptr;
@@ -1214,10 +1240,13 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         vis[s] = plan_fast_ok(rs->files, ssel, rs->empty_reads, 1) ? plan_search_fast(rs->n_reads, &visited[s])
                  : (ssel && rs->empty_reads.empty())                ? plan_search_select(rs->files, ssel, rs->n_reads, &visited[s])
                                                                     : plan_search(rs->files, ssel, rs->empty_reads, rs->n_reads, &visited[s]);
+        lap(ph_plan);
         if (upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
         HIP_OK(hipMemsetAsync(rs->d_tags, 0, bitmap_words(rs->n_reads) * 8, c->stream));
+        lap(ph_upload);
     }
     HIP_OK(hipStreamSynchronize(c->stream));   // the host bit arrays above are pageable
+    lap(ph_upload);
 
     // per (chunk, set) counters {scanned, found}
     const uint64_t n_chunks = plan.chunks.size();
@@ -1311,6 +1340,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         ci += (uint64_t) g;
     }
     c->cur_slot = 0;
+    lap(ph_launch);
     if (!rc)
         if (hipMemcpyAsync(h_cnt.data(), d_cnt, n_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail("counter copy failed");
@@ -1321,6 +1351,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 rc = fail("tag copy failed");
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    lap(ph_wait);
 
     if (!rc) {
         uint64_t scans = 0;
@@ -1378,6 +1409,12 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     }
     for (hipEvent_t e : evs) (void) hipEventDestroy(e);
     if (d_cnt) (void) hipFree(d_cnt);
+    if (job_verbose) {
+        double ph_tail = 0;
+        lap(ph_tail);
+        fprintf(stderr, "[job] plan %.2f ms, bitmap upload %.2f ms, launches %.2f ms, wait + download %.2f ms, stats + cleanup %.2f ms\n",
+                ph_plan, ph_upload, ph_launch, ph_wait, ph_tail);
+    }
     if (info && !rc)
         info->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return rc;

@@ -173,6 +173,18 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restri
     atomicMax(&len_minmax[1], len);
 }
 
+// sum of kcnt[r] over the reads whose bit is set in sel (bitmap, 64 reads per word): the k-mers a selection would feed
+__global__ __launch_bounds__(256) void sum_selected_kcnt_kernel(const uint32_t *__restrict__ kcnt, const uint64_t *__restrict__ sel,
+                                                                uint64_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    const uint64_t stride = (uint64_t) gridDim.x * 256ull;
+    for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < n; r += stride)
+        if ((sel[r >> 6] >> (r & 63)) & 1ull) s += kcnt[r];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 // ---------------------------------------------------------------------------
 // index: one lane per read, rolling forward keys, 4 atomic ORs per k-mer.
 // Replaces index_reads.h:51-59 + BloomFilter::feed (bloom_filter.h:112-118).

@@ -34,7 +34,14 @@ inline uint64_t count_bits(const uint8_t *bits, uint64_t lo, uint64_t hi)
     uint64_t n = 0;
     while (lo < hi && (lo & 7)) n += bit_at(bits, lo++);
     while (hi > lo && (hi & 7)) n += bit_at(bits, --hi);
-    for (uint64_t b = lo >> 3; b < (hi >> 3); ++b) n += (uint64_t) __builtin_popcount(bits[b]);
+    uint64_t b = lo >> 3;
+    const uint64_t be = hi >> 3;
+    for (; b + 8 <= be; b += 8) {
+        uint64_t w;
+        __builtin_memcpy(&w, bits + b, 8);
+        n += (uint64_t) __builtin_popcountll(w);
+    }
+    for (; b < be; ++b) n += (uint64_t) __builtin_popcount(bits[b]);
     return n;
 }
 
@@ -428,6 +435,38 @@ inline IndexPlan plan_index_select(const std::vector<FileSpan> &files, const uin
         // the final end-marker(s): index_reads keeps being called while seen < total (never more than once here)
         while (!stop && (in_chunk || seen < to_index)) fetch(SetIterator::NONE);
     }
+    return plan;
+}
+
+// Plan of a selection that fits ONE chunk (fewer than max_kmer k-mers in all, known from the device sum), every file
+// holding a selected read and no empty sequence: the fetch stream is the selected reads in order plus the final
+// end-marker, the chunk never fills, so it is closed by that end-marker with every selected read in it
+// (== plan_index_select on the same input, tests/test_host_plan.py) — no per-read work on the host.
+inline bool plan_single_ok(const std::vector<FileSpan> &files, const uint8_t *select, const std::vector<uint64_t> &empty_reads)
+{
+    if (!select || !empty_reads.empty() || files.empty()) return false;
+    for (const FileSpan &f : files)
+        if (f.count == 0 || next_set_bit(select, f.first, f.first + f.count) >= f.first + f.count) return false;
+    return true;
+}
+
+inline IndexPlan plan_index_single(const uint8_t *select, uint64_t n_reads, uint64_t kmers)
+{
+    IndexPlan plan;
+    plan.indexed_bits.assign(n_reads / 8 + 1, 0);
+    __builtin_memcpy(plan.indexed_bits.data(), select, n_reads / 8);
+    for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i)
+        if (bit_at(select, i)) bit_on(plan.indexed_bits.data(), i);
+    Chunk ch;
+    ch.n_reads = count_bits(select, 0, n_reads);
+    ch.first = next_set_bit(select, 0, n_reads);
+    uint64_t last = n_reads;
+    while (last > 0 && !bit_at(select, last - 1)) --last;   // plan_single_ok: there is one
+    ch.last = last - 1;
+    ch.kmers = kmers;
+    plan.chunks.push_back(ch);
+    plan.indexed_reads = ch.n_reads;
+    plan.kmers = kmers;
     return plan;
 }
 
