@@ -85,14 +85,26 @@ struct commet_ctx {
     int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
     int s2_swizzle = 128;             // scatter2 slab order: number of interleaved slab ranges (index_part.hpp), 0 = dispatch order
     uint64_t part_min_kmers = 8ull << 20;
-    // workspace of the bucketed construction (index_part.hpp)
-    uint32_t *part_bufA = nullptr, *part_bufB = nullptr;
-    uint64_t part_cap_keys = 0;
-    uint32_t *part_hist = nullptr, *part_wl = nullptr;
-    uint64_t *part_off = nullptr;
-    unsigned long long *part_cur2 = nullptr, *part_blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
-    uint32_t *part_blockcnt = nullptr;                                    // keys per [scatter1 workgroup][coarse bucket]
-    uint32_t part_nb = 0;
+    // workspaces of the bucketed construction (index_part.hpp): two, so that the chunks of a group can be built on two
+    // streams at once (the compute-bound hist / scatter1 of one chunk overlap the HBM-bound scatter2 / build of another)
+    struct PartWs {
+        uint32_t *bufA = nullptr, *bufB = nullptr;
+        uint64_t cap_keys = 0;
+        uint32_t *hist = nullptr, *wl = nullptr;
+        uint64_t *off = nullptr;
+        unsigned long long *cur2 = nullptr, *blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
+        uint32_t *blockcnt = nullptr;                              // keys per [scatter1 workgroup][coarse bucket]
+        uint32_t nb = 0;
+        void release()
+        {
+            (void) hipFree(bufA); (void) hipFree(bufB); (void) hipFree(hist); (void) hipFree(wl); (void) hipFree(off);
+            (void) hipFree(cur2); (void) hipFree(blockoff); (void) hipFree(blockcnt);
+            *this = PartWs();
+        }
+    } part[2];
+    hipStream_t aux_stream = nullptr;         // second lane of a chunk group's index phase
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
 
     int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)
     int cur_slot = 0;                 // slot the index / search launch helpers work on
@@ -213,6 +225,9 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_i1);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_s0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_s1);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream);
     if (e != hipSuccess) {
         fail("context creation failed: %s", hipGetErrorString(e));
@@ -236,14 +251,11 @@ void commet_destroy(commet_ctx *c)
         if (b.done) (void) hipEventDestroy(b.done);
     }
     (void) hipFree(c->il_a);
-    (void) hipFree(c->part_bufA);
-    (void) hipFree(c->part_bufB);
-    (void) hipFree(c->part_hist);
-    (void) hipFree(c->part_wl);
-    (void) hipFree(c->part_off);
-    (void) hipFree(c->part_blockcnt);
-    (void) hipFree(c->part_blockoff);
-    (void) hipFree(c->part_cur2);
+    c->part[0].release();
+    c->part[1].release();
+    if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
+    if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void) hipEventDestroy(c->ev_join);
     if (c->d_counters) (void) hipFree(c->d_counters);
     if (c->h_counters) (void) hipHostFree(c->h_counters);
     if (c->ev_i0) (void) hipEventDestroy(c->ev_i0);
@@ -870,9 +882,12 @@ bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
 // filter must have been zeroed on the stream before.  kmers = exact number of
 // complete k-mers of the selected reads of [first, first+count).
 int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                             uint64_t kmers, bool additive, bool zero_fill)
+                             uint64_t kmers, bool additive, bool zero_fill, int lane = 0)
 {
     if (count == 0 || kmers == 0) return 0;
+    commet_ctx::PartWs &ws = c->part[lane];
+    hipStream_t stream = lane ? c->aux_stream : c->stream;
+    uint32_t *const slot = c->slot_ptr(c->cur_slot);
     PartGeom g = make_geom(c->k);
     g.xcd_swizzle = c->s2_swizzle;
     g.debug = c->part_debug;
@@ -882,32 +897,32 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         g.nb1 = 1u << g.b1;
     }
     const uint64_t total = 4 * kmers;
-    if (c->part_nb != g.nb) {
-        (void) hipFree(c->part_hist); (void) hipFree(c->part_wl); (void) hipFree(c->part_off);
-        (void) hipFree(c->part_cur2);
-        c->part_hist = c->part_wl = nullptr; c->part_off = nullptr; c->part_cur2 = nullptr;
-        HIP_OK(hipMalloc((void **) &c->part_hist, (g.nb + 1) * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &c->part_wl, (g.nb + 1) * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &c->part_off, (g.nb + 1) * sizeof(uint64_t)));
-        if (!c->part_blockcnt) HIP_OK(hipMalloc((void **) &c->part_blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t)));
-        if (!c->part_blockoff) HIP_OK(hipMalloc((void **) &c->part_blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long)));
-        HIP_OK(hipMalloc((void **) &c->part_cur2, g.nb * sizeof(unsigned long long)));
-        c->part_nb = g.nb;
+    if (ws.nb != g.nb) {
+        (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off);
+        (void) hipFree(ws.cur2);
+        ws.hist = ws.wl = nullptr; ws.off = nullptr; ws.cur2 = nullptr;
+        HIP_OK(hipMalloc((void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &ws.off, (g.nb + 1) * sizeof(uint64_t)));
+        if (!ws.blockcnt) HIP_OK(hipMalloc((void **) &ws.blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t)));
+        if (!ws.blockoff) HIP_OK(hipMalloc((void **) &ws.blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long)));
+        HIP_OK(hipMalloc((void **) &ws.cur2, g.nb * sizeof(unsigned long long)));
+        ws.nb = g.nb;
     }
-    if (c->part_cap_keys < total) {
-        HIP_OK(hipStreamSynchronize(c->stream));
-        (void) hipFree(c->part_bufA); (void) hipFree(c->part_bufB);
-        c->part_bufA = c->part_bufB = nullptr;
-        c->part_cap_keys = 0;
+    if (ws.cap_keys < total) {
+        HIP_OK(hipStreamSynchronize(stream));
+        (void) hipFree(ws.bufA); (void) hipFree(ws.bufB);
+        ws.bufA = ws.bufB = nullptr;
+        ws.cap_keys = 0;
         const uint64_t cap = total + total / 16 + 4096;
-        HIP_OK(hipMalloc((void **) &c->part_bufA, cap * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &c->part_bufB, cap * sizeof(uint32_t)));
-        c->part_cap_keys = cap;
+        HIP_OK(hipMalloc((void **) &ws.bufA, cap * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **) &ws.bufB, cap * sizeof(uint32_t)));
+        ws.cap_keys = cap;
     }
     const bool wide = c->k > 32;
     // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
     const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;
-    HIP_OK(hipMemsetAsync(c->part_hist, 0, (g.nb + 1) * sizeof(uint32_t), c->stream));
+    HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
     // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
     const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
     {
@@ -924,48 +939,48 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             ReadsView rv = rs->view();
             const uint32_t *kc = rs->d_kcnt;
-            uint32_t *hist = c->part_hist, *bcnt = c->part_blockcnt;
+            uint32_t *hist = ws.hist, *bcnt = ws.blockcnt;
             uint32_t nblk = grid1;
             void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt};
-            HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, c->stream));
+            HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
         }
     }
-    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->part_hist, g, zero_fill ? 1 : 0, c->part_off,
-                       c->part_cur2, c->part_wl);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
+                       ws.cur2, ws.wl);
     HIP_OK(hipGetLastError());
-    hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, c->stream, c->part_blockcnt, c->part_off, g, grid1,
-                       c->part_blockoff);
+    hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
+                       ws.blockoff);
     HIP_OK(hipGetLastError());
     // scatter 1 (straight into the final buckets when there is a single level)
-    uint32_t *level1_out = g.b2 ? c->part_bufA : c->part_bufB;
+    uint32_t *level1_out = g.b2 ? ws.bufA : ws.bufB;
     {
         const void *fn = wide ? (uni ? (const void *) part_scatter1_kernel<uint64_t, true> : (const void *) part_scatter1_kernel<uint64_t, false>)
                               : (uni ? (const void *) part_scatter1_kernel<uint32_t, true> : (const void *) part_scatter1_kernel<uint32_t, false>);
         ReadsView rv = rs->view();
         const uint32_t *kc = rs->d_kcnt;
-        const unsigned long long *boff = c->part_blockoff;
+        const unsigned long long *boff = ws.blockoff;
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
-        HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, c->stream));
+        HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
     }
     if (g.debug) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
-        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, c->stream, c->part_bufA, c->part_bufB,
-                           c->part_off, g, c->part_cur2, total);
+        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
+                           ws.off, g, ws.cur2, total);
         HIP_OK(hipGetLastError());
     }
     {
         const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
         if (grid >= (1ull << 24)) return fail("build launch too large");
         if (zero_fill) {   // no memset happened: clear the tiles that several workgroups OR into
-            hipLaunchKernelGGL(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, c->stream, c->part_wl, g, c->slot_ptr(c->cur_slot));
+            hipLaunchKernelGGL(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, stream, ws.wl, g, slot);
             HIP_OK(hipGetLastError());
         }
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
-        hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), c->stream,
-                           c->part_bufB, c->part_off, c->part_wl, g, c->slot_ptr(c->cur_slot), additive ? 1 : 0);
+        hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), stream,
+                           ws.bufB, ws.off, ws.wl, g, slot, additive ? 1 : 0);
         HIP_OK(hipGetLastError());
     }
     return 0;
@@ -984,7 +999,8 @@ bool would_partition(const commet_ctx *c, const commet_readset *rs, uint64_t kme
 // fresh_filter: the filter holds nothing yet; filter_zeroed: the caller has zeroed it (if not, a bucketed build
 // zero-fills what it does not set; the atomic kernel always needs a zeroed filter).
 int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false, bool filter_zeroed = true)
+                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false, bool filter_zeroed = true,
+                 int lane = 0)
 {
     if (c->index_mode == 2) {
         if (!partition_eligible(c, rs)) return fail("bucketed index construction needs 20 <= k <= 34 and reads of at most %u k-mers", S1_KEYS / 4);
@@ -1000,7 +1016,7 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
         HIP_OK(hipMemcpyAsync(d_fed, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
-    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed);
+    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed, lane);
 }
 
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
@@ -1288,6 +1304,19 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             if (new_event(&a) || new_event(&b)) { rc = 1; break; }
             (void) hipEventRecord(a, c->stream);
         }
+        // two lanes: when every chunk of the group takes the bucketed construction (which writes all of its filter
+        // slot itself), odd chunks are built on the second stream with the second workspace, beside the even ones
+        bool lanes = g > 1 && c->index_lanes > 1;
+        for (int i = 0; i < g && lanes; ++i) {
+            const Chunk &ch = plan.chunks[ci + i];
+            lanes = ch.n_reads && would_partition(c, index_rs, ch.kmers);
+        }
+        if (lanes) {   // the second stream starts behind everything issued so far (the previous group's searches read the slots)
+            if (hipEventRecord(c->ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0) != hipSuccess) {
+                rc = fail("stream fork failed");
+                break;
+            }
+        }
         for (int i = 0; i < g && !rc; ++i) {
             const Chunk &ch = plan.chunks[ci + i];
             c->cur_slot = i;
@@ -1305,9 +1334,14 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 e_zero1.push_back(z1);
             }
             if (ch.n_reads) {
-                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, plan.dense ? nullptr : index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing)) { rc = 1; break; }
+                if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, plan.dense ? nullptr : index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing,
+                                 lanes ? (i & 1) : 0)) { rc = 1; break; }
                 ++n_index_launches;
             }
+        }
+        if (lanes && !rc) {
+            if (hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess)
+                rc = fail("stream join failed");
         }
         if (rc) break;
         if (g > 1 && launch_interleave(c, g, gs)) { rc = 1; break; }
@@ -1440,6 +1474,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "part_debug")) {
         c->part_debug = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "index_lanes")) {       // 1 = the chunks of a group are built one after the other
+        if (value < 1 || value > 2) return fail("index_lanes must be 1 or 2");
+        c->index_lanes = (int) value;
         return 0;
     }
     if (!strcmp(name, "part_no_uni")) {
