@@ -102,6 +102,8 @@ struct commet_ctx {
             *this = PartWs();
         }
     } part[2];
+    unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
+    uint64_t jobcnt_cap = 0;
     hipStream_t aux_stream = nullptr;         // second lane of a chunk group's index phase
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
@@ -251,6 +253,7 @@ void commet_destroy(commet_ctx *c)
         if (b.done) (void) hipEventDestroy(b.done);
     }
     (void) hipFree(c->il_a);
+    (void) hipFree(c->d_jobcnt);
     c->part[0].release();
     c->part[1].release();
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
@@ -1246,18 +1249,22 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                                             index_rs->n_reads, max_kmer);
     std::vector<uint64_t> visited(n_search, 0);
     std::vector<std::vector<uint8_t>> vis(n_search);
+    std::vector<char> all_visited(n_search, 0);   // every read of the set is visited: the kernels take a null bitmap
     lap(ph_plan);
-    if (upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
+    // a dense plan indexes whole read ranges: no bitmap needed on the device
+    if (!plan.dense && upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
     lap(ph_upload);
     for (int s = 0; s < n_search; ++s) {
         const commet_readset *rs = search_rs[s];
         const uint8_t *ssel = search_select ? search_select[s] : nullptr;
         if (ssel && all_ones(ssel, rs->n_reads)) ssel = nullptr;
-        vis[s] = plan_fast_ok(rs->files, ssel, rs->empty_reads, 1) ? plan_search_fast(rs->n_reads, &visited[s])
-                 : (ssel && rs->empty_reads.empty())                ? plan_search_select(rs->files, ssel, rs->n_reads, &visited[s])
-                                                                    : plan_search(rs->files, ssel, rs->empty_reads, rs->n_reads, &visited[s]);
+        all_visited[s] = plan_fast_ok(rs->files, ssel, rs->empty_reads, 1);
+        if (all_visited[s]) visited[s] = rs->n_reads;   // == plan_search_fast, whose bitmap nobody would read
+        else
+            vis[s] = (ssel && rs->empty_reads.empty()) ? plan_search_select(rs->files, ssel, rs->n_reads, &visited[s])
+                                                       : plan_search(rs->files, ssel, rs->empty_reads, rs->n_reads, &visited[s]);
         lap(ph_plan);
-        if (upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
+        if (!all_visited[s] && upload_bits(c, rs->d_sel, vis[s].data(), rs->n_reads)) return 1;
         HIP_OK(hipMemsetAsync(rs->d_tags, 0, bitmap_words(rs->n_reads) * 8, c->stream));
         lap(ph_upload);
     }
@@ -1267,9 +1274,16 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     // per (chunk, set) counters {scanned, found}
     const uint64_t n_chunks = plan.chunks.size();
     const uint64_t n_cnt = 2 * n_chunks * (uint64_t) n_search + 1;   // last slot: probe counter
-    unsigned long long *d_cnt = nullptr;
     std::vector<unsigned long long> h_cnt(n_cnt, 0);
-    HIP_OK(hipMalloc((void **) &d_cnt, n_cnt * sizeof(unsigned long long)));
+    if (c->jobcnt_cap < n_cnt) {   // kept between calls: hipMalloc / hipFree per job cost more than the counters' kernels
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) hipFree(c->d_jobcnt);
+        c->d_jobcnt = nullptr;
+        c->jobcnt_cap = 0;
+        HIP_OK(hipMalloc((void **) &c->d_jobcnt, std::max<uint64_t>(n_cnt, 64) * sizeof(unsigned long long)));
+        c->jobcnt_cap = std::max<uint64_t>(n_cnt, 64);
+    }
+    unsigned long long *const d_cnt = c->d_jobcnt;
     HIP_OK(hipMemsetAsync(d_cnt, 0, n_cnt * sizeof(unsigned long long), c->stream));
 
     // device timing: one event pair around all index work and one around all
@@ -1354,12 +1368,12 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             const commet_readset *rs = search_rs[s];
             unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
             if (g > 1 && group_searchable(c, rs, g)) {
-                if (launch_search_group(c, rs, g, gs, rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
+                if (launch_search_group(c, rs, g, gs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
                     c->cur_slot = i;
-                    if (launch_search(c, rs, rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
+                    if (launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
                     if (rs->n_reads) ++n_search_launches;
                 }
             }
@@ -1442,7 +1456,6 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         }
     }
     for (hipEvent_t e : evs) (void) hipEventDestroy(e);
-    if (d_cnt) (void) hipFree(d_cnt);
     if (job_verbose) {
         double ph_tail = 0;
         lap(ph_tail);
