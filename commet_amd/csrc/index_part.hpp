@@ -128,7 +128,8 @@ __device__ __forceinline__ uint32_t octets_of(uint32_t len, int k)
 }
 
 // calls f(plane, key) for the 4 forward keys of every complete k-mer ending in octet q of the read at p
-template <typename W, typename F>
+// TOP: the plane-A key is only good for its bucket (psi_a_top)
+template <typename W, bool TOP = false, typename F>
 __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t q, int k, F &&f)
 {
     using T = KeyTraits<W>;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, ui
         if (!it.window(j, k, mask, wh, wl)) continue;
         const W ka = T::brev(wh) >> sh;
         const W kb = T::brev(wl) >> sh;
-        f(0u, psi_a<W>(ka, k));   // plane A is stored strand-paired (kernels.hpp)
+        f(0u, TOP ? psi_a_top<W>(ka, k) : psi_a<W>(ka, k));   // plane A is stored strand-paired (kernels.hpp)
         f(1u, kb);
         f(2u, ka ^ kb);
         f(3u, ka | kb);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
             uint32_t q = threadIdx.x % opr;
             const uint32_t dpos = NT / opr, dq = NT % opr;
             for (uint64_t id = threadIdx.x; id < total; id += NT) {
-                for_each_key<W>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
+                for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
                 rd += dpos, q += dq;
                 if (q >= opr) q -= opr, ++rd;
             }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
                 for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
                     uint32_t slot, q;
                     item_lookup(istart, rp.n_reads, id, g.k, slot, q);
-                    for_each_key<W>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
+                    for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
                 }
                 __syncthreads();
                 r += rp.n_reads;

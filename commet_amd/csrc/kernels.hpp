@@ -121,6 +121,20 @@ __device__ __forceinline__ W psi_a(W key, int k, bool &self_paired)
     return ((W) s << h) | (W) y;
 }
 
+// psi_a(key) with the bits below its s field cleared: s fills the address from bit h (+1 for odd k) upwards and
+// h (+1) <= TILE_BITS for every k the bucketed construction takes, so  psi_a_top(key) >> TILE_BITS == psi_a(key) >> TILE_BITS
+// — all a bucket count needs, at a quarter of the arithmetic.
+template <typename W>
+__device__ __forceinline__ W psi_a_top(W key, int k)
+{
+    const int h = k >> 1, odd = k & 1;
+    const uint32_t hmask = (1u << h) - 1u;
+    const uint32_t L = (uint32_t) key & hmask;
+    const uint32_t u = (uint32_t) (key >> (h + odd)) & hmask;
+    const uint32_t v = (~(__brev(L) >> (32 - h))) & hmask;
+    return (W) (u ^ v) << (h + odd);
+}
+
 template <typename W>
 __device__ __forceinline__ W psi_a(W key, int k)
 {
