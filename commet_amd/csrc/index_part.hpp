@@ -129,8 +129,9 @@ __device__ __forceinline__ uint32_t octets_of(uint32_t len, int k)
 
 // calls f(plane, key) for the 4 forward keys of every complete k-mer ending in octet q of the read at p
 // TOP: the plane-A key is only good for its bucket (psi_a_top)
+// planes: bit p set = plane p's key is wanted (a histogram pass over part of the buckets needs only some planes)
 template <typename W, bool TOP = false, typename F>
-__device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t q, int k, F &&f)
+__device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, uint32_t q, int k, F &&f, uint32_t planes = 15u)
 {
     using T = KeyTraits<W>;
     const uint32_t w = q >> 2;
@@ -148,10 +149,10 @@ __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, ui
         if (!it.window(j, k, mask, wh, wl)) continue;
         const W ka = T::brev(wh) >> sh;
         const W kb = T::brev(wl) >> sh;
-        f(0u, TOP ? psi_a_top<W>(ka, k) : psi_a<W>(ka, k));   // plane A is stored strand-paired (kernels.hpp)
-        f(1u, kb);
-        f(2u, ka ^ kb);
-        f(3u, ka | kb);
+        if (planes & 1u) f(0u, TOP ? psi_a_top<W>(ka, k) : psi_a<W>(ka, k));   // plane A is stored strand-paired (kernels.hpp)
+        if (planes & 2u) f(1u, kb);
+        if (planes & 4u) f(2u, ka ^ kb);
+        if (planes & 8u) f(3u, ka | kb);
     }
 }
 
@@ -324,6 +325,10 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     const uint64_t per1 = (count + n_blk1 - 1) / n_blk1;
     const uint32_t nsub = 1u << g.b2, c_lo = b_lo >> g.b2, n_c = n_b >> g.b2;   // coarse buckets of this pass
     uint32_t prev = 0;   // thread c < n_c: keys of coarse bucket c_lo + c counted before this half
+    uint32_t planes = 0;  // planes with buckets in [b_lo, b_lo + n_b)
+    for (uint32_t pl = 0; pl < 4; ++pl)
+        if (((pl + 1) << g.plane_shift) > b_lo && (pl << g.plane_shift) < b_lo + n_b) planes |= 1u << pl;
+    if (FULL) planes = 15u;
     auto add = [&](uint32_t plane, W key) {
         if (FULL) {
             atomicAdd(h + (plane << g.plane_shift) + (uint32_t) (key >> TILE_BITS), 1u);
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
             uint32_t q = threadIdx.x % opr;
             const uint32_t dpos = NT / opr, dq = NT % opr;
             for (uint64_t id = threadIdx.x; id < total; id += NT) {
-                for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add);
+                for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add, planes);
                 rd += dpos, q += dq;
                 if (q >= opr) q -= opr, ++rd;
             }
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
                 for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
                     uint32_t slot, q;
                     item_lookup(istart, rp.n_reads, id, g.k, slot, q);
-                    for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add);
+                    for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add, planes);
                 }
                 __syncthreads();
                 r += rp.n_reads;
@@ -471,14 +476,14 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
                                                               uint32_t *__restrict__ out)
 {
     constexpr int NT = S1_NT;
-    constexpr bool CACHE = sizeof(W) == 4;
+    constexpr bool WIDE = sizeof(W) == 8;          // 33 <= k <= 34: keys of 33 / 34 bits
+    constexpr uint32_t NTR = WIDE ? 3u : 2u;       // word triples a k-mer window can span
     using T = KeyTraits<W>;
     __shared__ uint32_t sorted[S1_KEYS];
-    __shared__ uint32_t cnt[MAX_L1], base[MAX_L1], fill[MAX_L1];
+    __shared__ uint32_t cnt[MAX_L1], base[MAX_L1];
     __shared__ unsigned long long gbase[MAX_L1], gcur[MAX_L1];   // this round's / the next round's output position per coarse bucket
     __shared__ uint32_t istart[UNI ? 4 : NT + 4], rd_len[UNI ? 1 : NT], wsum[16], sh_n[4];
     __shared__ uint64_t rd_t0[UNI ? 1 : NT];
-    const uint32_t sub_mask = (1u << g.b2) - 1;
     const uint64_t per = (count + gridDim.x - 1) / gridDim.x;   // the cut part_hist_kernel counted with
     uint64_t r = min(first + count, first + blockIdx.x * per);
     const uint64_t r_end = min(first + count, r + per);
@@ -487,7 +492,8 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     const int sh = T::BITS - g.k;
     if (threadIdx.x < g.nb1) gcur[threadIdx.x] = blockoff[(uint64_t) blockIdx.x * g.nb1 + threadIdx.x];   // first use is behind a barrier
     // coarse bucket of a key of plane p = p * nbp + (key >> sA); payload = the key's low sA bits
-    // (= ((bucket & sub_mask) << TILE_BITS) | (key & TILE_MASK), the final-bucket bits sit right above the tile bits)
+    // (= ((bucket & sub_mask) << TILE_BITS) | (key & TILE_MASK), the final-bucket bits sit right above the tile bits;
+    // sA = TILE_BITS + b2 <= 28, so the payload always comes from the key's low word)
     const uint32_t sA = TILE_BITS + g.b2, nbp = g.nb1 >> 2, pay_mask = (1u << sA) - 1u;
     // UNI: this thread's item of the coming round = octet u_q + q_first of read u_rd
     const uint32_t q_first = (uint32_t) (g.k - 1) >> 3;
@@ -497,24 +503,31 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     uint64_t u_done = 0, u_rd = r + threadIdx.x / opr;
     uint32_t u_q = threadIdx.x % opr;
     auto uni_ptr = [&](uint64_t rd) { return rv.planes + 3 * (((rd * rv.uniform_len) >> 5) + rd); };
-    // prefetched word triples w-1 and w of the coming item, RAW: no branch and no use between the loads and the claim
-    // below, so that they really stay in flight (triple w-1 is read as triple 0 when w == 0 and zeroed at use)
-    uint32_t pre[6] = {0, 0, 0, 0, 0, 0};
+    // prefetched word triples w-NTR+1 .. w of the coming item, RAW: no branch and no use between the loads and the
+    // claim below, so that they really stay in flight (a triple before the read's first is read as triple 0 and
+    // zeroed at use)
+    uint32_t pre[3 * NTR];
+#pragma unroll
+    for (uint32_t i = 0; i < 3 * NTR; ++i) pre[i] = 0;
     auto pre_load = [&](const uint32_t *p, uint32_t w) {
-        const uint32_t *q0 = p + 3 * (w ? w - 1 : 0), *q1 = p + 3 * w;
-        pre[0] = q0[0], pre[1] = q0[1], pre[2] = q0[2];
-        pre[3] = q1[0], pre[4] = q1[1], pre[5] = q1[2];
+#pragma unroll
+        for (uint32_t t = 0; t < NTR; ++t) {
+            const uint32_t back = NTR - 1 - t;
+            const uint32_t *q = p + 3 * (w >= back ? w - back : 0u);
+            pre[3 * t] = q[0], pre[3 * t + 1] = q[1], pre[3 * t + 2] = q[2];
+        }
     };
     // vmcnt counts loads and stores in issue order, so a wait for these words that the compiler places behind the
     // write-out would also wait for that round's stores to be acknowledged (their whole HBM latency, every round).
     // Claiming the words right before the write-out costs nothing: the loads were issued half a round earlier and the
     // only stores still in flight are the previous round's.
     auto pre_claim = [&]() {
-        asm volatile("" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]));
+#pragma unroll
+        for (uint32_t i = 0; i < 3 * NTR; ++i) asm volatile("" : "+v"(pre[i]));
     };
     // (threads without an item load the block's first triple instead: an unconditional load needs no register copies,
     // which the compiler would otherwise park right behind the load together with a wait)
-    if (UNI && CACHE && u_total) {
+    if (UNI && u_total) {
         const bool in = threadIdx.x < u_total;
         pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
         pre_claim();
@@ -523,17 +536,17 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         RoundPlan rp;
         rp.n_reads = 0, rp.n_items = 0;
         if (!UNI) rp = plan_round<NT>(rv, kcnt, sel, r, r_end, S1_KEYS, S1_ITEMS, g.k, istart, rd_len, rd_t0, wsum, sh_n);
-        if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0, fill[threadIdx.x] = 0;
+        if (threadIdx.x < g.nb1) cnt[threadIdx.x] = 0;
         __syncthreads();
-        // my item of the round
-        uint32_t cka[8], ckb[8], cpa[8], crk[16], cvalid = 0;   // used when CACHE: keys, psi(keya), ranks
+        // my item of the round: low words of keya, keyb, psi(keya) of its 8 positions, the bits above them (6 per
+        // position, wide keys only), the ranks from the counting pass (two per word), valid positions
+        uint32_t cka[8], ckb[8], cpa[8], crk[16], chi[2] = {0, 0}, cvalid = 0;
         bool ion;
         uint32_t iq = 0, ilen = 0;
         const uint32_t *ip = rv.planes;
         if (UNI) {
             ion = u_done + threadIdx.x < u_total;
             iq = u_q + q_first, ilen = rv.uniform_len;
-            if (ion) ip = uni_ptr(u_rd);
         } else {
             ion = threadIdx.x < rp.n_items;
             if (ion) {
@@ -543,57 +556,51 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
                 ilen = rd_len[slot];
             }
         }
-        // pass A: keys, count per coarse bucket
+        // pass A: keys, count per coarse bucket; the returned value is the key's rank inside its coarse bucket for
+        // this round (< S1_KEYS <= 2^16)
         if (ion) {
-            if (CACHE) {
-                const uint32_t w = iq >> 2, j0 = (iq & 3u) * 8u;
-                ItemWords<W> it;
-                if (UNI) {
-                    if constexpr (CACHE) {
-                        it.hi[0] = w ? pre[0] : 0u, it.lo[0] = w ? pre[1] : 0u, it.va[0] = w ? pre[2] : 0u;
-                        it.hi[1] = pre[3], it.lo[1] = pre[4], it.va[1] = pre[5];
-                    }
-                } else {
-                    it.load(ip, w);
-                }
-                uint32_t *const cnt_b = cnt + nbp, *const cnt_c = cnt + 2 * nbp, *const cnt_d = cnt + 3 * nbp;
+            const uint32_t w = iq >> 2, j0 = (iq & 3u) * 8u;
+            ItemWords<W> it;
+            if (UNI) {
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8; ++jj) {
-                    const uint32_t j = j0 + jj, pos = 32u * w + j;
-                    W wh = 0, wl = 0;
-                    const bool ok = it.window(j, g.k, mask, wh, wl) && (pos + 1u >= (uint32_t) g.k) && (pos < ilen);
-                    const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
-                    const W pa = psi_a<W>(ka, g.k);
-                    cka[jj] = (uint32_t) ka;
-                    ckb[jj] = (uint32_t) kb;
-                    cpa[jj] = (uint32_t) pa;
-                    if (ok && !(g.debug & 4)) {   // crk[] of other positions is never read
-
-                        cvalid |= 1u << jj;
-                        // the returned value is the key's rank inside its coarse bucket for this round (< S1_KEYS <= 2^16)
-                        const uint32_t r0 = atomicAdd(cnt + (uint32_t) (pa >> sA), 1u);
-                        const uint32_t r1 = atomicAdd(cnt_b + (uint32_t) (kb >> sA), 1u);
-                        const uint32_t r2 = atomicAdd(cnt_c + (uint32_t) ((ka ^ kb) >> sA), 1u);
-                        const uint32_t r3 = atomicAdd(cnt_d + (uint32_t) ((ka | kb) >> sA), 1u);
-                        crk[2 * jj] = r0 | (r1 << 16);
-                        crk[2 * jj + 1] = r2 | (r3 << 16);
-                    }
+                for (uint32_t t = 0; t < NTR; ++t) {
+                    const bool there = w >= NTR - 1 - t;
+                    it.hi[t] = there ? pre[3 * t] : 0u, it.lo[t] = there ? pre[3 * t + 1] : 0u, it.va[t] = there ? pre[3 * t + 2] : 0u;
                 }
             } else {
-                for_each_key<W>(ip, ilen, iq, g.k, [&](uint32_t plane, W key) {
-                    const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-                    atomicAdd(&cnt[b >> g.b2], 1u);
-                });
+                it.load(ip, w);
+            }
+            uint32_t *const cnt_b = cnt + nbp, *const cnt_c = cnt + 2 * nbp, *const cnt_d = cnt + 3 * nbp;
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8; ++jj) {
+                const uint32_t j = j0 + jj, pos = 32u * w + j;
+                W wh = 0, wl = 0;
+                const bool ok = it.window(j, g.k, mask, wh, wl) && (pos + 1u >= (uint32_t) g.k) && (pos < ilen);
+                const W ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                const W pa = psi_a<W>(ka, g.k);
+                cka[jj] = (uint32_t) ka;
+                ckb[jj] = (uint32_t) kb;
+                cpa[jj] = (uint32_t) pa;
+                if (WIDE)   // k <= 34: at most two bits above the low word
+                    chi[jj >> 2] |= ((uint32_t) ((uint64_t) ka >> 32) | ((uint32_t) ((uint64_t) kb >> 32) << 2) | ((uint32_t) ((uint64_t) pa >> 32) << 4))
+                                    << (6u * (jj & 3u));
+                if (ok && !(g.debug & 4)) {   // crk[] of other positions is never read
+                    cvalid |= 1u << jj;
+                    const uint32_t r0 = atomicAdd(cnt + (uint32_t) (pa >> sA), 1u);
+                    const uint32_t r1 = atomicAdd(cnt_b + (uint32_t) (kb >> sA), 1u);
+                    const uint32_t r2 = atomicAdd(cnt_c + (uint32_t) ((ka ^ kb) >> sA), 1u);
+                    const uint32_t r3 = atomicAdd(cnt_d + (uint32_t) ((ka | kb) >> sA), 1u);
+                    crk[2 * jj] = r0 | (r1 << 16);
+                    crk[2 * jj + 1] = r2 | (r3 << 16);
+                }
             }
         }
         if (UNI) {   // next round's item; its words travel while this round is sorted and written
             u_done += NT;
             u_rd += u_dpos, u_q += u_dq;
             if (u_q >= opr) u_q -= opr, ++u_rd;
-            if (CACHE) {
-                const bool in = u_done + threadIdx.x < u_total;
-                pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
-            }
+            const bool in = u_done + threadIdx.x < u_total;
+            pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, g.nb1, wsum);
@@ -602,36 +609,32 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             gbase[threadIdx.x] = at;
             gcur[threadIdx.x] = at + cnt[threadIdx.x];
         }
-        // pass B: place (32-bit keys: the rank returned by pass A's counter; otherwise a second counter)
-        auto place = [&](uint32_t plane, W key) {
-            const uint32_t b = (plane << g.plane_shift) | (uint32_t) (key >> TILE_BITS);
-            const uint32_t c1 = b >> g.b2;
-            const uint32_t pos = base[c1] + atomicAdd(&fill[c1], 1u);
-            if (pos < S1_KEYS) sorted[pos] = ((b & sub_mask) << TILE_BITS) | ((uint32_t) key & TILE_MASK);
-        };
+        // pass B: place every key at its bucket's base + its rank
         if (ion && !(g.debug & 2)) {
-            if (CACHE) {
-                const uint32_t *const base_b = base + nbp, *const base_c = base + 2 * nbp, *const base_d = base + 3 * nbp;
+            const uint32_t *const base_b = base + nbp, *const base_c = base + 2 * nbp, *const base_d = base + 3 * nbp;
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8; ++jj) {
-                    if (!((cvalid >> jj) & 1u)) continue;
-                    const uint32_t ka = cka[jj], kb = ckb[jj], pa = cpa[jj], kc = ka ^ kb, kd = ka | kb;
-                    const uint32_t p0 = base[pa >> sA] + (crk[2 * jj] & 0xFFFFu);
-                    const uint32_t p1 = base_b[kb >> sA] + (crk[2 * jj] >> 16);
-                    const uint32_t p2 = base_c[kc >> sA] + (crk[2 * jj + 1] & 0xFFFFu);
-                    const uint32_t p3 = base_d[kd >> sA] + (crk[2 * jj + 1] >> 16);
-                    // p < S1_KEYS: a round holds at most S1_ITEMS * 32 = S1_KEYS keys
-                    sorted[p0] = pa & pay_mask;
-                    sorted[p1] = kb & pay_mask;
-                    sorted[p2] = kc & pay_mask;
-                    sorted[p3] = kd & pay_mask;
+            for (uint32_t jj = 0; jj < 8; ++jj) {
+                if (!((cvalid >> jj) & 1u)) continue;
+                const uint32_t ka = cka[jj], kb = ckb[jj], pa = cpa[jj], kc = ka ^ kb, kd = ka | kb;
+                uint32_t i0 = pa >> sA, i1 = kb >> sA, i2 = kc >> sA, i3 = kd >> sA;
+                if (WIDE) {   // the bits above the low word belong to the bucket number
+                    const uint32_t h6 = chi[jj >> 2] >> (6u * (jj & 3u));
+                    const uint32_t ha = h6 & 3u, hb = (h6 >> 2) & 3u, hp = (h6 >> 4) & 3u, up = 32u - sA;
+                    i0 |= hp << up, i1 |= hb << up, i2 |= (ha ^ hb) << up, i3 |= (ha | hb) << up;
                 }
-            } else {
-                for_each_key<W>(ip, ilen, iq, g.k, place);
+                const uint32_t p0 = base[i0] + (crk[2 * jj] & 0xFFFFu);
+                const uint32_t p1 = base_b[i1] + (crk[2 * jj] >> 16);
+                const uint32_t p2 = base_c[i2] + (crk[2 * jj + 1] & 0xFFFFu);
+                const uint32_t p3 = base_d[i3] + (crk[2 * jj + 1] >> 16);
+                // p < S1_KEYS: a round holds at most S1_ITEMS * 32 = S1_KEYS keys
+                sorted[p0] = pa & pay_mask;
+                sorted[p1] = kb & pay_mask;
+                sorted[p2] = kc & pay_mask;
+                sorted[p3] = kd & pay_mask;
             }
         }
         __syncthreads();
-        if (UNI && CACHE) pre_claim();
+        if (UNI) pre_claim();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
         if (!(g.debug & 1))
         for (uint32_t c1 = wave * 4 + (lane >> 4); c1 < g.nb1; c1 += (NT / 64) * 4)
