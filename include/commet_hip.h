@@ -164,8 +164,15 @@ int commet_index_and_search(commet_ctx *ctx,
                             commet_job_info *info);
 
 /* ---- test / measurement hooks --------------------------------------------- */
-/* Tunables / diagnostics, by name.  "count_probes" (0/1): the search kernels
- * count the filter words they load.  Unknown names are an error. */
+/* Tunables / diagnostics, by name.  Unknown names are an error.  None of them changes a result bit.
+ *   count_probes (0/1)   the search kernels count the filter words the REFERENCE flow loads (P_ref)
+ *   index_mode (0/1/2)   0 auto, 1 atomic-OR kernel, 2 bucketed (LDS-tile) construction
+ *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
+ *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
+ *   chunk_group (1..4)   chunk filters searched per pass over a set (1 = the reference's order)
+ *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
+ *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
+ *   part_debug           timing ablations of scatter1 (tools/s1_ablate.py; leaves the filter unbuilt) */
 int commet_set_option(commet_ctx *ctx, const char *name, int64_t value);
 /* Copies the filter to the host in the REFERENCE byte layout (byte key/2,
  * even keys 0x80/40/20/10, odd keys 0x08/04/02/01 for a/b/c/d,
