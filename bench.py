@@ -180,6 +180,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr[0] if tr else None,
                     "traffic_source": tr[1] if tr else None,
+                    # as executed: measured HBM bytes of the launch over its measured duration, against the same peak
+                    "traffic_GBps": round(tr[0] / (kms / max(launches, 1) * 1e-3) / 1e9, 1) if tr and kms > 0 else None,
+                    "traffic_frac": round(tr[0] / (kms / max(launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and kms > 0 else None,
                     "launches_per_step": launches, "avg_launch_ms": round(kms / max(launches, 1), 3),
                     "algorithmic_bytes_per_launch": round(kbytes / max(launches, 1)),
                     "note": "algorithmic bytes = reference probes x 64-B sectors (SURVEY 8d); frac > 1 or traffic < algorithmic "
