@@ -103,6 +103,8 @@ struct commet_ctx {
         }
     } part[2];
     unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
+    unsigned long long *d_plansum = nullptr;  // per-block k-mer sums of a selection (host planner input)
+    uint64_t plansum_cap = 0;
     uint64_t jobcnt_cap = 0;
     hipStream_t aux_stream = nullptr;         // second lane of a chunk group's index phase
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -255,6 +257,7 @@ void commet_destroy(commet_ctx *c)
     }
     (void) hipFree(c->il_a);
     (void) hipFree(c->d_jobcnt);
+    (void) hipFree(c->d_plansum);
     c->part[0].release();
     c->part[1].release();
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
@@ -1227,21 +1230,28 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
     // host plan: chunks of the index set, visited reads of each search set
     const uint64_t max_kmer = commet_max_kmer(c);
-    // a selection whose k-mers (summed on the device, where kcnt lives) fit one chunk needs no per-read planning
-    bool single = false;
-    uint64_t sel_kmers = 0;
-    if (max_kmer && index_rs->n_reads && plan_single_ok(index_rs->files, index_select, index_rs->empty_reads)) {
+    // a selection is planned from per-block k-mer sums made on the device, where kcnt lives: no per-read loop on the host
+    std::vector<uint64_t> blk_sums;
+    if (index_rs->n_reads && plan_blocks_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)) {
+        const uint64_t nblk = (index_rs->n_reads + PLAN_BLOCK_READS - 1) / PLAN_BLOCK_READS;
+        if (c->plansum_cap < nblk) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void) hipFree(c->d_plansum);
+            c->d_plansum = nullptr;
+            c->plansum_cap = 0;
+            HIP_OK(hipMalloc((void **) &c->d_plansum, nblk * sizeof(unsigned long long)));
+            c->plansum_cap = nblk;
+        }
         if (upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
-        HIP_OK(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(sum_selected_kcnt_kernel, dim3(1024), dim3(256), 0, c->stream, index_rs->d_kcnt, index_rs->d_sel,
-                           index_rs->n_reads, c->d_counters);
+        hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt, index_rs->d_sel,
+                           index_rs->n_reads, c->d_plansum);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        blk_sums.resize(nblk);
+        HIP_OK(hipMemcpyAsync(blk_sums.data(), c->d_plansum, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
-        sel_kmers = c->h_counters[0];
-        single = sel_kmers < max_kmer;
     }
-    const IndexPlan plan = single ? plan_index_single(index_select, index_rs->n_reads, sel_kmers)
+    const IndexPlan plan = !blk_sums.empty() ? plan_index_blocks(index_select, index_rs->h_kcnt.data(), index_rs->n_reads, max_kmer,
+                                                                 blk_sums.data(), PLAN_BLOCK_READS)
                            : plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
                                ? plan_index_fast(index_rs->h_kprefix, index_rs->n_reads, max_kmer)
                            : (index_select && index_rs->empty_reads.empty())

@@ -23,11 +23,12 @@ uint64_t commet_plan_index(const uint64_t *files, int n_files, const uint8_t *se
     std::vector<uint64_t> er(empty_reads, empty_reads + n_empty);
     std::vector<uint64_t> prefix;
     IndexPlan plan;
-    if (fast == 2 && max_kmer && n_reads && plan_single_ok(fs, select, er)) {   // the library sums on the device
-        uint64_t sum = 0;
+    if (fast >= 2 && n_reads && plan_blocks_ok(fs, select, er, max_kmer)) {   // fast = 2 + log2(block size); the library sums on the device
+        const uint64_t bs = 1ull << (fast - 2);
+        std::vector<uint64_t> sums((n_reads + bs - 1) / bs, 0);
         for (uint64_t r = 0; r < n_reads; ++r)
-            if (bit_at(select, r)) sum += kcnt[r];
-        plan = sum < max_kmer ? plan_index_single(select, n_reads, sum) : plan_index_select(fs, select, kcnt, n_reads, max_kmer);
+            if (bit_at(select, r)) sums[r / bs] += kcnt[r];
+        plan = plan_index_blocks(select, kcnt, n_reads, max_kmer, sums.data(), bs);
     } else if (fast && plan_fast_ok(fs, select, er, max_kmer)) {
         build_kmer_prefix(kcnt, n_reads, prefix);
         plan = plan_index_fast(prefix, n_reads, max_kmer);

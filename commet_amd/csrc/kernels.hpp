@@ -187,16 +187,23 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restri
     atomicMax(&len_minmax[1], len);
 }
 
-// sum of kcnt[r] over the reads whose bit is set in sel (bitmap, 64 reads per word): the k-mers a selection would feed
-__global__ __launch_bounds__(256) void sum_selected_kcnt_kernel(const uint32_t *__restrict__ kcnt, const uint64_t *__restrict__ sel,
-                                                                uint64_t n, unsigned long long *__restrict__ out)
+// sums[b] = k-mers of the selected reads (bitmap sel, 64 reads per word) among reads [b * 4096, (b + 1) * 4096):
+// what the host's selection planner walks instead of the reads (read_iter.hpp, plan_index_blocks)
+constexpr uint32_t PLAN_BLOCK_READS = 4096;
+__global__ __launch_bounds__(256) void block_kmer_sums_kernel(const uint32_t *__restrict__ kcnt, const uint64_t *__restrict__ sel,
+                                                              uint64_t n, unsigned long long *__restrict__ sums)
 {
+    __shared__ unsigned long long part[4];
+    const uint64_t r0 = (uint64_t) blockIdx.x * PLAN_BLOCK_READS;
     unsigned long long s = 0;
-    const uint64_t stride = (uint64_t) gridDim.x * 256ull;
-    for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < n; r += stride)
-        if ((sel[r >> 6] >> (r & 63)) & 1ull) s += kcnt[r];
+    for (uint32_t i = threadIdx.x; i < PLAN_BLOCK_READS; i += 256) {
+        const uint64_t r = r0 + i;
+        if (r < n && ((sel[r >> 6] >> (r & 63)) & 1ull)) s += kcnt[r];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
 // ---------------------------------------------------------------------------

@@ -438,35 +438,67 @@ inline IndexPlan plan_index_select(const std::vector<FileSpan> &files, const uin
     return plan;
 }
 
-// Plan of a selection that fits ONE chunk (fewer than max_kmer k-mers in all, known from the device sum), every file
-// holding a selected read and no empty sequence: the fetch stream is the selected reads in order plus the final
-// end-marker, the chunk never fills, so it is closed by that end-marker with every selected read in it
-// (== plan_index_select on the same input, tests/test_host_plan.py) — no per-read work on the host.
-inline bool plan_single_ok(const std::vector<FileSpan> &files, const uint8_t *select, const std::vector<uint64_t> &empty_reads)
+// Plan of a selection when every file holds a selected read and there is no empty sequence: the fetch stream is the
+// selected reads in order plus the final end-marker, so file borders play no role and a chunk is "selected reads from
+// `first` on until their k-mers reach max_kmer; the next selected read is dropped" (index_reads.h:49-60).
+// block_sums[b] = k-mers of the selected reads among reads [b * bs, (b + 1) * bs) (summed on the device, where kcnt
+// lives): whole blocks are skipped, only the blocks in which a chunk starts or ends are walked read by read — no
+// per-read work over the set on the host (== plan_index_select on the same input, tests/test_host_plan.py).
+inline bool plan_blocks_ok(const std::vector<FileSpan> &files, const uint8_t *select, const std::vector<uint64_t> &empty_reads,
+                           uint64_t max_kmer)
 {
-    if (!select || !empty_reads.empty() || files.empty()) return false;
+    if (!select || !empty_reads.empty() || files.empty() || max_kmer == 0) return false;
     for (const FileSpan &f : files)
         if (f.count == 0 || next_set_bit(select, f.first, f.first + f.count) >= f.first + f.count) return false;
     return true;
 }
 
-inline IndexPlan plan_index_single(const uint8_t *select, uint64_t n_reads, uint64_t kmers)
+inline IndexPlan plan_index_blocks(const uint8_t *select, const uint32_t *kcnt, uint64_t n_reads, uint64_t max_kmer,
+                                   const uint64_t *block_sums, uint64_t bs)
 {
     IndexPlan plan;
     plan.indexed_bits.assign(n_reads / 8 + 1, 0);
     __builtin_memcpy(plan.indexed_bits.data(), select, n_reads / 8);
     for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i)
         if (bit_at(select, i)) bit_on(plan.indexed_bits.data(), i);
-    Chunk ch;
-    ch.n_reads = count_bits(select, 0, n_reads);
-    ch.first = next_set_bit(select, 0, n_reads);
-    uint64_t last = n_reads;
-    while (last > 0 && !bit_at(select, last - 1)) --last;   // plan_single_ok: there is one
-    ch.last = last - 1;
-    ch.kmers = kmers;
-    plan.chunks.push_back(ch);
-    plan.indexed_reads = ch.n_reads;
-    plan.kmers = kmers;
+    uint64_t pos = next_set_bit(select, 0, n_reads);   // first read of the chunk being opened
+    while (pos < n_reads) {
+        Chunk ch;
+        ch.first = pos;
+        bool full = false;
+        uint64_t r = pos;
+        while (r < n_reads && !full) {
+            const uint64_t blk = r / bs, blk_end = std::min(n_reads, (blk + 1) * bs);
+            if (r == blk * bs && ch.kmers + block_sums[blk] < max_kmer) {   // the whole block fits: its reads are not looked at
+                ch.kmers += block_sums[blk];
+                r = blk_end;
+                continue;
+            }
+            for (uint64_t q = next_set_bit(select, r, blk_end); q < blk_end; q = next_set_bit(select, q + 1, blk_end)) {
+                ch.kmers += kcnt[q];
+                if (ch.kmers >= max_kmer) {   // the chunk is full with read q in it
+                    full = true;
+                    ch.last = q;
+                    break;
+                }
+            }
+            r = blk_end;
+        }
+        if (!full) {   // everything up to the end of the set: the last selected read
+            uint64_t e = n_reads;
+            while (!bit_at(select, e - 1)) --e;   // ch.first is selected
+            ch.last = e - 1;
+        }
+        ch.n_reads = count_bits(select, ch.first, ch.last + 1);
+        plan.chunks.push_back(ch);
+        plan.indexed_reads += ch.n_reads;
+        plan.kmers += ch.kmers;
+        if (!full) break;                                                // closed by the final end-marker
+        const uint64_t d = next_set_bit(select, ch.last + 1, n_reads);   // the look-ahead read that closes a full chunk
+        if (d >= n_reads) break;
+        plan.indexed_bits[d >> 3] &= (uint8_t) ~(1u << (d & 7));         // fetched, never indexed
+        pos = next_set_bit(select, d + 1, n_reads);
+    }
     return plan;
 }
 

@@ -171,26 +171,30 @@ def test_selected_plans_equal_generic_plans(plan, seed):
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_single_chunk_selected_plan_equals_generic_plan(plan, seed):
-    """a selection whose k-mers fit one chunk (the library learns the sum from the device) is planned without
-    per-read work: same chunk, same indexed bits as the reference-shaped iterator; selections that do not qualify
-    (a file without a selected read, too many k-mers) take the other planners"""
+@pytest.mark.parametrize("seed", range(60))
+def test_block_sum_selected_plan_equals_generic_plan(plan, seed):
+    """selections are planned from per-block k-mer sums (the library gets them from the device) without per-read work
+    over the set: same chunks, same dropped reads, same indexed bits as the reference-shaped iterator, for one and for
+    many chunks, for every block size; selections that do not qualify (a file without a selected read) take the other
+    planners"""
     rng = np.random.default_rng(5000 + seed)
     nfiles = int(rng.integers(1, 5))
-    counts = [int(rng.integers(1, 300)) for _ in range(nfiles)]
+    counts = [int(rng.integers(1, 400)) for _ in range(nfiles)]
     n = sum(counts)
     kcnt = rng.integers(0, 90, size=n).astype(np.uint32)
     if seed % 4 == 0:
+        kcnt[rng.random(n) < 0.6] = 0
+    if seed % 7 == 0:
         kcnt[:] = 0
     sel = rng.random(n) < rng.uniform(0.02, 0.95)
     pos = 0
     for c in counts:                       # mostly every file keeps a selected read (the qualifying shape)
-        if not sel[pos:pos + c].any() and rng.random() < 0.8:
+        if not sel[pos:pos + c].any() and rng.random() < 0.85:
             sel[pos + int(rng.integers(0, c))] = True
         pos += c
     total = int(kcnt[sel].sum())
-    for max_kmer in (1, max(total, 1), total + 1, 10 ** 9):
+    for max_kmer in (1, 7, 60, 500, max(total, 1), total + 1, 10 ** 9):
         a = plan_index(plan, counts, sel, kcnt, max_kmer, fast=False)
-        b = plan_index(plan, counts, sel, kcnt, max_kmer, fast=2)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (seed, max_kmer)
+        for log_bs in (0, 2, 5, 12):
+            b = plan_index(plan, counts, sel, kcnt, max_kmer, fast=2 + log_bs)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (seed, max_kmer, log_bs)
