@@ -160,8 +160,9 @@ struct commet_readset {
     uint64_t stage_bases = 0, stage_reads = 0;
     std::vector<FileSpan> files;
     std::vector<uint64_t> empty_reads;
-    std::vector<uint32_t> h_kcnt;
-    std::vector<uint64_t> h_kprefix;   // prefix sums of h_kcnt (fast chunk planning)
+    mutable std::vector<uint32_t> h_kcnt;      // host copy of d_kcnt, made on first use (host_counts)
+    mutable std::vector<uint64_t> h_kprefix;   // prefix sums of h_kcnt (fast chunk planning)
+    mutable bool have_host_counts = false;
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
     uint32_t max_len = 0;
@@ -308,12 +309,12 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     hipError_t e = hipMalloc((void **) &rs->d_planes, triples * 3 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_goff, (max_reads + 1) * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_kcnt, (max_reads + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_lenmm, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_lenmm, 3 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_sel, bw * 8);
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_tags, bw * 8);
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_found, bw * 8);
     if (e == hipSuccess) {
-        const uint32_t mm[2] = {0xFFFFFFFFu, 0u};
+        const uint32_t mm[3] = {0xFFFFFFFFu, 0u, 0u};
         e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
@@ -798,6 +799,18 @@ uint64_t commet_readset_file_reads(const commet_readset *rs, uint64_t file_index
     return file_index < rs->files.size() ? rs->files[file_index].count : 0;
 }
 
+// host copy of the per-read k-mer counts + prefix sums, on first need (a set that is only searched never needs them)
+static int host_counts(const commet_readset *rs)
+{
+    if (rs->have_host_counts) return 0;
+    HIP_OK(hipSetDevice(rs->ctx->device));
+    rs->h_kcnt.resize(rs->n_reads);
+    if (rs->n_reads) HIP_OK(hipMemcpy(rs->h_kcnt.data(), rs->d_kcnt, rs->n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    build_kmer_prefix(rs->h_kcnt.data(), rs->n_reads, rs->h_kprefix);
+    rs->have_host_counts = true;
+    return 0;
+}
+
 int commet_readset_finalize(commet_readset *rs)
 {
     if (rs->finalized) return 0;
@@ -806,17 +819,13 @@ int commet_readset_finalize(commet_readset *rs)
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     rs->st[0].inflight = rs->st[1].inflight = false;
-    rs->h_kcnt.resize(rs->n_reads);
-    uint32_t mm[2] = {0, 0};
-    if (rs->n_reads) {
-        HIP_OK(hipMemcpy(rs->h_kcnt.data(), rs->d_kcnt, rs->n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
-    }
+    // shortest / longest read and largest k-mer count come from the packing kernel; the host copy of the per-read
+    // counts and their prefix sums (chunk planning) are made when the set is first used as an index set (host_counts)
+    uint32_t mm[3] = {0, 0, 0};
+    if (rs->n_reads) HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
     rs->max_len = rs->n_reads ? mm[1] : 0;
-    rs->max_kcnt = 0;
-    for (uint32_t v : rs->h_kcnt) rs->max_kcnt = std::max(rs->max_kcnt, v);
-    build_kmer_prefix(rs->h_kcnt.data(), rs->n_reads, rs->h_kprefix);
+    rs->max_kcnt = rs->n_reads ? mm[2] : 0;
     // the staging buffers are no longer needed: give the memory back
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
@@ -838,6 +847,7 @@ uint64_t commet_readset_num_files(const commet_readset *rs) { return rs->files.s
 int commet_readset_kmer_counts(const commet_readset *rs, uint32_t *out)
 {
     if (!rs->finalized) return fail("read set not finalized");
+    if (host_counts(rs)) return 1;
     if (rs->n_reads) memcpy(out, rs->h_kcnt.data(), rs->n_reads * sizeof(uint32_t));
     return 0;
 }
@@ -1159,6 +1169,7 @@ int commet_index_reads(commet_ctx *c, const commet_readset *rs, uint64_t first, 
     }
     HIP_OK(hipEventRecord(c->ev_i0, c->stream));
     // exact k-mer count of the launch (host copy of the per-read counts): lets the bucketed path run
+    if (host_counts(rs)) return 1;
     uint64_t kmers = 0;
     for (uint64_t r = first; r < first + count; ++r)
         if (!select_bits || bit_at(select_bits, r)) kmers += rs->h_kcnt[r];
@@ -1226,6 +1237,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     }
     HIP_OK(hipSetDevice(c->device));
 
+    if (host_counts(index_rs)) return 1;
     // an input filter that selects every read is no filter (Commet.py passes all-ones bvs when nothing was filtered)
     if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
     // host plan: chunks of the index set, visited reads of each search set

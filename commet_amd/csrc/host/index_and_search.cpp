@@ -13,7 +13,9 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -138,6 +140,11 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     }
     // set-wide select bits = the per-file filters, concatenated
     out.select.assign(out.n_reads / 8 + 1, 0);
+    if (!out.any_bv) {   // every read of every file: whole bytes at once
+        std::fill(out.select.begin(), out.select.begin() + out.n_reads / 8, (uint8_t) 0xFF);
+        for (uint64_t i = (out.n_reads / 8) * 8; i < out.n_reads; ++i) out.select[i >> 3] |= (uint8_t) (1u << (i & 7));
+        return;
+    }
     uint64_t pos = 0;
     for (const LoadedFile &lf : out.files) {
         for (uint64_t i = 0; i < lf.nb_reads; ++i)
@@ -218,8 +225,17 @@ int main(int argc, char **argv)
         exit(1);
     }
 
+    // COMMET_INGEST_VERBOSE: wall time of the tool's phases on stderr
+    const bool phase_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    auto phase_t = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (phase_verbose) fprintf(stderr, "[tool] %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - phase_t).count());
+        phase_t = now;
+    };
     const char *dev_env = getenv("COMMET_DEVICE");
     commet_ctx *ctx = commet_create(dev_env ? atoi(dev_env) : 0, kmer_size, min_hits);
+    phase("context (HIP start-up)");
     if (!ctx) {
         std::cerr << commet_last_error() << "\n";
         exit(1);
@@ -236,6 +252,7 @@ int main(int argc, char **argv)
         for (SetMap::iterator it = search_sets.begin(); it != search_sets.end() && s < searches.size(); ++it, ++s)
             load_set(ctx, it->first, it->second, searches[s]);
     }
+    phase("load sets");
     if (searches.empty()) {
         // the reference dereferences search_sets[0] here (index_and_search.cpp:247): undefined
         std::cerr << "Error: no set to search\n";
@@ -262,6 +279,7 @@ int main(int argc, char **argv)
         exit(1);
     }
 
+    phase("index_and_search");
     // per-chunk banners (index_and_search.cpp:267-269)
     for (uint64_t c = 0; c < info.n_chunks; ++c)
         for (int s = 0; s < ns; ++s) {
@@ -371,9 +389,13 @@ int main(int argc, char **argv)
 
     // save_bv (index_and_search.cpp:397-399)
     for (int s = 0; s < ns; ++s) save_bv(searches[s], tags[s], index_set.nickname);
+    phase("logs + .bv files");
 
+    // (ending the process without this teardown was tried: the driver then reclaims the memory while the next job's
+    // HIP start-up waits for it — same wall time per job)
     for (LoadedSet &ls : searches) commet_readset_destroy(ls.rs);
     commet_readset_destroy(index_set.rs);
     commet_destroy(ctx);
+    phase("teardown");
     return 0;
 }

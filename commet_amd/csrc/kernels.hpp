@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restri
     kcnt[read0 + i] = cnt;
     atomicMin(&len_minmax[0], len);
     atomicMax(&len_minmax[1], len);
+    atomicMax(&len_minmax[2], cnt);   // largest per-read k-mer count of the set
 }
 
 // sums[b] = k-mers of the selected reads (bitmap sel, 64 reads per word) among reads [b * 4096, (b + 1) * 4096):

@@ -23,7 +23,7 @@ def main():
             fh.write(f"set{s}: {work}/s{s}.fa\n")
     exe = os.path.join(HERE, "commet_amd", "bin", "index_and_search")
     env = dict(os.environ, COMMET_INGEST_VERBOSE="1")
-    for rep in range(3):
+    for rep in range(int(os.environ.get("CLI_REPS", "3"))):
         t0 = time.perf_counter()
         r = subprocess.run([exe, "-i", f"{work}/c0.txt", "-s", f"{work}/c1.txt", "-o", f"{work}/out", "-l", f"{work}/out", "-k", k, "-t", "2"],
                            capture_output=True, text=True, env=env)
