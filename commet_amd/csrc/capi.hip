@@ -82,6 +82,7 @@ struct commet_ctx {
     int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
     int part_debug = 0;               // timing ablations of scatter1 (wrong results), tools only
     int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
+    int part_packed = 1;              // option: final buckets as groups of three 19-bit keys in 8 bytes (index_part.hpp)
     int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
     int s2_swizzle = 128;             // scatter2 slab order: number of interleaved slab ranges (index_part.hpp), 0 = dispatch order
     uint64_t part_min_kmers = 8ull << 20;
@@ -91,13 +92,13 @@ struct commet_ctx {
         uint32_t *bufA = nullptr, *bufB = nullptr;
         uint64_t cap_keys = 0;
         uint32_t *hist = nullptr, *wl = nullptr;
-        uint64_t *off = nullptr;
+        uint64_t *off = nullptr, *goff = nullptr;   // bucket offsets in keys / in 8-byte groups (packed final level)
         unsigned long long *cur2 = nullptr, *blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
         uint32_t *blockcnt = nullptr;                              // keys per [scatter1 workgroup][coarse bucket]
         uint32_t nb = 0;
         void release()
         {
-            (void) hipFree(bufA); (void) hipFree(bufB); (void) hipFree(hist); (void) hipFree(wl); (void) hipFree(off);
+            (void) hipFree(bufA); (void) hipFree(bufB); (void) hipFree(hist); (void) hipFree(wl); (void) hipFree(off); (void) hipFree(goff);
             (void) hipFree(cur2); (void) hipFree(blockoff); (void) hipFree(blockcnt);
             *this = PartWs();
         }
@@ -908,19 +909,22 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     PartGeom g = make_geom(c->k);
     g.xcd_swizzle = c->s2_swizzle;
     g.debug = c->part_debug;
+    g.packed = c->part_packed;
     if (c->part_b1 > 0 && c->part_b1 < g.nb_bits && c->part_b1 <= 8 && g.nb_bits - c->part_b1 <= 9) {
         g.b1 = c->part_b1;
         g.b2 = g.nb_bits - g.b1;
         g.nb1 = 1u << g.b1;
     }
+    if (g.b2 == 0) g.packed = 0;   // single level: scatter1 writes the final buckets itself, as plain keys
     const uint64_t total = 4 * kmers;
     if (ws.nb != g.nb) {
-        (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off);
+        (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off); (void) hipFree(ws.goff);
         (void) hipFree(ws.cur2);
-        ws.hist = ws.wl = nullptr; ws.off = nullptr; ws.cur2 = nullptr;
+        ws.hist = ws.wl = nullptr; ws.off = ws.goff = nullptr; ws.cur2 = nullptr;
         HIP_OK(hipMalloc((void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &ws.off, (g.nb + 1) * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void **) &ws.goff, (g.nb + 1) * sizeof(uint64_t)));
         if (!ws.blockcnt) HIP_OK(hipMalloc((void **) &ws.blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t)));
         if (!ws.blockoff) HIP_OK(hipMalloc((void **) &ws.blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long)));
         HIP_OK(hipMalloc((void **) &ws.cur2, g.nb * sizeof(unsigned long long)));
@@ -931,7 +935,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         (void) hipFree(ws.bufA); (void) hipFree(ws.bufB);
         ws.bufA = ws.bufB = nullptr;
         ws.cap_keys = 0;
-        const uint64_t cap = total + total / 16 + 4096;
+        const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
         HIP_OK(hipMalloc((void **) &ws.bufA, cap * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &ws.bufB, cap * sizeof(uint32_t)));
         ws.cap_keys = cap;
@@ -963,7 +967,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         }
     }
     hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
-                       ws.cur2, ws.wl);
+                       ws.cur2, ws.wl, ws.goff);
     HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
                        ws.blockoff);
@@ -997,7 +1001,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
         hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), stream,
-                           ws.bufB, ws.off, ws.wl, g, slot, additive ? 1 : 0);
+                           ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
         HIP_OK(hipGetLastError());
     }
     return 0;
@@ -1515,6 +1519,10 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "index_lanes")) {       // 1 = the chunks of a group are built one after the other
         if (value < 1 || value > 2) return fail("index_lanes must be 1 or 2");
         c->index_lanes = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "part_packed")) {
+        c->part_packed = value != 0;
         return 0;
     }
     if (!strcmp(name, "part_no_uni")) {

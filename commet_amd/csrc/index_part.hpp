@@ -55,6 +55,7 @@ struct PartGeom {
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
     int      xcd_swizzle;   // scatter2: slab order, number of interleaved slab ranges (speed only)
     int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics
+    int      packed;        // final buckets hold groups of three 19-bit keys in 8 bytes (two-level geometry only)
 };
 
 inline PartGeom make_geom(int k)
@@ -70,6 +71,7 @@ inline PartGeom make_geom(int k)
     g.plane_shift = k - TILE_BITS;
     g.xcd_swizzle = 0;
     g.debug = 0;
+    g.packed = 0;
     return g;
 }
 
@@ -228,6 +230,20 @@ __device__ __forceinline__ void write_run(uint32_t *__restrict__ out, unsigned l
     }
     const uint32_t done = head + 4 * nvec;
     if (g < n - done) out[dst + done + g] = sorted[src + done + g];
+}
+
+// Packed form of write_run: the run's n keys (19 bits each) leave as ceil(n / 3) groups of 8 bytes, three keys per
+// group, the last key repeated to fill the last group (setting a bit twice is harmless).  Groups are 8-byte aligned by
+// construction, so there is no head / tail handling.  dst = group index.
+__device__ __forceinline__ void write_run_p3(uint2 *__restrict__ out, unsigned long long dst, const uint32_t *sorted, uint32_t src,
+                                             uint32_t n, uint32_t g, uint32_t G)
+{
+    const uint32_t ng = (n + 2) / 3;
+    for (uint32_t v = g; v < ng; v += G) {
+        const uint32_t i0 = 3 * v, i1 = min(i0 + 1, n - 1), i2 = min(i0 + 2, n - 1);
+        const uint32_t k0 = sorted[src + i0], k1 = sorted[src + i1], k2 = sorted[src + i2];
+        out[dst + v] = make_uint2(k0 | (k1 << 19), (k1 >> 13) | (k2 << 6));
+    }
 }
 
 // Picks the next reads [r, r + R) of a block's range whose keys fit `cap`
@@ -391,7 +407,8 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
 __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ hist, PartGeom g, int fill_empty,
                                                          uint64_t *__restrict__ off /* nb+1 */,
                                                          unsigned long long *__restrict__ cursor2 /* nb */,
-                                                         uint32_t *__restrict__ wl_off /* nb+1 */)
+                                                         uint32_t *__restrict__ wl_off /* nb+1 */,
+                                                         uint64_t *__restrict__ goff /* nb+1, packed geometry */)
 {
     __shared__ uint64_t s_sum[1024];
     __shared__ uint32_t s_wl[1024];
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
             const uint32_t b = b0 + i;
             const uint32_t c = hist[b];
             off[b] = ex;
-            cursor2[b] = ex;
+            if (!g.packed) cursor2[b] = ex;
             wl_off[b] = wex;
             ex += c;
             wex += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;
@@ -437,6 +454,40 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
         off[g.nb] = s_sum[1023];
         wl_off[g.nb] = s_wl[1023];
     }
+    if (!g.packed) return;
+    // Packed geometry: a final bucket is a sequence of 8-byte groups of three keys.  Every (slab piece, final bucket)
+    // run of scatter2 is rounded up to whole groups (its last key repeated), so a bucket of c keys that receives runs
+    // from P pieces needs at most c / 3 + P groups; P = the slabs of S2_KEYS keys that overlap its coarse bucket.
+    __syncthreads();   // off[] of the whole array is visible to the block
+    uint64_t gs = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < g.nb) {
+            const uint32_t b = b0 + i, c = hist[b];
+            const uint64_t lo = off[(uint64_t) (b >> g.b2) << g.b2], hi = off[(uint64_t) ((b >> g.b2) + 1) << g.b2];
+            const uint64_t pieces = hi > lo ? (hi - 1) / S2_KEYS - lo / S2_KEYS + 1 : 0;
+            gs += c ? c / 3 + pieces + 1 : 0;
+        }
+    const uint64_t mine = gs;
+    __syncthreads();
+    s_sum[threadIdx.x] = gs;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint64_t a = threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint64_t gex = s_sum[threadIdx.x] - mine;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < g.nb) {
+            const uint32_t b = b0 + i, c = hist[b];
+            const uint64_t lo = off[(uint64_t) (b >> g.b2) << g.b2], hi = off[(uint64_t) ((b >> g.b2) + 1) << g.b2];
+            const uint64_t pieces = hi > lo ? (hi - 1) / S2_KEYS - lo / S2_KEYS + 1 : 0;
+            goff[b] = gex;
+            cursor2[b] = gex;
+            gex += c ? c / 3 + pieces + 1 : 0;
+        }
+    if (threadIdx.x == 1023) goff[g.nb] = s_sum[1023];
 }
 
 // blockoff[j * nb1 + c] = where scatter1 workgroup j starts writing in coarse bucket c
@@ -707,7 +758,8 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
         lds_scan<NT>(cnt, base, nsub, wsum);
         for (uint32_t i = threadIdx.x; i < nsub; i += NT) {
             const uint32_t c = cnt[i];
-            gbase[i] = c ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], (unsigned long long) c) : 0ull;
+            const unsigned long long want = g.packed ? (c + 2) / 3 : c;   // packed: whole groups of three keys
+            gbase[i] = c ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
         }
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
@@ -718,8 +770,13 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
             }
         }
         __syncthreads();
-        for (uint32_t sb = wave * 4 + (lane >> 4); sb < nsub; sb += (NT / 64) * 4)
-            write_run(out, gbase[sb], sorted, base[sb], cnt[sb], lane & 15u, 16u);
+        if (g.packed) {
+            for (uint32_t sb = wave * 2 + (lane >> 5); sb < nsub; sb += (NT / 64) * 2)
+                write_run_p3((uint2 *) out, gbase[sb], sorted, base[sb], cnt[sb], lane & 31u, 32u);
+        } else {
+            for (uint32_t sb = wave * 4 + (lane >> 4); sb < nsub; sb += (NT / 64) * 4)
+                write_run(out, gbase[sb], sorted, base[sb], cnt[sb], lane & 15u, 16u);
+        }
         __syncthreads();
         pos = seg_end;
         if (pos >= c_end) ++c1;
@@ -739,10 +796,13 @@ __global__ __launch_bounds__(256) void part_zero_split_kernel(const uint32_t *__
 // ---------------------------------------------------------------------------
 // build: (tile, split) work items -> LDS tile -> filter
 // ---------------------------------------------------------------------------
+// packed geometry: off = goff (group offsets), gend = the final scatter2 cursors: bucket b's groups are
+// [off[b], gend[b]); its n_split workgroups take equal shares of them
 __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restrict__ keys,
                                                          const uint64_t *__restrict__ off,
                                                          const uint32_t *__restrict__ wl_off, PartGeom g,
-                                                         uint32_t *__restrict__ filter, int additive)
+                                                         uint32_t *__restrict__ filter, int additive,
+                                                         const unsigned long long *__restrict__ gend)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // TILE_WORDS
     const uint32_t total_items = wl_off[g.nb];
@@ -762,7 +822,24 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
     uint4 *t4 = (uint4 *) tile;
     for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) t4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    {
+    if (g.packed) {
+        const uint64_t g0 = off[b], gn = gend[b] - g0;            // groups of the bucket
+        const uint64_t share = (gn + n_split - 1) / n_split;
+        const uint64_t v0 = min(gn, (uint64_t) split * share), v1 = min(gn, v0 + share);
+        const uint2 *gv = (const uint2 *) keys + g0;
+        auto put = [&](uint2 x) {
+            const uint32_t a = x.x & TILE_MASK, bq = ((x.x >> 19) | (x.y << 13)) & TILE_MASK, cq = (x.y >> 6) & TILE_MASK;
+            atomicOr(&tile[a >> 5], 1u << (a & 31u));
+            atomicOr(&tile[bq >> 5], 1u << (bq & 31u));
+            atomicOr(&tile[cq >> 5], 1u << (cq & 31u));
+        };
+        uint64_t v = v0 + threadIdx.x;
+        for (; v + 768 < v1; v += 1024) {
+            const uint2 x0 = gv[v], x1 = gv[v + 256], x2 = gv[v + 512], x3 = gv[v + 768];
+            put(x0), put(x1), put(x2), put(x3);
+        }
+        for (; v < v1; v += 256) put(gv[v]);
+    } else {
         // head up to 16-byte alignment, then 4 keys per lane per load, 4 loads in flight
         uint64_t a0 = (k0 + 3) & ~3ull;
         if (a0 > k1) a0 = k1;

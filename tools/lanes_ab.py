@@ -1,4 +1,5 @@
-"""A/B of the two-lane index phase (option index_lanes) on the BASELINE configs[1] job:  python tools/lanes_ab.py [reads] [k]"""
+"""A/B of an option (default: the two-lane index phase, index_lanes=2,1) on the BASELINE configs[1] job:
+  [AB_OPTION=part_packed AB_VALUES=1,0] python tools/lanes_ab.py [reads] [k]"""
 import os
 import sys
 import time
@@ -6,6 +7,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import commet_amd  # noqa: E402
 from commet_amd import synth  # noqa: E402
+
+
+OPTION = os.environ.get("AB_OPTION", "index_lanes")
+VALUES = [int(x) for x in os.environ.get("AB_VALUES", "2,1").split(",")]
 
 
 def main():
@@ -18,14 +23,14 @@ def main():
         s1 = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
         ref = None
         for rep in range(3):
-            for lanes in (2, 1):
-                ctx.set_option("index_lanes", lanes)
+            for lanes in VALUES:
+                ctx.set_option(OPTION, lanes)
                 t0 = time.perf_counter()
                 tags, st, inf = ctx.index_and_search(s0, [s1])
                 wall = (time.perf_counter() - t0) * 1e3
                 ref = ref if ref is not None else tags[0].tobytes()
                 assert ref == tags[0].tobytes(), "lanes change results"
-                print(f"lanes={lanes}: chunks {inf['n_chunks']} index {inf['index_ms']:.2f} ms search {inf['search_ms']:.2f} ms "
+                print(f"{OPTION}={lanes}: chunks {inf['n_chunks']} index {inf['index_ms']:.2f} ms search {inf['search_ms']:.2f} ms "
                       f"call {wall:.2f} ms shared {st[0]['shared']}", flush=True)
 
 
