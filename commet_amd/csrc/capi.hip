@@ -966,8 +966,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
         }
     }
-    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
-                       ws.cur2, ws.wl, ws.goff);
+    {
+        const bool lds_hist = (size_t) g.nb * 4 <= (128u << 10);   // stage the histogram in LDS (coalesced loads) when it fits
+        const size_t lds = lds_hist ? (size_t) g.nb * 4 : 0;
+        if (lds) HIP_OK(hipFuncSetAttribute((const void *) part_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
+                           ws.cur2, ws.wl, ws.goff, lds_hist ? 1 : 0);
+    }
     HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
                        ws.blockoff);

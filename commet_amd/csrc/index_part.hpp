@@ -185,6 +185,30 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *wsum /* NT/
     return base + inc - v;
 }
 
+// the same for 64-bit values (bucket offsets); wsum: NT/64 uint64 of LDS
+template <int NT>
+__device__ __forceinline__ uint64_t block_scan64(uint64_t v, uint64_t *wsum, uint64_t *total)
+{
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t n = __shfl_up((unsigned long long) inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (int i = 0; i < NW; ++i) {
+        const uint64_t s = wsum[i];
+        if (i < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
 // exclusive scan of cnt[0..n) (n <= 1024) into base[]
 template <int NT>
 __device__ __forceinline__ void lds_scan(const uint32_t *cnt, uint32_t *base, uint32_t n, uint32_t *wsum)
@@ -408,86 +432,74 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
                                                          uint64_t *__restrict__ off /* nb+1 */,
                                                          unsigned long long *__restrict__ cursor2 /* nb */,
                                                          uint32_t *__restrict__ wl_off /* nb+1 */,
-                                                         uint64_t *__restrict__ goff /* nb+1, packed geometry */)
+                                                         uint64_t *__restrict__ goff /* nb+1, packed geometry */,
+                                                         int lds_hist /* nb * 4 bytes of dynamic LDS were given */)
 {
-    __shared__ uint64_t s_sum[1024];
-    __shared__ uint32_t s_wl[1024];
+    __shared__ uint64_t s_w64[16];
+    __shared__ uint32_t s_w32[16];
+    __shared__ uint64_t c_off[MAX_L1 + 1];               // key offsets of the coarse buckets
+    extern __shared__ uint32_t h_lds[];                   // the histogram, staged with coalesced loads when it fits (lds_hist)
+    const bool staged = lds_hist != 0;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < g.nb; i += 1024) h_lds[i] = hist[i];
+        __syncthreads();
+    }
+    auto count_of = [&](uint32_t b) { return staged ? h_lds[b] : hist[b]; };
     const uint32_t per = (g.nb + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
+    const uint32_t sub_mask = (1u << g.b2) - 1u;
     uint64_t s = 0;
     uint32_t wl = 0;
     for (uint32_t i = 0; i < per; ++i)
         if (b0 + i < g.nb) {
-            const uint32_t c = hist[b0 + i];
+            const uint32_t c = count_of(b0 + i);
             s += c;
             wl += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;   // empty buckets: no workgroup unless they must be zero-filled
         }
-    s_sum[threadIdx.x] = s;
-    s_wl[threadIdx.x] = wl;
-    __syncthreads();
-    // Hillis-Steele over 1024 partials
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint64_t a = 0;
-        uint32_t b = 0;
-        if (threadIdx.x >= o) {
-            a = s_sum[threadIdx.x - o];
-            b = s_wl[threadIdx.x - o];
-        }
-        __syncthreads();
-        s_sum[threadIdx.x] += a;
-        s_wl[threadIdx.x] += b;
-        __syncthreads();
-    }
-    uint64_t ex = s_sum[threadIdx.x] - s;
-    uint32_t wex = s_wl[threadIdx.x] - wl;
+    uint64_t s_tot;
+    uint32_t wl_tot;
+    uint64_t ex = block_scan64<1024>(s, s_w64, &s_tot);
+    uint32_t wex = block_scan<1024>(wl, s_w32, &wl_tot);
     for (uint32_t i = 0; i < per; ++i)
         if (b0 + i < g.nb) {
             const uint32_t b = b0 + i;
-            const uint32_t c = hist[b];
+            const uint32_t c = count_of(b);
             off[b] = ex;
+            if ((b & sub_mask) == 0) c_off[b >> g.b2] = ex;
             if (!g.packed) cursor2[b] = ex;
             wl_off[b] = wex;
             ex += c;
             wex += (c || !fill_empty) ? (c + BUILD_CAP - 1) / BUILD_CAP : 1u;
         }
     if (threadIdx.x == 1023) {
-        off[g.nb] = s_sum[1023];
-        wl_off[g.nb] = s_wl[1023];
+        off[g.nb] = s_tot;
+        wl_off[g.nb] = wl_tot;
+        c_off[g.nb1] = s_tot;
     }
     if (!g.packed) return;
     // Packed geometry: a final bucket is a sequence of 8-byte groups of three keys.  Every (slab piece, final bucket)
     // run of scatter2 is rounded up to whole groups (its last key repeated), so a bucket of c keys that receives runs
     // from P pieces needs at most c / 3 + P groups; P = the slabs of S2_KEYS keys that overlap its coarse bucket.
-    __syncthreads();   // off[] of the whole array is visible to the block
+    __syncthreads();
+    auto groups_of = [&](uint32_t b) -> uint64_t {
+        const uint32_t c = count_of(b);
+        const uint64_t lo = c_off[b >> g.b2], hi = c_off[(b >> g.b2) + 1];
+        const uint64_t pieces = hi > lo ? (hi - 1) / S2_KEYS - lo / S2_KEYS + 1 : 0;
+        return c ? c / 3 + pieces + 1 : 0;
+    };
     uint64_t gs = 0;
     for (uint32_t i = 0; i < per; ++i)
-        if (b0 + i < g.nb) {
-            const uint32_t b = b0 + i, c = hist[b];
-            const uint64_t lo = off[(uint64_t) (b >> g.b2) << g.b2], hi = off[(uint64_t) ((b >> g.b2) + 1) << g.b2];
-            const uint64_t pieces = hi > lo ? (hi - 1) / S2_KEYS - lo / S2_KEYS + 1 : 0;
-            gs += c ? c / 3 + pieces + 1 : 0;
-        }
-    const uint64_t mine = gs;
-    __syncthreads();
-    s_sum[threadIdx.x] = gs;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint64_t a = threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_sum[threadIdx.x] += a;
-        __syncthreads();
-    }
-    uint64_t gex = s_sum[threadIdx.x] - mine;
+        if (b0 + i < g.nb) gs += groups_of(b0 + i);
+    uint64_t g_tot;
+    uint64_t gex = block_scan64<1024>(gs, s_w64, &g_tot);
     for (uint32_t i = 0; i < per; ++i)
         if (b0 + i < g.nb) {
-            const uint32_t b = b0 + i, c = hist[b];
-            const uint64_t lo = off[(uint64_t) (b >> g.b2) << g.b2], hi = off[(uint64_t) ((b >> g.b2) + 1) << g.b2];
-            const uint64_t pieces = hi > lo ? (hi - 1) / S2_KEYS - lo / S2_KEYS + 1 : 0;
+            const uint32_t b = b0 + i;
             goff[b] = gex;
             cursor2[b] = gex;
-            gex += c ? c / 3 + pieces + 1 : 0;
+            gex += groups_of(b);
         }
-    if (threadIdx.x == 1023) goff[g.nb] = s_sum[1023];
+    if (threadIdx.x == 1023) goff[g.nb] = g_tot;
 }
 
 // blockoff[j * nb1 + c] = where scatter1 workgroup j starts writing in coarse bucket c
