@@ -420,6 +420,30 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
     return 0;
 }
 
+// memcpy with a few host threads (COMMET_INGEST_THREADS, default 8) for large blocks
+static void parallel_copy(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    static const int nt = [] {
+        const char *e = getenv("COMMET_INGEST_THREADS");
+        int t = e ? atoi(e) : 8;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && t > (int) hw) t = (int) hw;
+        return t < 1 ? 1 : t;
+    }();
+    if (nt == 1 || n < (8u << 20)) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const uint64_t per = ((n + nt - 1) / nt + 63) & ~63ull;
+    for (int i = 1; i < nt; ++i) {
+        const uint64_t a = std::min<uint64_t>(n, (uint64_t) i * per), b = std::min<uint64_t>(n, a + per);
+        if (b > a) th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+    }
+    memcpy(dst, src, std::min<uint64_t>(n, per));
+    for (std::thread &t : th) t.join();
+}
+
 int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads)
 {
     uint64_t done = 0;
@@ -437,7 +461,8 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
                         (unsigned long long) bcap);
         }
         for (uint64_t i = 0; i <= take; ++i) ho[i] = offsets[done + i] - b0;
-        memcpy(hb, bases + b0, ho[take]);
+        // the copy into the pinned staging buffer is what bounds this path (one thread: ~8 GB/s): several threads
+        parallel_copy(hb, bases + b0, ho[take]);
         if (commet_readset_stage_commit(rs, take)) return 1;
         done += take;
     }
