@@ -101,3 +101,46 @@ def test_long_and_ragged_reads(tmp_path, k, t, chunk_group):
         _, n, bits = util.read_bv(str(tmp_path / "o" / "q.fa_in_I.bv"))
         assert np.array_equal(util.bools_from_bits(tags[0], n), util.bools_from_bits(bits, n))
         assert stats[0]["shared"] > 100
+
+
+@pytest.mark.parametrize("k,L,uniform,n_idx", [(24, 100, True, 70000), (25, 90, True, 200000), (25, 120, False, 260000)])
+def test_bucketed_multi_chunk_variants_match_oracle(tmp_path, k, L, uniform, n_idx):
+    """several chunks, every one on the bucketed construction (part_min_kmers lowered): the two index lanes, the packed
+    final level and the fixed-read-length fast path are each switched on and off — every combination must give the CPU
+    checker's tags, chunk count and log numbers (groups of 4, 2 and 1 chunk filters per pass)"""
+    import commet_amd as commet
+    rng = np.random.default_rng(100 * k + L)
+    lo = L if uniform else 40
+    idx_reads = util.random_reads(rng, n_idx, lo, L, n_rate=0.003)
+    idx_reads += [b"A" * L] * 300 + [(b"ACGT" * L)[:L]] * 200                     # hot buckets
+    q_reads = util.related_reads(rng, idx_reads[:20000], 30000, lo, L, share=0.5, n_rate=0.003)
+    d = tmp_path / "mc"
+    os.makedirs(d)
+    util.write_fasta(str(d / "i.fa"), idx_reads)
+    util.write_fasta(str(d / "q.fa"), q_reads)
+    (d / "index.txt").write_text("I:i.fa\n")
+    (d / "search.txt").write_text("Q:q.fa\n")
+
+    class S:
+        dir, index_cfg, search_cfg = str(d), "index.txt", "search.txt"
+    S.k, S.t = k, 2
+    rc, res, chunks, kmers = run_oracle(S, str(tmp_path / "o"), str(tmp_path / "l"))
+    assert rc == 0 and chunks >= 3, chunks
+    _, n, bits = util.read_bv(str(tmp_path / "o" / "q.fa_in_I.bv"))
+    want = util.bools_from_bits(bits, n)
+    with commet.Context(k=k, t=2) as ctx:
+        ctx.set_option("index_mode", 2)
+        ctx.set_option("part_min_kmers", 1000)
+        irs = commet.ReadSet.from_fasta(ctx, [str(d / "i.fa")])
+        qrs = commet.ReadSet.from_fasta(ctx, [str(d / "q.fa")])
+        for lanes, packed, no_uni, group in [(2, 1, 0, 4), (1, 1, 0, 4), (2, 0, 0, 2), (2, 1, 1, 4), (1, 0, 1, 1)]:
+            ctx.set_option("index_lanes", lanes)
+            ctx.set_option("part_packed", packed)
+            ctx.set_option("part_no_uni", no_uni)
+            ctx.set_option("chunk_group", group)
+            tags, stats, info = ctx.index_and_search(irs, [qrs])
+            assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers, (lanes, packed, no_uni, group)
+            assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == \
+                (res[0]["indexed"], res[0]["searched"], res[0]["shared"]), (lanes, packed, no_uni, group)
+            assert np.array_equal(util.bools_from_bits(tags[0], n), want), (lanes, packed, no_uni, group)
+        assert stats[0]["shared"] > 1000
