@@ -1013,7 +1013,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
     }
-    if (g.debug) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
+    if (g.debug & 31) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
@@ -1021,6 +1021,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
                            ws.off, g, ws.cur2, total);
         HIP_OK(hipGetLastError());
     }
+    if (g.debug) return 0;   // scatter2 ablations: bufB holds garbage
     {
         const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
         if (grid >= (1ull << 24)) return fail("build launch too large");

@@ -54,7 +54,8 @@ struct PartGeom {
     uint32_t nb1;        // coarse buckets
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
     int      xcd_swizzle;   // scatter2: slab order, number of interleaved slab ranges (speed only)
-    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics
+    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics;
+                            // of scatter2: 32 no placement, 64 no write-out, 128 no cursor reservation, 256 no counting
     int      packed;        // final buckets hold groups of three 19-bit keys in 8 bytes (two-level geometry only)
 };
 
@@ -764,25 +765,26 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
             const uint32_t i = threadIdx.x + NT * q;
-            if (i < n) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+            if (i < n && !(g.debug & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, nsub, wsum);
         for (uint32_t i = threadIdx.x; i < nsub; i += NT) {
             const uint32_t c = cnt[i];
             const unsigned long long want = g.packed ? (c + 2) / 3 : c;   // packed: whole groups of three keys
-            gbase[i] = c ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
+            gbase[i] = (c && !(g.debug & 128)) ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
         }
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
             const uint32_t i = threadIdx.x + NT * q;
-            if (i < n) {
+            if (i < n && !(g.debug & 32)) {
                 const uint32_t sb = key[q] >> TILE_BITS;
                 sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
             }
         }
         __syncthreads();
-        if (g.packed) {
+        if (g.debug & 64) {
+        } else if (g.packed) {
             for (uint32_t sb = wave * 2 + (lane >> 5); sb < nsub; sb += (NT / 64) * 2)
                 write_run_p3((uint2 *) out, gbase[sb], sorted, base[sb], cnt[sb], lane & 31u, 32u);
         } else {
