@@ -22,6 +22,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <future>
 #include <thread>
 #include <string>
 #include <vector>
@@ -656,9 +657,19 @@ commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *path
     std::vector<std::unique_ptr<commet_host::ReadFileData>> maps;
     std::vector<const char *> data;
     std::vector<uint64_t> sizes;
+    // one thread per file maps it or, when gzipped, inflates it (a zlib stream is sequential; files are independent)
+    std::vector<std::future<std::unique_ptr<commet_host::ReadFileData>>> opening;
     for (int i = 0; i < n_paths; ++i) {
-        std::unique_ptr<commet_host::ReadFileData> mf(new commet_host::ReadFileData);
-        if (!mf->open_file(paths[i])) {
+        const std::string path = paths[i];
+        opening.push_back(std::async(std::launch::async, [path]() {
+            std::unique_ptr<commet_host::ReadFileData> f(new commet_host::ReadFileData);
+            if (!f->open_file(path)) f.reset();
+            return f;
+        }));
+    }
+    for (int i = 0; i < n_paths; ++i) {
+        std::unique_ptr<commet_host::ReadFileData> mf = opening[i].get();
+        if (!mf) {
             fail("Cannot open file %s", paths[i]);
             return nullptr;
         }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -85,11 +86,23 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     out.nickname = nickname;
     std::vector<std::unique_ptr<ReadFileData>> maps;
     std::vector<bool> bv_given;
+    // the files of a set are opened (mapped, or inflated when gzipped: one zlib stream each) by one thread per file;
+    // messages and error handling stay in file order
+    std::vector<std::future<std::unique_ptr<ReadFileData>>> opening;
+    for (const SetEntry &en : entries) {
+        const std::string path = en.file;
+        opening.push_back(std::async(std::launch::async, [path]() {
+            std::unique_ptr<ReadFileData> f(new ReadFileData);
+            if (!f->open_file(path)) f.reset();
+            return f;
+        }));
+    }
+    size_t entry_no = 0;
     for (const SetEntry &en : entries) {
         if (en.bv.empty()) std::cout << "open " << en.file << "\n";
         else std::cout << "open " << en.file << "," << en.bv << "\n";
-        std::unique_ptr<ReadFileData> mf(new ReadFileData);
-        if (!mf->open_file(en.file)) {
+        std::unique_ptr<ReadFileData> mf = opening[entry_no++].get();
+        if (!mf) {
             if (en.bv.empty()) {
                 std::cerr << "Cannot open file file " << en.file << " -> ignore\n";   // file_manager.h:121-123
                 std::cerr << "Cannot open file " << en.file << " -> ignore\n";        // gz path, :144-147
