@@ -1,8 +1,11 @@
 """Timing ablations of part_scatter1_kernel (option part_debug, results become wrong on purpose): run under
   rocprofv3 --kernel-trace --output-format csv -d DIR -o abl -- python3 tools/s1_ablate.py
 then  python tools/s1_ablate.py --report DIR/abl_kernel_trace.csv
-Each debug value does REP index_reads calls of one BASELINE-configs[1] chunk; the report lists the scatter1 / hist
-durations of the calls in launch order."""
+Each debug value does REP index_reads calls of one BASELINE-configs[1] chunk; the report lists the scatter1 / hist /
+scatter2 / build durations of the calls in launch order.  S1_DEBUGS picks the values (scatter1: 1 no write-out, 2 no
+placement, 4 no counting atomics; scatter2: 32 no placement, 64 no write-out, 128 no cursor reservation, 256 no counting;
+kernels downstream of an ablated one are not launched), S1_REP the repeats, S2_SWIZZLE=1 sweeps the slab order of
+scatter2 with the same values instead."""
 import csv
 import os
 import sys
