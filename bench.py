@@ -24,6 +24,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -92,7 +93,10 @@ def measured_traffic(workload, kernel):
     PMC counters cannot be collected from inside the timed run; None when no matching profile exists."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
-    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+    def natural(name):   # r01_v10 after r01_v9
+        return [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", name)]
+
+    for d in sorted(os.listdir(pdir), key=natural) if os.path.isdir(pdir) else []:
         tj, bj = os.path.join(pdir, d, "traffic.json"), os.path.join(pdir, d, "bench.json")
         if not (os.path.exists(tj) and os.path.exists(bj)):
             continue
