@@ -73,7 +73,7 @@ def build_tools(force=False):
             continue
         out = os.path.join(BIN_DIR, tool)
         if force or _newer(out, srcs):
-            _run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", out, src, "-lz"])
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", out, src, "-lz"])
         built.append(out)
     return built
 

@@ -2,6 +2,8 @@
 // `.bv`, drop-in for Commet's tool (reference: src/filter_reads.cpp:48-306).
 // Commet.py runs it on every input file when no filter bvs are given
 // (Commet.py:103-121, 557-562).  O(bases) streaming over the mapped file.
+#include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -9,6 +11,8 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "bv_file.hpp"
 #include "fasta_source.hpp"
@@ -37,32 +41,56 @@ static void print_usage()
 // per-read statistics gathered while scanning a record's lines
 struct ReadStats {
     uint64_t len = 0;
-    uint64_t cnt[5] = {0, 0, 0, 0, 0};   // A C G T other (case-folded, filter_reads.cpp:277-295)
-    uint64_t non_acgt = 0;               // Alphabet::is_in == false (filter_reads.cpp:249-259)
+    uint64_t cnt[5] = {0, 0, 0, 0, 0};   // A C G T other (case-folded, filter_reads.cpp:277-295); other == Alphabet::is_in false (249-259)
+    static const uint8_t *classes()
+    {
+        static uint8_t lut[256];
+        static const bool init = [] {
+            for (int i = 0; i < 256; ++i) lut[i] = 4;
+            lut['A'] = lut['a'] = 0, lut['C'] = lut['c'] = 1, lut['G'] = lut['g'] = 2, lut['T'] = lut['t'] = 3;
+            return true;
+        }();
+        (void) init;
+        return lut;
+    }
     void add(const char *s, size_t n)
     {
+        const uint8_t *lut = classes();
         len += n;
-        for (size_t i = 0; i < n; ++i) {
-            switch (s[i]) {
-            case 'A': case 'a': ++cnt[0]; break;
-            case 'C': case 'c': ++cnt[1]; break;
-            case 'G': case 'g': ++cnt[2]; break;
-            case 'T': case 't': ++cnt[3]; break;
-            default: ++cnt[4]; ++non_acgt;
-            }
-        }
+        for (size_t i = 0; i < n; ++i) ++cnt[lut[(uint8_t) s[i]]];
     }
-    // filter_reads.cpp:265-306, same float / double mix
-    float shannon() const
+    uint64_t non_acgt() const { return cnt[4]; }
+};
+
+// filter_reads.cpp:265-306, same float / double mix:  index (float) += f * log(f) / log(2)  with f = (float) count / (float) len.
+// The double term depends on (count, len) only and is remembered per worker for the read lengths that occur.
+struct Shannon {
+    std::vector<std::vector<double>> memo;   // memo[len][count], NaN = not computed yet
+    float operator()(const ReadStats &st)
     {
         float index = 0;
         for (int i = 0; i < 5; ++i) {
-            const float f = (float) cnt[i] / (float) len;
-            if (f != 0) index += f * log(f) / log(2);
+            const float f = (float) st.cnt[i] / (float) st.len;
+            if (f == 0) continue;
+            double term;
+            if (st.len <= 1024) {
+                if (memo.size() <= st.len) memo.resize(st.len + 1);
+                std::vector<double> &row = memo[st.len];
+                if (row.empty()) row.assign(st.len + 1, std::nan(""));
+                double &slot = row[st.cnt[i]];
+                if (slot != slot) slot = f * log(f) / log(2);
+                term = slot;
+            } else {
+                term = f * log(f) / log(2);
+            }
+            index += term;
         }
         return fabs(index);
     }
 };
+
+// what the reference's loop does with a read (filter_reads.cpp:186-200), decided from its statistics alone
+enum Verdict : uint8_t { KEEP = 0, RM_LENGTH = 1, RM_N = 2, RM_SHANNON = 3, EMPTY = 4 };
 
 int main(int argc, char **argv)
 {
@@ -129,41 +157,94 @@ int main(int argc, char **argv)
     bv.init_true(count_records(mf.format(), d, n));
     if (max_reads == -1) max_reads = (long) bv.size;
     long rm_length = 0, rm_N = 0, rm_shannon = 0;
-    uint64_t pos = 0;          // current_read_pos
-    bool stopped = false;      // the reference iterator stops at an empty sequence / at the -m cap
-    auto judge = [&](const ReadStats &st) {
-        if (stopped) return;
-        if (nb_selected >= max_reads || st.len == 0) {   // loop condition of filter_reads.cpp:186
-            stopped = true;
-            return;
-        }
-        if ((int) st.len < min_size) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_length; }
-        else if ((long) st.non_acgt > (long) max_N) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_N; }
-        else if (st.shannon() < min_shannon) { bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7)); ++rm_shannon; }
-        else ++nb_selected;
-        ++pos;                 // the look-ahead get_next_read (filter_reads.cpp:200)
+    auto classify = [&](const ReadStats &st, Shannon &sh) -> uint8_t {
+        if (st.len == 0) return EMPTY;
+        if ((int) st.len < min_size) return RM_LENGTH;
+        if ((long) st.non_acgt() > (long) max_N) return RM_N;
+        // the index is |...| >= 0: only a positive threshold can remove a read (the usual -e 0 never computes it)
+        if (min_shannon > 0 && sh(st) < min_shannon) return RM_SHANNON;
+        return KEEP;
     };
+    // FASTA: pieces of whole records (cut at lines starting with '>', the reference's own record rule) are classified
+    // by several threads; FASTQ stays one piece ('@' may also start a quality line).  The reference's sequential loop
+    // (stop at an empty sequence or at the -m cap, counters, bits) then runs over the verdicts.
+    std::vector<std::vector<uint8_t>> verdicts;
     if (mf.format() == ReadFormat::Fastq) {
+        verdicts.resize(1);
+        verdicts[0].reserve(bv.size);
+        Shannon sh;
         for_each_fastq_record(d, n, bv.size, [&](const char *s, size_t len) {
             ReadStats st;
             st.add(s, len);
-            judge(st);
+            verdicts[0].push_back(classify(st, sh));
         });
     } else {
-        size_t i = 0;
-        while (i < n && !stopped) {
-            const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
-            size_t j = nl ? (size_t) (nl - d) + 1 : n;
-            ReadStats st;
-            while (j < n && d[j] != '>') {
-                nl = (const char *) memchr(d + j, '\n', n - j);
-                const size_t e = nl ? (size_t) (nl - d) : n;
-                st.add(d + j, e - j);
-                j = nl ? e + 1 : n;
+        std::vector<size_t> cuts(1, 0);
+        const size_t target = 8u << 20;
+        for (size_t at = target; at < n; at += target) {
+            const char *q = d + at;
+            while (true) {   // next line start that begins with '>'
+                q = (const char *) memchr(q, '\n', (size_t) (d + n - q));
+                if (!q || q + 1 >= d + n) { q = nullptr; break; }
+                ++q;
+                if (*q == '>') break;
             }
-            i = j;
-            judge(st);
+            if (!q) break;
+            const size_t c = (size_t) (q - d);
+            if (c > cuts.back()) cuts.push_back(c);
+            at = std::max(at, c);
         }
+        cuts.push_back(n);
+        verdicts.resize(cuts.size() - 1);
+        auto work = [&](size_t pi) {
+            Shannon sh;
+            std::vector<uint8_t> &out = verdicts[pi];
+            size_t i = cuts[pi];
+            const size_t end = cuts[pi + 1];
+            while (i < end) {
+                const char *nl = (const char *) memchr(d + i, '\n', end - i);   // header
+                size_t j = nl ? (size_t) (nl - d) + 1 : end;
+                ReadStats st;
+                while (j < end && d[j] != '>') {
+                    nl = (const char *) memchr(d + j, '\n', end - j);
+                    const size_t e = nl ? (size_t) (nl - d) : end;
+                    st.add(d + j, e - j);
+                    j = nl ? e + 1 : end;
+                }
+                i = j;
+                out.push_back(classify(st, sh));
+            }
+        };
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char *e = getenv("COMMET_INGEST_THREADS")) nt = (unsigned) std::max(1, atoi(e));
+        nt = std::max(1u, std::min<unsigned>(std::min(nt, 16u), (unsigned) verdicts.size()));
+        std::atomic<size_t> next(0);
+        auto loop = [&]() {
+            for (size_t pi = next.fetch_add(1); pi < verdicts.size(); pi = next.fetch_add(1)) work(pi);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(loop);
+        loop();
+        for (std::thread &t : th) t.join();
+    }
+    uint64_t pos = 0;          // current_read_pos
+    bool stopped = false;      // the reference iterator stops at an empty sequence / at the -m cap
+    for (const std::vector<uint8_t> &piece : verdicts) {
+        for (const uint8_t v : piece) {
+            if (nb_selected >= max_reads || v == EMPTY) {   // loop condition of filter_reads.cpp:186
+                stopped = true;
+                break;
+            }
+            if (v == KEEP) ++nb_selected;
+            else {
+                bv.bytes[pos >> 3] &= (uint8_t) ~(1u << (pos & 7));
+                if (v == RM_LENGTH) ++rm_length;
+                else if (v == RM_N) ++rm_N;
+                else ++rm_shannon;
+            }
+            ++pos;             // the look-ahead get_next_read (filter_reads.cpp:200)
+        }
+        if (stopped) break;
     }
     if (nb_selected >= max_reads)   // untag_last_reads: everything from the look-ahead read on
         for (uint64_t r = pos; r < bv.size; ++r) bv.bytes[r >> 3] &= (uint8_t) ~(1u << (r & 7));
