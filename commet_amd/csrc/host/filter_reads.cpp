@@ -154,8 +154,8 @@ int main(int argc, char **argv)
     const char *d = mf.data();
     const size_t n = mf.size();
     BitVector bv;
-    bv.init_true(count_records(mf.format(), d, n));
-    if (max_reads == -1) max_reads = (long) bv.size;
+    const bool fastq = mf.format() == ReadFormat::Fastq;
+    if (fastq) bv.init_true(count_records(mf.format(), d, n));   // FASTA: the classification below counts the records
     long rm_length = 0, rm_N = 0, rm_shannon = 0;
     auto classify = [&](const ReadStats &st, Shannon &sh) -> uint8_t {
         if (st.len == 0) return EMPTY;
@@ -169,7 +169,7 @@ int main(int argc, char **argv)
     // by several threads; FASTQ stays one piece ('@' may also start a quality line).  The reference's sequential loop
     // (stop at an empty sequence or at the -m cap, counters, bits) then runs over the verdicts.
     std::vector<std::vector<uint8_t>> verdicts;
-    if (mf.format() == ReadFormat::Fastq) {
+    if (fastq) {
         verdicts.resize(1);
         verdicts[0].reserve(bv.size);
         Shannon sh;
@@ -227,6 +227,12 @@ int main(int argc, char **argv)
         loop();
         for (std::thread &t : th) t.join();
     }
+    if (!fastq) {              // one verdict per line starting with '>' == the reference's read count (fasta_file.h:61-68)
+        uint64_t total = 0;
+        for (const std::vector<uint8_t> &piece : verdicts) total += piece.size();
+        bv.init_true(total);
+    }
+    if (max_reads == -1) max_reads = (long) bv.size;
     uint64_t pos = 0;          // current_read_pos
     bool stopped = false;      // the reference iterator stops at an empty sequence / at the -m cap
     for (const std::vector<uint8_t> &piece : verdicts) {

@@ -143,6 +143,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     if bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
+        cmds = []
         for q, (s, j) in enumerate(todo):
             if q % ranks.world != ranks.rank:
                 continue
@@ -153,7 +154,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 cmd += ["-m", str(m / len(files[s]))]
             cmd += ["-o", bvs[s][j]]
             say("Filtering command: " + " ".join(cmd))
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+            cmds.append(cmd)
+        # independent processes (each one multi-threaded over its file): a few at a time
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3"))) as pool:
+            list(pool.map(lambda c: subprocess.run(c, check=True, stdout=subprocess.DEVNULL), cmds))
         ranks.barrier()
 
     # ---- residency: every rank holds every set (packed: 12 B per 32 bases) ----------------------------------
