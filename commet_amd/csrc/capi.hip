@@ -1283,12 +1283,13 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     }
     HIP_OK(hipSetDevice(c->device));
 
-    if (host_counts(index_rs)) return 1;
     // an input filter that selects every read is no filter (Commet.py passes all-ones bvs when nothing was filtered)
     if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
     // host plan: chunks of the index set, visited reads of each search set
     const uint64_t max_kmer = commet_max_kmer(c);
-    // a selection is planned from per-block k-mer sums made on the device, where kcnt lives: no per-read loop on the host
+    // The plan is made from per-block k-mer sums computed on the device, where kcnt lives; the host walks only the
+    // blocks in which a chunk starts or ends and fetches just those blocks' counts: no per-read loop over the set and
+    // no host copy of its counts (a selection bitmap, when there is one, is uploaded first for the kernel to use).
     std::vector<uint64_t> blk_sums;
     if (index_rs->n_reads && plan_blocks_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)) {
         const uint64_t nblk = (index_rs->n_reads + PLAN_BLOCK_READS - 1) / PLAN_BLOCK_READS;
@@ -1300,15 +1301,30 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             HIP_OK(hipMalloc((void **) &c->d_plansum, nblk * sizeof(unsigned long long)));
             c->plansum_cap = nblk;
         }
-        if (upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
-        hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt, index_rs->d_sel,
-                           index_rs->n_reads, c->d_plansum);
+        if (index_select && upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
+        hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt,
+                           index_select ? index_rs->d_sel : nullptr, index_rs->n_reads, c->d_plansum);
         HIP_OK(hipGetLastError());
         blk_sums.resize(nblk);
         HIP_OK(hipMemcpyAsync(blk_sums.data(), c->d_plansum, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
-    const IndexPlan plan = !blk_sums.empty() ? plan_index_blocks(index_select, index_rs->h_kcnt.data(), index_rs->n_reads, max_kmer,
+    // counts of one block of reads, fetched on demand (or taken from the host copy when somebody made one)
+    std::vector<uint32_t> kblock(PLAN_BLOCK_READS);
+    uint64_t kblock_no = ~0ull;
+    bool kfetch_failed = false;
+    auto kcnt_of = [&](uint64_t q) -> uint32_t {
+        if (index_rs->have_host_counts) return index_rs->h_kcnt[q];
+        const uint64_t blk = q / PLAN_BLOCK_READS;
+        if (blk != kblock_no) {
+            const uint64_t lo = blk * PLAN_BLOCK_READS, cnt = std::min<uint64_t>(PLAN_BLOCK_READS, index_rs->n_reads - lo);
+            if (hipMemcpy(kblock.data(), index_rs->d_kcnt + lo, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) kfetch_failed = true;
+            kblock_no = blk;
+        }
+        return kblock[q % PLAN_BLOCK_READS];
+    };
+    if (blk_sums.empty() && host_counts(index_rs)) return 1;   // the other planners read the counts on the host
+    const IndexPlan plan = !blk_sums.empty() ? plan_index_blocks(index_select, kcnt_of, index_rs->n_reads, max_kmer,
                                                                  blk_sums.data(), PLAN_BLOCK_READS)
                            : plan_fast_ok(index_rs->files, index_select, index_rs->empty_reads, max_kmer)
                                ? plan_index_fast(index_rs->h_kprefix, index_rs->n_reads, max_kmer)
@@ -1316,6 +1332,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                                ? plan_index_select(index_rs->files, index_select, index_rs->h_kcnt.data(), index_rs->n_reads, max_kmer)
                                : plan_index(index_rs->files, index_select, index_rs->empty_reads, index_rs->h_kcnt.data(),
                                             index_rs->n_reads, max_kmer);
+    if (kfetch_failed) return fail("k-mer count fetch failed: %s", hipGetErrorString(hipGetLastError()));
     std::vector<uint64_t> visited(n_search, 0);
     std::vector<std::vector<uint8_t>> vis(n_search);
     std::vector<char> all_visited(n_search, 0);   // every read of the set is visited: the kernels take a null bitmap

@@ -27,8 +27,8 @@ uint64_t commet_plan_index(const uint64_t *files, int n_files, const uint8_t *se
         const uint64_t bs = 1ull << (fast - 2);
         std::vector<uint64_t> sums((n_reads + bs - 1) / bs, 0);
         for (uint64_t r = 0; r < n_reads; ++r)
-            if (bit_at(select, r)) sums[r / bs] += kcnt[r];
-        plan = plan_index_blocks(select, kcnt, n_reads, max_kmer, sums.data(), bs);
+            if (!select || bit_at(select, r)) sums[r / bs] += kcnt[r];
+        plan = plan_index_blocks(select, [&](uint64_t q) { return kcnt[q]; }, n_reads, max_kmer, sums.data(), bs);
     } else if (fast && plan_fast_ok(fs, select, er, max_kmer)) {
         build_kmer_prefix(kcnt, n_reads, prefix);
         plan = plan_index_fast(prefix, n_reads, max_kmer);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void block_kmer_sums_kernel(const uint32_t *__
     unsigned long long s = 0;
     for (uint32_t i = threadIdx.x; i < PLAN_BLOCK_READS; i += 256) {
         const uint64_t r = r0 + i;
-        if (r < n && ((sel[r >> 6] >> (r & 63)) & 1ull)) s += kcnt[r];
+        if (r < n && (!sel || ((sel[r >> 6] >> (r & 63)) & 1ull))) s += kcnt[r];   // sel == nullptr: every read
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;

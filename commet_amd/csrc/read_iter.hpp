@@ -447,21 +447,29 @@ inline IndexPlan plan_index_select(const std::vector<FileSpan> &files, const uin
 inline bool plan_blocks_ok(const std::vector<FileSpan> &files, const uint8_t *select, const std::vector<uint64_t> &empty_reads,
                            uint64_t max_kmer)
 {
-    if (!select || !empty_reads.empty() || files.empty() || max_kmer == 0) return false;
+    if (!empty_reads.empty() || files.empty() || max_kmer == 0) return false;
     for (const FileSpan &f : files)
-        if (f.count == 0 || next_set_bit(select, f.first, f.first + f.count) >= f.first + f.count) return false;
+        if (f.count == 0 || (select && next_set_bit(select, f.first, f.first + f.count) >= f.first + f.count)) return false;
     return true;
 }
 
-inline IndexPlan plan_index_blocks(const uint8_t *select, const uint32_t *kcnt, uint64_t n_reads, uint64_t max_kmer,
+// select == nullptr: every read is selected (the plan is then `dense`).  kcnt_of(q) = k-mers of read q; it is asked
+// only for reads of the blocks in which a chunk starts or ends (the library fetches those blocks from the device).
+template <typename KcntOf>
+inline IndexPlan plan_index_blocks(const uint8_t *select, KcntOf &&kcnt_of, uint64_t n_reads, uint64_t max_kmer,
                                    const uint64_t *block_sums, uint64_t bs)
 {
+    auto sel_next = [&](uint64_t from, uint64_t end) { return select ? next_set_bit(select, from, end) : std::min(from, end); };
+    auto sel_at = [&](uint64_t i) { return !select || bit_at(select, i); };
+    auto sel_count = [&](uint64_t lo, uint64_t hi) { return select ? count_bits(select, lo, hi) : hi - lo; };
     IndexPlan plan;
+    plan.dense = select == nullptr;
     plan.indexed_bits.assign(n_reads / 8 + 1, 0);
-    __builtin_memcpy(plan.indexed_bits.data(), select, n_reads / 8);
+    if (select) __builtin_memcpy(plan.indexed_bits.data(), select, n_reads / 8);
+    else __builtin_memset(plan.indexed_bits.data(), 0xFF, n_reads / 8);
     for (uint64_t i = (n_reads / 8) * 8; i < n_reads; ++i)
-        if (bit_at(select, i)) bit_on(plan.indexed_bits.data(), i);
-    uint64_t pos = next_set_bit(select, 0, n_reads);   // first read of the chunk being opened
+        if (sel_at(i)) bit_on(plan.indexed_bits.data(), i);
+    uint64_t pos = sel_next(0, n_reads);   // first read of the chunk being opened
     while (pos < n_reads) {
         Chunk ch;
         ch.first = pos;
@@ -474,8 +482,8 @@ inline IndexPlan plan_index_blocks(const uint8_t *select, const uint32_t *kcnt, 
                 r = blk_end;
                 continue;
             }
-            for (uint64_t q = next_set_bit(select, r, blk_end); q < blk_end; q = next_set_bit(select, q + 1, blk_end)) {
-                ch.kmers += kcnt[q];
+            for (uint64_t q = sel_next(r, blk_end); q < blk_end; q = sel_next(q + 1, blk_end)) {
+                ch.kmers += kcnt_of(q);
                 if (ch.kmers >= max_kmer) {   // the chunk is full with read q in it
                     full = true;
                     ch.last = q;
@@ -486,18 +494,18 @@ inline IndexPlan plan_index_blocks(const uint8_t *select, const uint32_t *kcnt, 
         }
         if (!full) {   // everything up to the end of the set: the last selected read
             uint64_t e = n_reads;
-            while (!bit_at(select, e - 1)) --e;   // ch.first is selected
+            while (!sel_at(e - 1)) --e;   // ch.first is selected
             ch.last = e - 1;
         }
-        ch.n_reads = count_bits(select, ch.first, ch.last + 1);
+        ch.n_reads = sel_count(ch.first, ch.last + 1);
         plan.chunks.push_back(ch);
         plan.indexed_reads += ch.n_reads;
         plan.kmers += ch.kmers;
-        if (!full) break;                                                // closed by the final end-marker
-        const uint64_t d = next_set_bit(select, ch.last + 1, n_reads);   // the look-ahead read that closes a full chunk
+        if (!full) break;                                        // closed by the final end-marker
+        const uint64_t d = sel_next(ch.last + 1, n_reads);       // the look-ahead read that closes a full chunk
         if (d >= n_reads) break;
-        plan.indexed_bits[d >> 3] &= (uint8_t) ~(1u << (d & 7));         // fetched, never indexed
-        pos = next_set_bit(select, d + 1, n_reads);
+        plan.indexed_bits[d >> 3] &= (uint8_t) ~(1u << (d & 7));   // fetched, never indexed
+        pos = sel_next(d + 1, n_reads);
     }
     return plan;
 }

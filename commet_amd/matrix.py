@@ -140,6 +140,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     if l < k * t and l != 0:                                      # Commet.py:509-513 (l stays 0 by default)
         l = k * t
     # ---- filter step (Commet.py:103-121): one filter_reads per file, dealt over the ranks -------------
+    t_filter = time.perf_counter()
     if bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
@@ -161,6 +162,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             list(pool.map(lambda c: subprocess.run(c, check=True, stdout=subprocess.DEVNULL), cmds))
         ranks.barrier()
 
+    filter_s = time.perf_counter() - t_filter
     # ---- residency: every rank holds every set (packed: 12 B per 32 bases) ----------------------------------
     t0 = time.perf_counter()
     # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU
@@ -238,7 +240,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     slowest = ranks.max_seconds(jobs_s)
     total_searched = ranks.sum_int(reads_searched)
     if result is not None:
-        result.update(load_s=load_s, jobs_s=slowest, reads_searched=total_searched, world=ranks.world, rank0_profile=prof,
+        result.update(filter_s=filter_s, load_s=load_s, jobs_s=slowest, reads_searched=total_searched, world=ranks.world, rank0_profile=prof,
                       reads_per_s=total_searched / slowest if slowest > 0 else 0.0)
         say(f"{total_searched} reads searched in {slowest:.3f} s on {ranks.world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s")
     for rs in sets:

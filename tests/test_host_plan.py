@@ -198,3 +198,9 @@ def test_block_sum_selected_plan_equals_generic_plan(plan, seed):
         for log_bs in (0, 2, 5, 12):
             b = plan_index(plan, counts, sel, kcnt, max_kmer, fast=2 + log_bs)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (seed, max_kmer, log_bs)
+    # no selection at all: the same planner with every read selected (what the library uses for whole sets)
+    for max_kmer in (1, 7, 60, 500, 10 ** 9):
+        a = plan_index(plan, counts, None, kcnt, max_kmer, fast=False)
+        for log_bs in (0, 3, 12):
+            b = plan_index(plan, counts, None, kcnt, max_kmer, fast=2 + log_bs)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (seed, max_kmer, log_bs)
