@@ -76,53 +76,6 @@ inline PartGeom make_geom(int k)
     return g;
 }
 
-// ---------------------------------------------------------------------------
-// direct window extraction: the k-mer ending at base p = 32*w + j of a read,
-// from the word triples w-2, w-1, w (no serial rolling: any lane, any position)
-// ---------------------------------------------------------------------------
-template <typename W> struct ItemWords;
-template <> struct ItemWords<uint32_t> {
-    uint32_t hi[2], lo[2], va[2];   // [0] = word w-1, [1] = word w
-    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
-    {
-        hi[1] = p[3 * w], lo[1] = p[3 * w + 1], va[1] = p[3 * w + 2];
-        if (w) hi[0] = p[3 * w - 3], lo[0] = p[3 * w - 2], va[0] = p[3 * w - 1];
-        else hi[0] = lo[0] = va[0] = 0;
-    }
-    // window of the k bases ending at bit j of word w; false if any is not ACGT
-    __device__ __forceinline__ bool window(uint32_t j, int k, uint32_t mask, uint32_t &wh, uint32_t &wl) const
-    {
-        const uint32_t s = 33u + j - (uint32_t) k;   // 1..32
-        const uint32_t v = (uint32_t) ((((uint64_t) va[1] << 32) | va[0]) >> s) & mask;
-        wh = (uint32_t) ((((uint64_t) hi[1] << 32) | hi[0]) >> s) & mask;
-        wl = (uint32_t) ((((uint64_t) lo[1] << 32) | lo[0]) >> s) & mask;
-        return v == mask;
-    }
-};
-template <> struct ItemWords<uint64_t> {
-    uint32_t hi[3], lo[3], va[3];   // words w-2, w-1, w
-    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
-    {
-        hi[2] = p[3 * w], lo[2] = p[3 * w + 1], va[2] = p[3 * w + 2];
-        if (w) hi[1] = p[3 * w - 3], lo[1] = p[3 * w - 2], va[1] = p[3 * w - 1];
-        else hi[1] = lo[1] = va[1] = 0;
-        if (w > 1) hi[0] = p[3 * w - 6], lo[0] = p[3 * w - 5], va[0] = p[3 * w - 4];
-        else hi[0] = lo[0] = va[0] = 0;
-    }
-    __device__ __forceinline__ static uint64_t ext(const uint32_t *x, uint32_t s, uint64_t mask)
-    {
-        const uint64_t lo64 = ((uint64_t) x[1] << 32) | x[0];
-        return ((lo64 >> s) | ((uint64_t) x[2] << (64 - s))) & mask;   // 27 <= s <= 63 for 33 <= k <= 38
-    }
-    __device__ __forceinline__ bool window(uint32_t j, int k, uint64_t mask, uint64_t &wh, uint64_t &wl) const
-    {
-        const uint32_t s = 65u + j - (uint32_t) k;
-        wh = ext(hi, s, mask);
-        wl = ext(lo, s, mask);
-        return ext(va, s, mask) == mask;
-    }
-};
-
 // An item = 8 consecutive bases of a read ("octet" q covers bases 8q..8q+7).
 // Octets below (k-1)>>3 hold no k-mer end and are never enumerated.
 __device__ __forceinline__ uint32_t octets_of(uint32_t len, int k)

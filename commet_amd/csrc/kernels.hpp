@@ -143,6 +143,53 @@ __device__ __forceinline__ W psi_a(W key, int k)
 }
 
 // ---------------------------------------------------------------------------
+// direct window extraction: the k-mer ending at base p = 32*w + j of a read,
+// from the word triples w-2, w-1, w (no serial rolling: any lane, any position)
+// ---------------------------------------------------------------------------
+template <typename W> struct ItemWords;
+template <> struct ItemWords<uint32_t> {
+    uint32_t hi[2], lo[2], va[2];   // [0] = word w-1, [1] = word w
+    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
+    {
+        hi[1] = p[3 * w], lo[1] = p[3 * w + 1], va[1] = p[3 * w + 2];
+        if (w) hi[0] = p[3 * w - 3], lo[0] = p[3 * w - 2], va[0] = p[3 * w - 1];
+        else hi[0] = lo[0] = va[0] = 0;
+    }
+    // window of the k bases ending at bit j of word w; false if any is not ACGT
+    __device__ __forceinline__ bool window(uint32_t j, int k, uint32_t mask, uint32_t &wh, uint32_t &wl) const
+    {
+        const uint32_t s = 33u + j - (uint32_t) k;   // 1..32
+        const uint32_t v = (uint32_t) ((((uint64_t) va[1] << 32) | va[0]) >> s) & mask;
+        wh = (uint32_t) ((((uint64_t) hi[1] << 32) | hi[0]) >> s) & mask;
+        wl = (uint32_t) ((((uint64_t) lo[1] << 32) | lo[0]) >> s) & mask;
+        return v == mask;
+    }
+};
+template <> struct ItemWords<uint64_t> {
+    uint32_t hi[3], lo[3], va[3];   // words w-2, w-1, w
+    __device__ __forceinline__ void load(const uint32_t *p, uint32_t w)
+    {
+        hi[2] = p[3 * w], lo[2] = p[3 * w + 1], va[2] = p[3 * w + 2];
+        if (w) hi[1] = p[3 * w - 3], lo[1] = p[3 * w - 2], va[1] = p[3 * w - 1];
+        else hi[1] = lo[1] = va[1] = 0;
+        if (w > 1) hi[0] = p[3 * w - 6], lo[0] = p[3 * w - 5], va[0] = p[3 * w - 4];
+        else hi[0] = lo[0] = va[0] = 0;
+    }
+    __device__ __forceinline__ static uint64_t ext(const uint32_t *x, uint32_t s, uint64_t mask)
+    {
+        const uint64_t lo64 = ((uint64_t) x[1] << 32) | x[0];
+        return ((lo64 >> s) | ((uint64_t) x[2] << (64 - s))) & mask;   // 27 <= s <= 63 for 33 <= k <= 38
+    }
+    __device__ __forceinline__ bool window(uint32_t j, int k, uint64_t mask, uint64_t &wh, uint64_t &wl) const
+    {
+        const uint32_t s = 65u + j - (uint32_t) k;
+        wh = ext(hi, s, mask);
+        wl = ext(lo, s, mask);
+        return ext(va, s, mask) == mask;
+    }
+};
+
+// ---------------------------------------------------------------------------
 // pack: ASCII -> {hi, lo, valid} planes, per-read complete-k-mer counts.
 // One lane per read.  Replaces the per-char work of Alphabet::is_in
 // (alphabet.h:44-58) and HashKey::add's base classes (hash_key.h:72-88).
@@ -508,6 +555,65 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
             const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
             const uint32_t *pc = pb + fg.plane_words;
             const uint32_t *pd = pc + fg.plane_words;
+            if constexpr (!COUNT) {
+                // Sparse replay: the reference probes a window iff its k bases are ACGT (that is what a gathered mask
+                // bit stands on) and it ends at least k bases after the strand's last full hit.  A window whose lane-a
+                // bit is clear can never be a hit, so only the set mask bits are visited, in order, with that rule;
+                // their keys come straight from the read's words (no rolling over the bases in between).
+                for (int strand = 0; strand < 2 && !found; ++strand) {
+                    int seen = 0, next_ok = 0;
+                    bool dead = false;
+                    auto probe_bcd = [&](W wh, W wl) -> bool {
+                        W ka, kb;
+                        if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                        else ka = ~wh & mask, kb = ~wl & mask;
+                        return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
+                    };
+                    for (uint32_t w = 0; (int) (w * 32u) <= pe && !found && !dead; ++w) {
+                        uint32_t m = mask_at(i, strand, w);
+                        if (!m) continue;
+                        ItemWords<W> it;
+                        it.load(p, w);
+                        while (m && !found) {
+                            const uint32_t j = (uint32_t) __ffs((int) m) - 1u;
+                            m &= m - 1u;
+                            const int q = (int) (32u * w + j);
+                            if (q < next_ok) continue;
+                            if (q + (t - seen - 1) * k > last) {
+                                dead = true;
+                                break;
+                            }
+                            W wh, wl;
+                            (void) it.window(j, k, mask, wh, wl);   // valid: the gather saw a complete window here
+                            if (probe_bcd(wh, wl)) {
+                                ++seen;
+                                next_ok = q + k;
+                                if (seen >= t) found = true;
+                            }
+                        }
+                    }
+                    // windows behind the gathered ones matter only after a first full hit (pruning, see above)
+                    if (!found && !dead && seen >= 1) {
+                        for (int q = max(pe + 1, next_ok); q <= last && !found; ++q) {
+                            if (q + (t - seen - 1) * k > last) break;
+                            ItemWords<W> it;
+                            it.load(p, (uint32_t) q >> 5);
+                            W wh, wl;
+                            if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;   // a base of the window is not ACGT
+                            const W ka = strand == 0 ? (W) (T::brev(wh) >> sh) : (W) (~wh & mask);
+                            const W addr = psi_a<W>(ka, k);
+                            if (!((fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> ((uint32_t) addr & 31u)) & 1u)) continue;
+                            if (probe_bcd(wh, wl)) {
+                                ++seen;
+                                q += k - 1;   // the next complete window ends k bases later
+                                if (seen >= t) found = true;
+                            }
+                        }
+                    }
+                }
+                if (found) found_chunk = i;
+                continue;
+            }
             for (int strand = 0; strand < 2 && !found; ++strand) {
                 W wh = 0, wl = 0;
                 uint32_t run = 0;
