@@ -116,7 +116,7 @@ struct commet_ctx {
     int cur_slot = 0;                 // slot the index / search launch helpers work on
     uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
     int il_stride = 0;
-    int chunk_group = 4;              // option: chunks searched per pass (1 = one pass per chunk)
+    int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
     struct IngestBuf {
         uint8_t *h_bases = nullptr;
@@ -1138,8 +1138,11 @@ int launch_interleave(commet_ctx *c, int g, int gs)
     if (gs == 2)
         hipLaunchKernelGGL(interleave_a_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
-    else
+    else if (gs == 4)
         hipLaunchKernelGGL(interleave_a_kernel<4>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+                           c->plane_words, g, c->il_a);
+    else
+        hipLaunchKernelGGL(interleave_a_kernel<8>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1176,6 +1179,17 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.slot_words = 4 * c->plane_words;
     fg.plane_words = c->plane_words;
     fg.g = g;
+    if (gs == 8) {   // register masks, no LDS (group8_ok)
+        const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
+        if (c->k <= 32)
+            hipLaunchKernelGGL(search_group8_kernel<uint32_t>, grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel, d_tags,
+                               d_counters, cstride);
+        else
+            hipLaunchKernelGGL(search_group8_kernel<uint64_t>, grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel, d_tags,
+                               d_counters, cstride);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     const uint32_t nw_max = (rs->max_len + 31) / 32;
     if (c->k <= 32) {
         if (gs == 2) return launch_search_group_t<uint32_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
@@ -1190,6 +1204,14 @@ bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
     // LDS masks: g chunks x 2 strands x ceil(max_len/32) words per lane, at most 64 KiB per workgroup
     const uint64_t nw = ((uint64_t) rs->max_len + 31) / 32;
     return c->k >= 2 && nw >= 1 && (uint64_t) g * 2 * nw * 256 * 4 <= (64u << 10);
+}
+
+// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 64 first-hit windows per read in
+// registers (kernels.hpp); the probe-counting builds exist for groups of <= 4 only
+bool group8_ok(const commet_ctx *c, const commet_readset *rs)
+{
+    const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) c->t * c->k + 1;
+    return c->k >= 2 && !c->count_probes && first_hit_windows <= 64;
 }
 
 }  // namespace
@@ -1390,13 +1412,23 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     int rc = 0;
     // chunks are taken in groups of up to `chunk_group`: their filters are built into separate slots and every
     // search set is scanned ONCE per group (search_group_kernel) instead of once per chunk
-    int group_cap = (c->k >= 2) ? std::max(1, std::min(4, c->chunk_group)) : 1;
+    int group_cap = (c->k >= 2) ? std::max(1, std::min(8, c->chunk_group)) : 1;
     if (n_chunks < 2) group_cap = 1;
+    if (group_cap > 4) {   // more than four filters per pass: every search set must qualify for the register-mask kernel
+        bool ok8 = n_chunks > 4;
+        for (int s = 0; s < n_search && ok8; ++s) ok8 = group8_ok(c, search_rs[s]);
+        if (!ok8) group_cap = 4;
+    }
     for (uint64_t ci = 0; ci < n_chunks && !rc;) {
         int g = (int) std::min<uint64_t>((uint64_t) group_cap, n_chunks - ci);
-        const int gs = g <= 2 ? 2 : 4;
-        if (g > 1 && ensure_slots(c, g, gs)) {   // not enough memory for a group: one chunk at a time
-            g = 1;
+        const int gs = g <= 2 ? 2 : g <= 4 ? 4 : 8;
+        if (g > 1 && ensure_slots(c, g, gs)) {   // not enough memory for the group
+            (void) hipGetLastError();
+            if (g > 4) {                          // eight slots do not fit: groups of four
+                group_cap = 4;
+                continue;
+            }
+            g = 1;                                // one chunk at a time
             group_cap = 1;
         }
         hipEvent_t a = nullptr, b = nullptr;
@@ -1453,7 +1485,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         for (int s = 0; s < n_search && !rc; ++s) {
             const commet_readset *rs = search_rs[s];
             unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
-            if (g > 1 && group_searchable(c, rs, g)) {
+            if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
                 if (launch_search_group(c, rs, g, gs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
             } else {
@@ -1567,7 +1599,7 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         return 0;
     }
     if (!strcmp(name, "chunk_group")) {       // chunk filters searched per pass over a set (1 = reference order)
-        if (value < 1 || value > 4) return fail("chunk_group must be 1..4");
+        if (value < 1 || value > 8) return fail("chunk_group must be 1..8");
         c->chunk_group = (int) value;
         return 0;
     }

@@ -691,6 +691,158 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
     }
 }
 
+// ---------------------------------------------------------------------------
+// Up to EIGHT chunk filters in one pass (A planes interleaved with stride 8: the eight words of a window are 32
+// contiguous bytes of one 64-byte sector, still one request).  For read sets whose first-hit windows number at most
+// 64 per read (len - t*k + 1 <= 64: 100-bp reads at k = 32, t = 2 have 37) the gathered lane-a bits live in REGISTERS,
+// bit = window end - (k-1): no LDS at all, so the occupancy does not fall with the number of filters.  Replay = the
+// sparse replay of search_group_kernel, unrolled over the filters.  Sets of more than four chunks need half the passes.
+// ---------------------------------------------------------------------------
+template <typename W>
+__global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, FilterGroupView fg, int k, int t,
+                                                            const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
+                                                            unsigned long long *__restrict__ counters, uint32_t cstride)
+{
+    using T = KeyTraits<W>;
+    constexpr int GS = 8;
+    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t word = r >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = (word << 6) < rv.n;
+    uint64_t selw = ~0ull, tagw = 0;
+    if (in_range) {
+        if (sel) selw = sel[word];
+        if (tags) tagw = tags[word];
+    }
+    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    bool found = false;
+    int found_chunk = -1;
+    if (active) {
+        uint64_t t0;
+        uint32_t len;
+        read_extent(rv, r, t0, len);
+        const uint32_t *p = rv.planes + 3 * t0;
+        const int sh = T::BITS - k;
+        const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+        const int last = (int) len - 1;
+        const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 64
+        const int q0 = k - 1;
+        uint32_t fm[2][GS], rm[2][GS];         // [half of the 64 relative positions][filter]
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < GS; ++i) fm[h][i] = 0, rm[h][i] = 0;
+        // (1) gather
+        {
+            W wh = 0;
+            uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
+            auto roll = [&](int pos) {
+                const uint32_t w = (uint32_t) pos >> 5, j = (uint32_t) pos & 31u;
+                if (w != cw) hi = p[3 * w], va = p[3 * w + 2], cw = w;
+                wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                run = ((va >> j) & 1u) ? run + 1 : 0;
+            };
+            for (int pos = 0; pos < q0 && pos <= pe; ++pos) roll(pos);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                for (int jj = 0; jj < 32; ++jj) {
+                    const int q = q0 + 32 * h + jj;
+                    if (q > pe) break;
+                    roll(q);
+                    if (run >= (uint32_t) k) {
+                        bool selfp;
+                        const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
+                        const uint32_t *src = fg.il_a + (uint64_t) (addr >> 5) * GS;
+                        const uint4 v = *(const uint4 *) src, u = *(const uint4 *) (src + 4);
+                        const uint32_t x[GS] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
+                        const uint32_t bit = (uint32_t) addr & 31u;
+#pragma unroll
+                        for (int i = 0; i < GS; ++i) {
+                            const uint32_t fb = (x[i] >> bit) & 1u;
+                            const uint32_t rb = selfp ? fb : ((x[i] >> (bit ^ 1u)) & 1u);
+                            fm[h][i] |= fb << jj;
+                            rm[h][i] |= rb << jj;
+                        }
+                    }
+                }
+            }
+        }
+        // (2) sparse replay, filter by filter (unrolled: the masks are registers)
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            if (i >= fg.g || found) continue;
+            const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
+            const uint32_t *pc = pb + fg.plane_words;
+            const uint32_t *pd = pc + fg.plane_words;
+#pragma unroll
+            for (int strand = 0; strand < 2; ++strand) {
+                if (found) continue;
+                int seen = 0, next_ok = 0;
+                bool dead = false;
+                auto probe_bcd = [&](W wh, W wl) -> bool {
+                    W ka, kb;
+                    if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                    else ka = ~wh & mask, kb = ~wl & mask;
+                    return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
+                };
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t m = strand ? rm[h][i] : fm[h][i];
+                    while (m && !found && !dead) {
+                        const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;
+                        m &= m - 1u;
+                        const int q = q0 + 32 * h + (int) jj;
+                        if (q < next_ok) continue;
+                        if (q + (t - seen - 1) * k > last) {
+                            dead = true;
+                            break;
+                        }
+                        ItemWords<W> it;
+                        it.load(p, (uint32_t) q >> 5);
+                        W wh, wl;
+                        (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
+                        if (probe_bcd(wh, wl)) {
+                            ++seen;
+                            next_ok = q + k;
+                            if (seen >= t) found = true;
+                        }
+                    }
+                }
+                if (!found && !dead && seen >= 1) {   // windows behind the gathered ones, after a first full hit only
+                    for (int q = max(pe + 1, next_ok); q <= last && !found; ++q) {
+                        if (q + (t - seen - 1) * k > last) break;
+                        ItemWords<W> it;
+                        it.load(p, (uint32_t) q >> 5);
+                        W wh, wl;
+                        if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;
+                        const W ka = strand == 0 ? (W) (T::brev(wh) >> sh) : (W) (~wh & mask);
+                        const W addr = psi_a<W>(ka, k);
+                        if (!((fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> ((uint32_t) addr & 31u)) & 1u)) continue;
+                        if (probe_bcd(wh, wl)) {
+                            ++seen;
+                            q += k - 1;
+                            if (seen >= t) found = true;
+                        }
+                    }
+                }
+            }
+            if (found && found_chunk < 0) found_chunk = i;
+        }
+    }
+    const uint64_t fb = __ballot(found);
+    if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
+    if (counters) {
+        for (int i = 0; i < fg.g; ++i) {
+            const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
+            const uint64_t fd = __ballot(found_chunk == i);
+            if (lane == 0) {
+                if (sc) atomicAdd(&counters[(uint64_t) i * cstride + 0], (unsigned long long) __popcll(sc));
+                if (fd) atomicAdd(&counters[(uint64_t) i * cstride + 1], (unsigned long long) __popcll(fd));
+            }
+        }
+    }
+}
+
 // il_a[w * GS + i] = plane A word w of filter slot i (0 for i >= g)
 template <int GS>
 __global__ __launch_bounds__(256) void interleave_a_kernel(const uint32_t *__restrict__ slot0, uint64_t slot_words,
@@ -702,7 +854,11 @@ __global__ __launch_bounds__(256) void interleave_a_kernel(const uint32_t *__res
 #pragma unroll
         for (int i = 0; i < GS; ++i) x[i] = i < g ? slot0[(uint64_t) i * slot_words + w] : 0u;
         if (GS == 2) *(uint2 *) (il_a + w * 2) = make_uint2(x[0], x[1]);
-        else *(uint4 *) (il_a + w * 4) = make_uint4(x[0], x[1 % GS], x[2 % GS], x[3 % GS]);
+        else if (GS == 4) *(uint4 *) (il_a + w * 4) = make_uint4(x[0], x[1 % GS], x[2 % GS], x[3 % GS]);
+        else {
+            *(uint4 *) (il_a + w * 8) = make_uint4(x[0], x[1 % GS], x[2 % GS], x[3 % GS]);
+            *(uint4 *) (il_a + w * 8 + 4) = make_uint4(x[4 % GS], x[5 % GS], x[6 % GS], x[7 % GS]);
+        }
     }
 }
 

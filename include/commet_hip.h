@@ -169,7 +169,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *   index_mode (0/1/2)   0 auto, 1 atomic-OR kernel, 2 bucketed (LDS-tile) construction
  *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
- *   chunk_group (1..4)   chunk filters searched per pass over a set (1 = the reference's order)
+ *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
+ *                        for read sets with at most 64 first-hit windows per read, else 4)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
  *   part_debug           timing ablations of scatter1 (tools/s1_ablate.py; leaves the filter unbuilt) */

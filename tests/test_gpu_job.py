@@ -103,11 +103,12 @@ def test_long_and_ragged_reads(tmp_path, k, t, chunk_group):
         assert stats[0]["shared"] > 100
 
 
-@pytest.mark.parametrize("k,L,uniform,n_idx", [(24, 100, True, 70000), (25, 90, True, 200000), (25, 120, False, 260000)])
+@pytest.mark.parametrize("k,L,uniform,n_idx", [(24, 100, True, 150000), (25, 90, True, 200000), (25, 120, False, 260000)])
 def test_bucketed_multi_chunk_variants_match_oracle(tmp_path, k, L, uniform, n_idx):
     """several chunks, every one on the bucketed construction (part_min_kmers lowered): the two index lanes, the packed
     final level and the fixed-read-length fast path are each switched on and off — every combination must give the CPU
-    checker's tags, chunk count and log numbers (groups of 4, 2 and 1 chunk filters per pass)"""
+    checker's tags, chunk count and log numbers (groups of 8 — the register-mask kernel where the read length allows it —,
+    4, 2 and 1 chunk filters per pass)"""
     import commet_amd as commet
     rng = np.random.default_rng(100 * k + L)
     lo = L if uniform else 40
@@ -133,7 +134,7 @@ def test_bucketed_multi_chunk_variants_match_oracle(tmp_path, k, L, uniform, n_i
         ctx.set_option("part_min_kmers", 1000)
         irs = commet.ReadSet.from_fasta(ctx, [str(d / "i.fa")])
         qrs = commet.ReadSet.from_fasta(ctx, [str(d / "q.fa")])
-        for lanes, packed, no_uni, group in [(2, 1, 0, 4), (1, 1, 0, 4), (2, 0, 0, 2), (2, 1, 1, 4), (1, 0, 1, 1)]:
+        for lanes, packed, no_uni, group in [(2, 1, 0, 8), (2, 1, 0, 4), (1, 1, 0, 4), (2, 0, 0, 2), (2, 1, 1, 8), (1, 0, 1, 1)]:
             ctx.set_option("index_lanes", lanes)
             ctx.set_option("part_packed", packed)
             ctx.set_option("part_no_uni", no_uni)
