@@ -1181,12 +1181,22 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
         const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
-        if (c->k <= 32)
-            hipLaunchKernelGGL(search_group8_kernel<uint32_t>, grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel, d_tags,
-                               d_counters, cstride);
-        else
-            hipLaunchKernelGGL(search_group8_kernel<uint64_t>, grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel, d_tags,
-                               d_counters, cstride);
+        const bool three = (int64_t) rs->max_len - (int64_t) c->t * c->k + 1 > 64;   // mask words per strand and filter
+        if (c->k <= 32) {
+            if (three)
+                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                                   d_tags, d_counters, cstride);
+            else
+                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                                   d_tags, d_counters, cstride);
+        } else {
+            if (three)
+                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                                   d_tags, d_counters, cstride);
+            else
+                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                                   d_tags, d_counters, cstride);
+        }
         HIP_OK(hipGetLastError());
         return 0;
     }
@@ -1206,12 +1216,12 @@ bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
     return c->k >= 2 && nw >= 1 && (uint64_t) g * 2 * nw * 256 * 4 <= (64u << 10);
 }
 
-// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 64 first-hit windows per read in
+// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 96 first-hit windows per read in
 // registers (kernels.hpp); the probe-counting builds exist for groups of <= 4 only
 bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 {
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) c->t * c->k + 1;
-    return c->k >= 2 && !c->count_probes && first_hit_windows <= 64;
+    return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
 }
 
 }  // namespace

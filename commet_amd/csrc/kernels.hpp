@@ -694,11 +694,12 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
 // ---------------------------------------------------------------------------
 // Up to EIGHT chunk filters in one pass (A planes interleaved with stride 8: the eight words of a window are 32
 // contiguous bytes of one 64-byte sector, still one request).  For read sets whose first-hit windows number at most
-// 64 per read (len - t*k + 1 <= 64: 100-bp reads at k = 32, t = 2 have 37) the gathered lane-a bits live in REGISTERS,
+// 32 * MW per read (len - t*k + 1; MW = 2 or 3: 100-bp reads at k = 32, t = 2 have 37, 150-bp reads 87) the gathered
+// lane-a bits live in REGISTERS,
 // bit = window end - (k-1): no LDS at all, so the occupancy does not fall with the number of filters.  Replay = the
 // sparse replay of search_group_kernel, unrolled over the filters.  Sets of more than four chunks need half the passes.
 // ---------------------------------------------------------------------------
-template <typename W>
+template <typename W, int MW>
 __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, FilterGroupView fg, int k, int t,
                                                             const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                             unsigned long long *__restrict__ counters, uint32_t cstride)
@@ -725,11 +726,11 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
         const int sh = T::BITS - k;
         const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
         const int last = (int) len - 1;
-        const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 64
+        const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW
         const int q0 = k - 1;
-        uint32_t fm[2][GS], rm[2][GS];         // [half of the 64 relative positions][filter]
+        uint32_t fm[MW][GS], rm[MW][GS];       // [word of the 32 * MW relative positions][filter]
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < MW; ++h)
 #pragma unroll
             for (int i = 0; i < GS; ++i) fm[h][i] = 0, rm[h][i] = 0;
         // (1) gather
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
             };
             for (int pos = 0; pos < q0 && pos <= pe; ++pos) roll(pos);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < MW; ++h) {
                 for (int jj = 0; jj < 32; ++jj) {
                     const int q = q0 + 32 * h + jj;
                     if (q > pe) break;
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                     return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
                 };
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < MW; ++h) {
                     uint32_t m = strand ? rm[h][i] : fm[h][i];
                     while (m && !found && !dead) {
                         const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;

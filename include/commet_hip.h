@@ -170,7 +170,7 @@ int commet_index_and_search(commet_ctx *ctx,
  *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
- *                        for read sets with at most 64 first-hit windows per read, else 4)
+ *                        for read sets with at most 96 first-hit windows per read, else 4)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
  *   part_debug           timing ablations of scatter1 (tools/s1_ablate.py; leaves the filter unbuilt) */

@@ -1,5 +1,5 @@
 """A/B of an option (default: the two-lane index phase, index_lanes=2,1) on the BASELINE configs[1] job:
-  [AB_OPTION=part_packed AB_VALUES=1,0] python tools/lanes_ab.py [reads] [k]"""
+  [AB_OPTION=part_packed AB_VALUES=1,0] python tools/lanes_ab.py [reads] [k] [read length]"""
 import os
 import sys
 import time
@@ -16,8 +16,9 @@ VALUES = [int(x) for x in os.environ.get("AB_VALUES", "2,1").split(",")]
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    b0, o0 = synth.synth_set(0, n, 100)
-    b1, o1 = synth.synth_set(1, n, 100)
+    L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    b0, o0 = synth.synth_set(0, n, L)
+    b1, o1 = synth.synth_set(1, n, L)
     with commet_amd.Context(k=k, t=2) as ctx:
         s0 = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
         s1 = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
