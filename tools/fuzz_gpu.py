@@ -37,15 +37,16 @@ def main():
             rc, res, chunks, kmers = run_oracle(scn, os.path.join(d, "o"), os.path.join(d, "l"))
             assert rc == 0
             with commet_amd.Context(k=scn.k, t=scn.t) as ctx:
-                ctx.set_option("count_probes", 1)
+                counting = seed % 2 == 0           # the probe-counting builds keep groups <= 4 and the full replay
+                ctx.set_option("count_probes", int(counting))
                 ctx.set_option("index_mode", mode)
-                ctx.set_option("chunk_group", 1 + seed % 4)
+                ctx.set_option("chunk_group", 1 + seed % 8)
                 irs, isel = load_set(ctx, scn.sets[scn.index_name], scn.dir)
                 names = sorted(scn.search_names)
                 loaded = [load_set(ctx, scn.sets[nme], scn.dir) for nme in names]
                 tags, stats, info = ctx.index_and_search(irs, [x[0] for x in loaded], isel, [x[1] for x in loaded])
                 ok = info["n_chunks"] == chunks and info["kmers_indexed"] == kmers and \
-                    info["probes"] == sum(r["probes"] for r in res)
+                    (not counting or info["probes"] == sum(r["probes"] for r in res))
                 by = {r["name"]: r for r in res}
                 for nme, tg, st in zip(names, tags, stats):
                     o = by[nme]
