@@ -81,7 +81,6 @@ struct commet_ctx {
     bool have_index_ev = false, have_search_ev = false;
     bool count_probes = false;
     int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
-    int part_debug = 0;               // timing ablations of scatter1 (wrong results), tools only
     int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
     int part_packed = 1;              // option: final buckets as groups of three 19-bit keys in 8 bytes (index_part.hpp)
     int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
@@ -116,6 +115,7 @@ struct commet_ctx {
     int cur_slot = 0;                 // slot the index / search launch helpers work on
     uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
     int il_stride = 0;
+    uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
     int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
     struct IngestBuf {
@@ -281,6 +281,7 @@ int commet_min_hits(const commet_ctx *c) { return c->t; }
 
 uint64_t commet_max_kmer(const commet_ctx *c)
 {
+    if (c->max_kmer_test) return c->max_kmer_test;          // test hook, see commet_set_option
     return (uint64_t) (1000000000.0 / pow(2, 33 - c->k));   // index_and_search.cpp:73,146
 }
 
@@ -586,8 +587,38 @@ int ingest_piece(IngestShared &sh, const Piece &p, IngestStage st[2])
         have = true;
         return 0;
     };
+    // a record longer than a staging buffer (a contig or a genome used as a set: the reference takes any length) goes
+    // through a one-off pinned / device buffer pair of its own size
+    auto add_long_read = [&](const char *const *segs, const size_t *lens, int nseg, size_t total) -> int {
+        if (total > 0x7FFFFFFFull) return 2;
+        if (flush()) return 1;
+        IngestStage big;
+        int rc = 1;
+        if (hipSetDevice(sh.rs->ctx->device) == hipSuccess && hipHostMalloc((void **) &big.h_bases, total) == hipSuccess &&
+            hipHostMalloc((void **) &big.h_offs, 2 * sizeof(uint64_t)) == hipSuccess &&
+            hipMalloc((void **) &big.d_bases, total) == hipSuccess && hipMalloc((void **) &big.d_offs, 2 * sizeof(uint64_t)) == hipSuccess &&
+            hipEventCreateWithFlags(&big.done, hipEventDisableTiming) == hipSuccess) {
+            size_t at = 0;
+            for (int q = 0; q < nseg; ++q) {
+                memcpy(big.h_bases + at, segs[q], lens[q]);
+                at += lens[q];
+            }
+            big.h_offs[0] = 0, big.h_offs[1] = total;
+            if (commit_at(sh, big, 1, read_pos, base_pos) == 0 && hipEventSynchronize(big.done) == hipSuccess) {
+                read_pos += 1;
+                base_pos += total;
+                rc = 0;
+            }
+        }
+        if (big.h_bases) (void) hipHostFree(big.h_bases);
+        if (big.h_offs) (void) hipHostFree(big.h_offs);
+        (void) hipFree(big.d_bases);
+        (void) hipFree(big.d_offs);
+        if (big.done) (void) hipEventDestroy(big.done);
+        return rc;
+    };
     auto add_read = [&](const char *const *segs, const size_t *lens, int nseg, size_t total) -> int {
-        if (total > INGEST_STAGE_BASES) return 2;
+        if (total > INGEST_STAGE_BASES) return add_long_read(segs, lens, nseg, total);
         if (have && (nreads >= INGEST_STAGE_READS || used + total > INGEST_STAGE_BASES))
             if (flush()) return 1;
         if (!have && begin()) return 1;
@@ -787,6 +818,16 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
              hipMalloc((void **) &b.d_bases, INGEST_STAGE_BASES) == hipSuccess &&
              hipMalloc((void **) &b.d_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
              hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {   // a half-made entry must not stay in the pool: the next ingest would take its null pointers
+            if (b.h_bases) (void) hipHostFree(b.h_bases);
+            if (b.h_offs) (void) hipHostFree(b.h_offs);
+            (void) hipFree(b.d_bases);
+            (void) hipFree(b.d_offs);
+            if (b.done) (void) hipEventDestroy(b.done);
+            (void) hipGetLastError();
+            sh.err = "cannot allocate the ingest staging buffers";
+            break;
+        }
         c->ingest_pool.push_back(b);
     }
     for (size_t i = 0; ok && i < stages.size(); ++i) {
@@ -809,7 +850,7 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
                     const int rc = ingest_piece(sh, pieces[i], &stages[(size_t) t * 2]);
                     if (rc) {
                         std::lock_guard<std::mutex> lk(sh.mu);
-                        sh.err = rc == 2 ? "a read does not fit the staging buffer" : "upload failed";
+                        sh.err = rc == 2 ? "read longer than 2^31-1 bases" : "upload failed";
                         sh.failed = true;
                     }
                 }
@@ -944,7 +985,6 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     uint32_t *const slot = c->slot_ptr(c->cur_slot);
     PartGeom g = make_geom(c->k);
     g.xcd_swizzle = c->s2_swizzle;
-    g.debug = c->part_debug;
     g.packed = c->part_packed;
     if (c->part_b1 > 0 && c->part_b1 < g.nb_bits && c->part_b1 <= 8 && g.nb_bits - c->part_b1 <= 9) {
         g.b1 = c->part_b1;
@@ -1024,7 +1064,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
     }
-    if (g.debug & 31) return 0;   // timing ablations of scatter1 leave garbage in bufA: nothing downstream may consume it
+    if (COMMET_ABLATE & 31) return 0;   // ablation builds only: scatter1 left garbage in bufA, nothing downstream may consume it
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
@@ -1032,7 +1072,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
                            ws.off, g, ws.cur2, total);
         HIP_OK(hipGetLastError());
     }
-    if (g.debug) return 0;   // scatter2 ablations: bufB holds garbage
+    if (COMMET_ABLATE) return 0;   // ablation builds only: bufB holds garbage
     {
         const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
         if (grid >= (1ull << 24)) return fail("build launch too large");
@@ -1082,6 +1122,14 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
     return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed, lane);
 }
 
+// min_hits as the kernels get it: a read of max_len bases holds at most max_len / k non-overlapping k-mers, so every
+// t above max_len / k + 1 behaves like that value (never found, same probes); clamping keeps (t - seen - 1) * k and
+// last - (t - 1) * k inside 32-bit int whatever atoi handed to commet_create
+inline int t_eff(const commet_ctx *c, const commet_readset *rs)
+{
+    return (int) std::min<uint64_t>((uint64_t) c->t, (uint64_t) rs->max_len / (uint64_t) c->k + 1);
+}
+
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
                   unsigned long long *d_counters, unsigned long long *d_probes = nullptr)
 {
@@ -1092,17 +1140,17 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
     const bool cnt = d_probes != nullptr;
     if (c->k <= 32) {
         if (cnt)
-            hipLaunchKernelGGL((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+            hipLaunchKernelGGL((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
         else
-            hipLaunchKernelGGL((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+            hipLaunchKernelGGL((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
     } else {
         if (cnt)
-            hipLaunchKernelGGL((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+            hipLaunchKernelGGL((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
         else
-            hipLaunchKernelGGL((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, c->t, d_sel,
+            hipLaunchKernelGGL((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
     }
     HIP_OK(hipGetLastError());
@@ -1156,11 +1204,11 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
     const size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
     if (d_probes) {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, c->t, nw_max, d_sel, d_tags,
+        hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
                            d_counters, cstride, d_probes);
     } else {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        hipLaunchKernelGGL((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, c->t, nw_max, d_sel, d_tags,
+        hipLaunchKernelGGL((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
                            d_counters, cstride, d_probes);
     }
     HIP_OK(hipGetLastError());
@@ -1181,20 +1229,20 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
         const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
-        const bool three = (int64_t) rs->max_len - (int64_t) c->t * c->k + 1 > 64;   // mask words per strand and filter
+        const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;   // mask words per strand and filter
         if (c->k <= 32) {
             if (three)
-                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
             else
-                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
         } else {
             if (three)
-                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
             else
-                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, c->t, d_sel,
+                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
         }
         HIP_OK(hipGetLastError());
@@ -1220,7 +1268,7 @@ bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
 // registers (kernels.hpp); the probe-counting builds exist for groups of <= 4 only
 bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 {
-    const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) c->t * c->k + 1;
+    const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
 }
 
@@ -1613,8 +1661,9 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->chunk_group = (int) value;
         return 0;
     }
-    if (!strcmp(name, "part_debug")) {
-        c->part_debug = (int) value;
+    if (!strcmp(name, "max_kmer")) {          // chunk size in k-mers (0 = the reference's constant); changes the chunking
+        if (value < 0) return fail("max_kmer must be >= 0");
+        c->max_kmer_test = (uint64_t) value;
         return 0;
     }
     if (!strcmp(name, "index_lanes")) {       // 1 = the chunks of a group are built one after the other

@@ -30,6 +30,13 @@
 
 namespace commet {
 
+// Timing ablations (results become wrong on purpose) exist only in builds made with -DCOMMET_ABLATE=<mask>; the shipped
+// library compiles them out.  scatter1: 1 no write-out, 2 no pass B, 4 no pass-A atomics; scatter2: 32 no placement,
+// 64 no write-out, 128 no cursor reservation, 256 no counting.
+#ifndef COMMET_ABLATE
+#define COMMET_ABLATE 0
+#endif
+
 constexpr int      TILE_BITS = 19;
 constexpr uint32_t TILE_MASK = (1u << TILE_BITS) - 1;
 constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 KiB
@@ -54,8 +61,6 @@ struct PartGeom {
     uint32_t nb1;        // coarse buckets
     int      plane_shift;   // k - TILE_BITS: bucket = (plane << plane_shift) | (key >> TILE_BITS)
     int      xcd_swizzle;   // scatter2: slab order, number of interleaved slab ranges (speed only)
-    int      debug;         // timing ablations of scatter1 (results become wrong): 1 no write-out, 2 no pass B, 4 no pass-A atomics;
-                            // of scatter2: 32 no placement, 64 no write-out, 128 no cursor reservation, 256 no counting
     int      packed;        // final buckets hold groups of three 19-bit keys in 8 bytes (two-level geometry only)
 };
 
@@ -71,7 +76,6 @@ inline PartGeom make_geom(int k)
     g.nb1 = 1u << g.b1;
     g.plane_shift = k - TILE_BITS;
     g.xcd_swizzle = 0;
-    g.debug = 0;
     g.packed = 0;
     return g;
 }
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
                 if (WIDE)   // k <= 34: at most two bits above the low word
                     chi[jj >> 2] |= ((uint32_t) ((uint64_t) ka >> 32) | ((uint32_t) ((uint64_t) kb >> 32) << 2) | ((uint32_t) ((uint64_t) pa >> 32) << 4))
                                     << (6u * (jj & 3u));
-                if (ok && !(g.debug & 4)) {   // crk[] of other positions is never read
+                if (ok && !(COMMET_ABLATE & 4)) {   // crk[] of other positions is never read
                     cvalid |= 1u << jj;
                     const uint32_t r0 = atomicAdd(cnt + (uint32_t) (pa >> sA), 1u);
                     const uint32_t r1 = atomicAdd(cnt_b + (uint32_t) (kb >> sA), 1u);
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             gcur[threadIdx.x] = at + cnt[threadIdx.x];
         }
         // pass B: place every key at its bucket's base + its rank
-        if (ion && !(g.debug & 2)) {
+        if (ion && !(COMMET_ABLATE & 2)) {
             const uint32_t *const base_b = base + nbp, *const base_c = base + 2 * nbp, *const base_d = base + 3 * nbp;
 #pragma unroll
             for (uint32_t jj = 0; jj < 8; ++jj) {
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         __syncthreads();
         if (UNI) pre_claim();
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
-        if (!(g.debug & 1))
+        if (!(COMMET_ABLATE & 1))
         for (uint32_t c1 = wave * 4 + (lane >> 4); c1 < g.nb1; c1 += (NT / 64) * 4)
             write_run(out, gbase[c1], sorted, base[c1], cnt[c1], lane & 15u, 16u);
         __syncthreads();
@@ -718,25 +722,25 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
             const uint32_t i = threadIdx.x + NT * q;
-            if (i < n && !(g.debug & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+            if (i < n && !(COMMET_ABLATE & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, nsub, wsum);
         for (uint32_t i = threadIdx.x; i < nsub; i += NT) {
             const uint32_t c = cnt[i];
             const unsigned long long want = g.packed ? (c + 2) / 3 : c;   // packed: whole groups of three keys
-            gbase[i] = (c && !(g.debug & 128)) ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
+            gbase[i] = (c && !(COMMET_ABLATE & 128)) ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
         }
 #pragma unroll
         for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
             const uint32_t i = threadIdx.x + NT * q;
-            if (i < n && !(g.debug & 32)) {
+            if (i < n && !(COMMET_ABLATE & 32)) {
                 const uint32_t sb = key[q] >> TILE_BITS;
                 sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
             }
         }
         __syncthreads();
-        if (g.debug & 64) {
+        if (COMMET_ABLATE & 64) {
         } else if (g.packed) {
             for (uint32_t sb = wave * 2 + (lane >> 5); sb < nsub; sb += (NT / 64) * 2)
                 write_run_p3((uint2 *) out, gbase[sb], sorted, base[sb], cnt[sb], lane & 31u, 32u);

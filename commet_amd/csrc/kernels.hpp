@@ -545,8 +545,10 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                 }
 #pragma unroll
                 for (int i = 0; i < GS; ++i) {
-                    mask_at(i, 0, w) = fm[i];
-                    mask_at(i, 1, w) = rm[i];
+                    if (i < fg.g) {   // the dynamic LDS holds fg.g slots (launch_search_group_t), not GS
+                        mask_at(i, 0, w) = fm[i];
+                        mask_at(i, 1, w) = rm[i];
+                    }
                 }
             }
         }

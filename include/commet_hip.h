@@ -164,7 +164,8 @@ int commet_index_and_search(commet_ctx *ctx,
                             commet_job_info *info);
 
 /* ---- test / measurement hooks --------------------------------------------- */
-/* Tunables / diagnostics, by name.  Unknown names are an error.  None of them changes a result bit.
+/* Tunables / diagnostics, by name.  Unknown names are an error.  None of them changes a result bit, except the test
+ * hook max_kmer.
  *   count_probes (0/1)   the search kernels count the filter words the REFERENCE flow loads (P_ref)
  *   index_mode (0/1/2)   0 auto, 1 atomic-OR kernel, 2 bucketed (LDS-tile) construction
  *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
@@ -173,7 +174,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        for read sets with at most 96 first-hit windows per read, else 4)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
- *   part_debug           timing ablations of scatter1 (tools/s1_ablate.py; leaves the filter unbuilt) */
+ *   max_kmer             TEST HOOK: k-mers per index chunk instead of the reference's constant (0 = reference; the
+ *                        results are then those of a reference built with that constant, index_and_search.cpp:73) */
 int commet_set_option(commet_ctx *ctx, const char *name, int64_t value);
 /* Copies the filter to the host in the REFERENCE byte layout (byte key/2,
  * even keys 0x80/40/20/10, odd keys 0x08/04/02/01 for a/b/c/d,

@@ -1,0 +1,66 @@
+"""Runs the CPU checker's batch kernels (oracle_binding.Bloom) in worker PROCESSES, one index chunk each.
+TEST INFRASTRUCTURE ONLY.  A chunk's filter depends on that chunk's reads alone and a read's final tag is the OR of
+its per-chunk results (index_and_search.cpp:255-277: a read found in chunk c is merely skipped afterwards), so the
+chunks of a large index set can be replayed side by side; each worker builds one 2^(k-1)-byte filter.
+
+Workers are spawned (not forked: the parent holds a HIP context) and never touch the GPU; arrays travel as .npy
+files in a scratch directory."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+
+def chunks_from_counts(kc, max_kmer):
+    """Chunk read ranges [a, e) of a sequence of reads with kc[i] complete k-mers each, the reference's way
+    (index_reads.h:49,60): a chunk is full once its k-mers reach max_kmer; the look-ahead read e is dropped."""
+    out, n, i = [], len(kc), 0
+    pre = np.concatenate([[0], np.cumsum(kc, dtype=np.int64)])
+    while i < n:
+        e = int(np.searchsorted(pre, pre[i] + max_kmer, side="left"))     # first e with pre[e] - pre[i] >= max
+        e = min(max(e, i + 1), n)
+        out.append((i, e))
+        i = e + 1
+    return out
+
+
+def _one_chunk(args):
+    bases_npy, a, e, L, k, t, sample_npy = args
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import oracle_binding as ob
+    bases = np.load(bases_npy, mmap_mode="r")
+    sb = np.load(sample_npy)
+    f = ob.Bloom(k)
+    chunk = np.ascontiguousarray(bases[a * L: e * L])
+    fed = f.index(chunk, np.arange(e - a + 1, dtype=np.uint64) * np.uint64(L))
+    ns = sb.size // L
+    found, _ = f.search(t, sb, np.arange(ns + 1, dtype=np.uint64) * np.uint64(L))
+    f.close()
+    return fed, found.tobytes()
+
+
+def search_sample_over_chunks(scratch, tag, index_bases, L, chunks, k, t, sample_bases, workers=None):
+    """index_bases: uint8[n * L] of the reads that are fed (already restricted to the selected reads, in order);
+    chunks: [(a, e)] over those reads; sample_bases: uint8[m * L] query reads.  Returns (bool[m] found in any chunk,
+    [k-mers fed per chunk])."""
+    os.makedirs(scratch, exist_ok=True)
+    bnpy, snpy = os.path.join(scratch, tag + "_index.npy"), os.path.join(scratch, tag + "_sample.npy")
+    np.save(bnpy, np.asarray(index_bases, dtype=np.uint8))
+    np.save(snpy, np.asarray(sample_bases, dtype=np.uint8))
+    m = len(sample_bases) // L
+    jobs = [(bnpy, a, e, L, k, t, snpy) for a, e in chunks]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 8))
+    if len(jobs) == 1 or workers == 1:
+        res = [_one_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_one_chunk, jobs, chunksize=1)
+    found = np.zeros(m, dtype=bool)
+    for _, fb in res:
+        found |= np.unpackbits(np.frombuffer(fb, dtype=np.uint8), bitorder="little")[:m].astype(bool)
+    os.remove(bnpy)
+    os.remove(snpy)
+    return found, [fed for fed, _ in res]

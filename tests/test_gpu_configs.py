@@ -1,0 +1,224 @@
+"""BASELINE.json configs[2] (10 sets x 10 M reads, the full 10 x 10 matrix on one GPU) and a configs[3]-sized pair
+(2 x 50 M reads: 7 index chunks, searched in ONE pass by search_group8_kernel) at full size, plus the
+search_group8_kernel instantiations the smaller scenarios cannot reach (three mask words; 64-bit keys).
+
+Full-size parity, as the CPU checker allows it:
+  * bit-exact on a random SAMPLE of query reads, for every job of one pair chain J1 -> J2 -> J3 of the matrix
+    (Commet.py:186-240): the CPU checker builds the chunk filters of the WHOLE index set (chunk boundaries from its
+    own rule, index_reads.h:49,60; the chunks replayed in parallel processes, tests/oracle_pool.py) and replays
+    search_reads on the sample;
+  * size-independent properties: matrix invariants, J3 subset of J1, every grouping of the chunk filters
+    (chunk_group 1 = the reference's order ... 8) gives the same bits.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import oracle_pool
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(rng, n, n_first, n_rest):
+    return np.sort(np.concatenate([rng.choice(n // 4, n_first, replace=False),
+                                   n // 4 + rng.choice(n - n // 4, n_rest, replace=False)]))
+
+
+def _bits_at(bits, n, idx):
+    return util.bools_from_bits(bits, n)[idx]
+
+
+def _replay(scratch, tag, bases, L, sel_bools, kc, k, t, sample_bases):
+    """CPU checker: index the selected reads of `bases` chunk by chunk, search the sample; returns bool[m]"""
+    n = len(kc)
+    if sel_bools is None:
+        ib, ikc = bases, kc
+    else:
+        idx = np.flatnonzero(sel_bools)
+        ib = np.ascontiguousarray(bases.reshape(n, L)[idx]).reshape(-1)
+        ikc = kc[idx]
+    chunks = oracle_pool.chunks_from_counts(ikc, ob.max_kmer(k))
+    found, fed = oracle_pool.search_sample_over_chunks(scratch, tag, ib, L, chunks, k, t, sample_bases)
+    assert fed == [int(ikc[a:e].sum()) for a, e in chunks]
+    return found, len(chunks)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[2]: 10 synthetic sets x 10 M reads, full 10 x 10 matrix, one GPU
+# ---------------------------------------------------------------------------------------------------------------
+C3_N, C3_L, C3_SETS, C3_PAIR = 10_000_000, 100, 10, (3, 7)
+
+
+@pytest.fixture(scope="module")
+def c3(tmp_path_factory):
+    from commet_amd import build, matrix, synth
+    build.build_lib()
+    build.build_tools()
+    d = tmp_path_factory.mktemp("c3")
+    keep = {}
+    import multiprocessing as mp
+    with open(d / "sets.txt", "w") as fh:
+        for s in range(C3_SETS):
+            fh.write(f"S{s}: {d}/set{s}.fa\n")
+    # the sets are generated side by side in worker processes (spawned: no GPU state is inherited); the two sets of
+    # the pair that is replayed on the CPU checker are made here, where their bases are needed
+    with mp.get_context("spawn").Pool(min(8, max(1, (os.cpu_count() or 2) - 1))) as pool:
+        pending = pool.map_async(util.gen_set_fasta, [(s, C3_N, C3_L, str(d / f"set{s}.fa")) for s in range(C3_SETS)
+                                                       if s not in C3_PAIR], chunksize=1)
+        for s in C3_PAIR:
+            keep[s], _ = synth.synth_set(s, C3_N, C3_L)
+            synth.write_fasta_fast(str(d / f"set{s}.fa"), keep[s], C3_N, C3_L)
+        pending.get()
+    res = matrix.run(str(d / "sets.txt"), str(d / "out") + "/", k=32, t=2, verbose=False)
+    yield dict(dir=d, res=res, bases=keep)
+    for s in range(C3_SETS):
+        os.remove(d / f"set{s}.fa")
+
+
+def test_c3_matrix_invariants(c3):
+    res, N = c3["res"], C3_SETS
+    m, considered = res["matrix"], res["considered"]
+    assert considered == [C3_N] * N                                # filter_reads with -l 0 -e 0 keeps every read
+    for i in range(N):
+        assert m[i][i] == considered[i]
+        for j in range(N):
+            assert 0 <= m[i][j] <= considered[i]
+            if i != j:
+                # a quarter of every set derives from set 0's first reads (1 % substitutions each): most of them are
+                # shared, and almost nothing else is
+                assert 0.50 * C3_N / 4 < m[i][j] < 1.05 * C3_N / 4, (i, j, m[i][j])
+    out = str(c3["dir"] / "out")
+    assert sum(1 for f in os.listdir(out) if "_in_" in f and f.endswith(".bv")) == N * (N - 1)
+    # every matrix cell is the bit count of its .bv file (what Commet.py reads back through bvop -i, Commet.py:247-262)
+    for (a, b) in [(0, 9), (9, 0), C3_PAIR, C3_PAIR[::-1], (5, 4)]:
+        _, n, bits = util.read_bv(os.path.join(out, f"set{a}.fa_in_S{b}.bv"))
+        assert n == C3_N and int(util.bools_from_bits(bits, n).sum()) == m[a][b]
+    assert res["reads_searched"] == 3 * C3_N * N * (N - 1) // 2   # J1 + J2 + J3 of every pair, each over 10 M considered reads
+    assert res["world"] == 1 and res["jobs_s"] > 0
+
+
+def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
+    """J1, J2, J3 of one pair (ref, i), every job checked on a 20 000-read sample of its search set"""
+    import commet_amd
+    ref, i = C3_PAIR
+    k, t, n, L = 32, 2, C3_N, C3_L
+    b_ref, b_i = c3["bases"][ref], c3["bases"][i]
+    out = str(c3["dir"] / "out")
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        rs_ref = commet_amd.ReadSet.from_files(ctx, [(b_ref, offs)])
+        rs_i = commet_amd.ReadSet.from_files(ctx, [(b_i, offs)])
+        kc_ref, kc_i = rs_ref.kmer_counts(), rs_i.kmer_counts()
+        tags1, st1, inf1 = ctx.index_and_search(rs_ref, [rs_i])          # J1(ref, i) on its own
+    T1 = util.bools_from_bits(tags1[0], n)
+    _, n2, bits2 = util.read_bv(os.path.join(out, f"set{ref}.fa_in_S{i}.bv"))      # J2: S_ref in (S_i restricted to T1)
+    _, n3, bits3 = util.read_bv(os.path.join(out, f"set{i}.fa_in_S{ref}.bv"))      # J3: S_i in (S_ref restricted to T2)
+    T2, T3 = util.bools_from_bits(bits2, n2), util.bools_from_bits(bits3, n3)
+    assert n2 == n3 == n
+    assert not (T3 & ~T1).any()                                          # J3 indexes a subset of what J1 indexed
+    assert T3.sum() == c3["res"]["matrix"][i][ref] and T2.sum() == c3["res"]["matrix"][ref][i]
+    rng = np.random.default_rng(11)
+    smp_i, smp_ref = _sample(rng, n, 6000, 14000), _sample(rng, n, 6000, 14000)
+    sb_i = np.ascontiguousarray(b_i.reshape(n, L)[smp_i]).reshape(-1)
+    sb_ref = np.ascontiguousarray(b_ref.reshape(n, L)[smp_ref]).reshape(-1)
+    scratch = str(tmp_path)
+    f1, nch1 = _replay(scratch, "j1", b_ref, L, None, kc_ref, k, t, sb_i)
+    assert nch1 == inf1["n_chunks"] == 2
+    assert np.array_equal(T1[smp_i], f1)
+    f2, _ = _replay(scratch, "j2", b_i, L, T1, kc_i, k, t, sb_ref)         # index set restricted to J1's result
+    assert np.array_equal(T2[smp_ref], f2)
+    f3, _ = _replay(scratch, "j3", b_ref, L, T2, kc_ref, k, t, sb_i)
+    assert np.array_equal(T3[smp_i], f3)
+    assert f1.sum() > 4000 and f2.sum() > 4000 and f3.sum() > 4000      # the samples do contain shared reads
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one pair of configs[3]: 2 x 50 M reads, 7 index chunks -> search_group8_kernel<u32, 2>, one pass
+# ---------------------------------------------------------------------------------------------------------------
+def test_c4_sized_pair_seven_chunks(tmp_path):
+    import commet_amd
+    from commet_amd import synth
+    k, t, n, L = 32, 2, 50_000_000, 100
+    b0, o0 = synth.synth_set(0, n, L)
+    b1, o1 = synth.synth_set(1, n, L)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
+        del o0, o1
+        kc = irs.kmer_counts()
+        tags, stats, info = ctx.index_and_search(irs, [qrs])              # default: up to 8 chunk filters per pass
+        assert info["n_chunks"] == 7 and info["search_launches"] == 1
+        for group in (1, 4):                                              # the reference's order; the LDS-mask kernel
+            ctx.set_option("chunk_group", group)
+            tg, sg, ig = ctx.index_and_search(irs, [qrs])
+            assert ig["search_launches"] == (7 if group == 1 else 2)
+            assert np.array_equal(tg[0], tags[0]), group
+            assert (sg[0]["indexed"], sg[0]["searched"], sg[0]["shared"]) == \
+                (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]), group
+    found = util.bools_from_bits(tags[0], n)
+    assert stats[0]["shared"] == int(found.sum())
+    assert stats[0]["indexed"] == n - 6                                   # six look-ahead reads dropped
+    assert found[: n // 4].mean() > 0.85 and found[n // 4:].mean() < 0.02
+    rng = np.random.default_rng(5)
+    smp = _sample(rng, n, 6000, 14000)
+    sb = np.ascontiguousarray(b1.reshape(n, L)[smp]).reshape(-1)
+    del b1
+    want, nch = _replay(str(tmp_path), "c4", b0, L, None, kc, k, t, sb)
+    assert nch == 7
+    assert np.array_equal(found[smp], want)
+    assert want.sum() > 4000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# search_group8_kernel: three mask words (65..96 first-hit windows) and 64-bit keys, more than four chunks each
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,t,L,max_kmer,n_idx", [
+    (20, 1, 110, 0, 9000),          # 91 first-hit windows -> <u32, 3>; the reference's own chunk size (122 070 k-mers)
+    (24, 2, 140, 60000, 6000),      # 93 windows -> <u32, 3>
+    (33, 2, 100, 50000, 6000),      # 35 windows -> <u64, 2>
+    (34, 1, 128, 60000, 5000),      # 95 windows -> <u64, 3>
+    (33, 3, 150, 40000, 4000),      # 52 windows, t = 3 -> <u64, 2>
+])
+def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx):
+    """max_kmer != 0 uses the library's test hook (k-mers per chunk) so that k >= 33 gets more than four chunks from a
+    few thousand reads; the CPU checker is then chunked with the same constant."""
+    import commet_amd
+    rng = np.random.default_rng(1000 * k + L)
+    idx_reads = util.random_reads(rng, n_idx, L, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 12000, L, L, share=0.5, n_rate=0.002)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        if max_kmer:
+            ctx.set_option("max_kmer", max_kmer)
+        irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+        kc = irs.kmer_counts()
+        res = {}
+        for group in (8, 4, 1):
+            ctx.set_option("chunk_group", group)
+            res[group] = ctx.index_and_search(irs, [qrs])
+    chunks = oracle_pool.chunks_from_counts(kc, max_kmer or ob.max_kmer(k))
+    assert len(chunks) > 4
+    tags, stats, info = res[8]
+    assert info["n_chunks"] == len(chunks)
+    assert info["search_launches"] == (len(chunks) + 7) // 8               # the eight-filter kernel did run
+    found = np.zeros(len(q_reads) // 8 + 1, dtype=np.uint8)
+    searched_last = 0
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
+        active = ~found
+        searched_last = int(util.bools_from_bits(active, len(q_reads)).sum())
+        fnd, _ = f.search(t, qb, qo, active)
+        found |= fnd
+        f.close()
+    for group in (8, 4, 1):
+        tg, sg, _ = res[group]
+        assert np.array_equal(tg[0], found), group
+        assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
+        assert sg[0]["searched"] == searched_last and sg[0]["indexed"] == sum(e - a for a, e in chunks)
+    assert stats[0]["shared"] > 2000

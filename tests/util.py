@@ -192,3 +192,17 @@ def parse_reads(path):
         return parse_fasta(tmp)
     finally:
         os.remove(tmp)
+
+
+def gen_set_fasta(args):
+    """(set id, reads, read length, path): writes one synthetic set (commet_amd.synth) as FASTA.
+    Top-level so that a spawn pool can run it."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from commet_amd import synth
+    s, n, L, path = args
+    b, _ = synth.synth_set(s, n, L)
+    synth.write_fasta_fast(path, b, n, L)
+    return s
