@@ -140,6 +140,13 @@ class Context:
         self._check(self._lib.commet_last_kernel_ms(self._h, C.byref(i), C.byref(s)))
         return i.value, s.value
 
+    def kernel_times(self):
+        """{kernel: (launches, total_ms)} since set_option("kernel_timing", 1)"""
+        arr = (_l.KernelTime * 64)()
+        n = C.c_int(0)
+        self._check(self._lib.commet_kernel_times(self._h, arr, 64, C.byref(n)))
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 64))}
+
     def membench(self, atomic, table_bytes, n_access):
         ms = C.c_double(0)
         self._check(self._lib.commet_membench(self._h, int(atomic), int(table_bytes), int(n_access), C.byref(ms)))
@@ -167,6 +174,20 @@ class ReadSet:
         """Maps the FASTA files of one set (host parser in the library), streams them to HBM, finalizes."""
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
         h = ctx._lib.commet_readset_from_fasta(ctx._h, arr, len(paths))
+        if not h:
+            raise CommetError(_err(ctx._lib))
+        rs = cls(ctx, 0, 0, _handle=h)
+        rs.finalize()
+        return rs
+
+    def save(self, path):
+        """Writes the packed image of the set (commet_readset_save)."""
+        self._check(self._lib.commet_readset_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, ctx, path):
+        """Loads a packed image written by save() — no parsing; finalizes."""
+        h = ctx._lib.commet_readset_load(ctx._h, os.fsencode(path))
         if not h:
             raise CommetError(_err(ctx._lib))
         rs = cls(ctx, 0, 0, _handle=h)

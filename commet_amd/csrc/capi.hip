@@ -12,6 +12,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -115,6 +120,47 @@ struct commet_ctx {
     int cur_slot = 0;                 // slot the index / search launch helpers work on
     uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
     int il_stride = 0;
+    // option "kernel_timing": a hipEvent pair around every kernel launch of commet_index_and_search, on the stream the
+    // kernel is launched on; per-kernel totals are read with commet_kernel_times (bench.py's roofline leg)
+    struct KernelClock {
+        struct Rec { const char *name; hipEvent_t a, b; };
+        bool on = false;
+        std::vector<Rec> open;                         // launches of the current call
+        std::vector<hipEvent_t> spare;                 // events kept for the next call
+        std::vector<std::string> names;                // totals, in first-seen order
+        std::vector<uint64_t> launches;
+        std::vector<double> total_ms;
+        hipEvent_t get()
+        {
+            hipEvent_t e = nullptr;
+            if (!spare.empty()) e = spare.back(), spare.pop_back();
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        }
+        void collect()                                  // after the stream has been synchronised
+        {
+            for (Rec &r : open) {
+                float ms = 0;
+                if (r.a && r.b && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                    size_t i = 0;
+                    while (i < names.size() && names[i] != r.name) ++i;
+                    if (i == names.size()) names.push_back(r.name), launches.push_back(0), total_ms.push_back(0);
+                    launches[i] += 1;
+                    total_ms[i] += ms;
+                }
+                if (r.a) spare.push_back(r.a);
+                if (r.b) spare.push_back(r.b);
+            }
+            open.clear();
+        }
+        void reset() { names.clear(), launches.clear(), total_ms.clear(); }
+        void release()
+        {
+            collect();
+            for (hipEvent_t e : spare) (void) hipEventDestroy(e);
+            spare.clear();
+        }
+    } kclock;
     uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
     int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
@@ -167,7 +213,7 @@ struct commet_readset {
     mutable bool have_host_counts = false;
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
-    uint32_t max_len = 0;
+    uint32_t max_len = 0, min_len = 0;
     bool finalized = false;
 
     ReadsView view() const
@@ -180,6 +226,27 @@ struct commet_readset {
         return v;
     }
 };
+
+namespace {
+// times one kernel launch when option "kernel_timing" is on (no-op otherwise)
+struct KScope {
+    commet_ctx::KernelClock &kc;
+    hipStream_t stream;
+    size_t idx = ~(size_t) 0;
+    KScope(commet_ctx *c, const char *name, hipStream_t s) : kc(c->kclock), stream(s)
+    {
+        if (!kc.on) return;
+        commet_ctx::KernelClock::Rec r{name, kc.get(), kc.get()};
+        if (r.a) (void) hipEventRecord(r.a, stream);
+        idx = kc.open.size();
+        kc.open.push_back(r);
+    }
+    ~KScope()
+    {
+        if (idx != ~(size_t) 0 && kc.open[idx].b) (void) hipEventRecord(kc.open[idx].b, stream);
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -258,6 +325,7 @@ void commet_destroy(commet_ctx *c)
         (void) hipFree(b.d_offs);
         if (b.done) (void) hipEventDestroy(b.done);
     }
+    c->kclock.release();
     (void) hipFree(c->il_a);
     (void) hipFree(c->d_jobcnt);
     (void) hipFree(c->d_plansum);
@@ -903,6 +971,7 @@ int commet_readset_finalize(commet_readset *rs)
     if (rs->n_reads) HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
     rs->max_len = rs->n_reads ? mm[1] : 0;
+    rs->min_len = rs->n_reads ? mm[0] : 0;
     rs->max_kcnt = rs->n_reads ? mm[2] : 0;
     // the staging buffers are no longer needed: give the memory back
     for (int i = 0; i < 2; ++i) {
@@ -917,6 +986,125 @@ int commet_readset_finalize(commet_readset *rs)
     }
     rs->finalized = true;
     return 0;
+}
+
+/* ---- packed images of a read set (k-independent): parse once, load everywhere ---------------------------------- */
+namespace {
+struct PackHeader {
+    char     magic[8];          // "CMTPK01"
+    uint64_t n_reads, n_bases, triples, n_files, n_empty;
+    uint32_t uniform_len, min_len, max_len, pad;
+};
+inline uint64_t align64(uint64_t x) { return (x + 63) & ~63ull; }
+struct PackLayout {
+    uint64_t files_at, empty_at, planes_at, goff_at, total;
+    PackLayout(const PackHeader &h)
+    {
+        files_at = align64(sizeof(PackHeader));
+        empty_at = files_at + h.n_files * sizeof(FileSpan);
+        planes_at = align64(empty_at + h.n_empty * 8);
+        goff_at = align64(planes_at + h.triples * 12);
+        total = goff_at + (h.uniform_len ? 0 : (h.n_reads + 1) * 8);
+    }
+};
+}  // namespace
+
+int commet_readset_save(const commet_readset *rs, const char *path)
+{
+    if (!rs->finalized) return fail("read set not finalized");
+    commet_ctx *c = rs->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    PackHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "CMTPK01", 8);
+    h.n_reads = rs->n_reads, h.n_bases = rs->n_bases, h.triples = (rs->n_bases >> 5) + rs->n_reads + 1;
+    h.n_files = rs->files.size(), h.n_empty = rs->empty_reads.size();
+    h.uniform_len = rs->uniform_len, h.min_len = rs->min_len, h.max_len = rs->max_len;
+    const PackLayout lay(h);
+    const std::string tmp = std::string(path) + ".tmp";
+    const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
+    if (fd < 0) return fail("cannot create %s: %s", tmp.c_str(), strerror(errno));
+    if (ftruncate(fd, (off_t) lay.total) != 0) {
+        close(fd);
+        return fail("cannot size %s to %llu bytes: %s", tmp.c_str(), (unsigned long long) lay.total, strerror(errno));
+    }
+    uint8_t *m = (uint8_t *) mmap(nullptr, lay.total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail("cannot map %s: %s", tmp.c_str(), strerror(errno));
+    memcpy(m, &h, sizeof h);
+    if (h.n_files) memcpy(m + lay.files_at, rs->files.data(), h.n_files * sizeof(FileSpan));
+    if (h.n_empty) memcpy(m + lay.empty_at, rs->empty_reads.data(), h.n_empty * 8);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(m + lay.planes_at, rs->d_planes, h.triples * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && !h.uniform_len) e = hipMemcpy(m + lay.goff_at, rs->d_goff, (h.n_reads + 1) * 8, hipMemcpyDeviceToHost);
+    munmap(m, lay.total);
+    if (e != hipSuccess) {
+        unlink(tmp.c_str());
+        return fail("read set download failed: %s", hipGetErrorString(e));
+    }
+    if (rename(tmp.c_str(), path) != 0) return fail("cannot rename %s: %s", tmp.c_str(), strerror(errno));
+    return 0;
+}
+
+commet_readset *commet_readset_load(commet_ctx *c, const char *path)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        fail("cannot open %s: %s", path, strerror(errno));
+        return nullptr;
+    }
+    struct stat st;
+    PackHeader h;
+    if (fstat(fd, &st) != 0 || (uint64_t) st.st_size < sizeof h || pread(fd, &h, sizeof h, 0) != (ssize_t) sizeof h ||
+        memcmp(h.magic, "CMTPK01", 8) != 0) {
+        close(fd);
+        fail("%s is not a packed read set", path);
+        return nullptr;
+    }
+    const PackLayout lay(h);
+    if (h.triples != (h.n_bases >> 5) + h.n_reads + 1 || lay.total != (uint64_t) st.st_size) {
+        close(fd);
+        fail("%s: inconsistent packed read set", path);
+        return nullptr;
+    }
+    const uint8_t *m = (const uint8_t *) mmap(nullptr, lay.total, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        fail("cannot map %s: %s", path, strerror(errno));
+        return nullptr;
+    }
+    commet_readset *rs = commet_readset_create(c, h.n_reads, h.n_bases);
+    if (!rs) {
+        munmap((void *) m, lay.total);
+        return nullptr;
+    }
+    const FileSpan *fs = (const FileSpan *) (m + lay.files_at);
+    rs->files.assign(fs, fs + h.n_files);
+    const uint64_t *er = (const uint64_t *) (m + lay.empty_at);
+    rs->empty_reads.assign(er, er + h.n_empty);
+    rs->n_reads = h.n_reads;
+    rs->n_bases = h.n_bases;
+    const uint32_t mm[3] = {h.n_reads ? h.min_len : 0xFFFFFFFFu, h.max_len, 0u};
+    hipError_t e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
+    // the image is pageable memory: the copies below are staged by the runtime and return when the source has been read
+    if (e == hipSuccess) e = hipMemcpyAsync(rs->d_planes, m + lay.planes_at, h.triples * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !h.uniform_len)
+        e = hipMemcpyAsync(rs->d_goff, m + lay.goff_at, (h.n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && h.n_reads) {
+        ReadsView v = rs->view();
+        v.uniform_len = h.uniform_len;
+        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->stream, v, c->k, rs->d_kcnt,
+                           rs->d_lenmm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    munmap((void *) m, lay.total);
+    if (e != hipSuccess) {
+        fail("read set upload failed: %s", hipGetErrorString(e));
+        commet_readset_destroy(rs);
+        return nullptr;
+    }
+    return rs;
 }
 
 uint64_t commet_readset_num_reads(const commet_readset *rs) { return rs->n_reads; }
@@ -935,6 +1123,7 @@ int commet_readset_kmer_counts(const commet_readset *rs, uint32_t *out)
 int commet_filter_reset(commet_ctx *c)
 {
     HIP_OK(hipSetDevice(c->device));
+    KScope ks(c, "filter_memset", c->stream);
     HIP_OK(hipMemsetAsync(c->slot_ptr(c->cur_slot), 0, c->filter_bytes, c->stream));
     return 0;
 }
@@ -957,6 +1146,7 @@ int launch_index_atomic(commet_ctx *c, const commet_readset *rs, uint64_t first,
     if (count == 0) return 0;
     const uint64_t blocks = (count + 255) / 256;
     if (blocks >= (1ull << 24)) return fail("index launch too large (>= 2^32 reads in one chunk)");
+    KScope ks(c, "index_kernel", c->stream);
     if (c->k <= 32)
         hipLaunchKernelGGL(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
                            c->k, first, count, d_sel, d_fed);
@@ -1039,6 +1229,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             uint32_t *hist = ws.hist, *bcnt = ws.blockcnt;
             uint32_t nblk = grid1;
             void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt};
+            KScope ks(c, "part_hist_kernel", stream);
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
         }
     }
@@ -1046,12 +1237,16 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const bool lds_hist = (size_t) g.nb * 4 <= (128u << 10);   // stage the histogram in LDS (coalesced loads) when it fits
         const size_t lds = lds_hist ? (size_t) g.nb * 4 : 0;
         if (lds) HIP_OK(hipFuncSetAttribute((const void *) part_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        KScope ks(c, "part_scan_kernel", stream);
         hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
                            ws.cur2, ws.wl, ws.goff, lds_hist ? 1 : 0);
     }
     HIP_OK(hipGetLastError());
-    hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
-                       ws.blockoff);
+    {
+        KScope ks(c, "part_blockoff_kernel", stream);
+        hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
+                           ws.blockoff);
+    }
     HIP_OK(hipGetLastError());
     // scatter 1 (straight into the final buckets when there is a single level)
     uint32_t *level1_out = g.b2 ? ws.bufA : ws.bufB;
@@ -1062,14 +1257,18 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const uint32_t *kc = rs->d_kcnt;
         const unsigned long long *boff = ws.blockoff;
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
+        KScope ks(c, "part_scatter1_kernel", stream);
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
     }
     if (COMMET_ABLATE & 31) return 0;   // ablation builds only: scatter1 left garbage in bufA, nothing downstream may consume it
     if (g.b2) {
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
-        hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
-                           ws.off, g, ws.cur2, total);
+        {
+            KScope ks(c, "part_scatter2_kernel", stream);
+            hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
+                               ws.off, g, ws.cur2, total);
+        }
         HIP_OK(hipGetLastError());
     }
     if (COMMET_ABLATE) return 0;   // ablation builds only: bufB holds garbage
@@ -1077,13 +1276,17 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
         if (grid >= (1ull << 24)) return fail("build launch too large");
         if (zero_fill) {   // no memset happened: clear the tiles that several workgroups OR into
+            KScope ks(c, "part_zero_split_kernel", stream);
             hipLaunchKernelGGL(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, stream, ws.wl, g, slot);
             HIP_OK(hipGetLastError());
         }
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
-        hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), stream,
-                           ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
+        {
+            KScope ks(c, "part_build_kernel", stream);
+            hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), stream,
+                               ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
+        }
         HIP_OK(hipGetLastError());
     }
     return 0;
@@ -1138,6 +1341,7 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
     if (blocks >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
     const dim3 g((unsigned) blocks), b(256);
     const bool cnt = d_probes != nullptr;
+    KScope ks(c, "search_kernel", c->stream);
     if (c->k <= 32) {
         if (cnt)
             hipLaunchKernelGGL((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
@@ -1183,6 +1387,7 @@ int ensure_slots(commet_ctx *c, int g, int gs)
 int launch_interleave(commet_ctx *c, int g, int gs)
 {
     const uint64_t blocks = std::min<uint64_t>((c->plane_words + 255) / 256, 1u << 16);
+    KScope ks(c, "interleave_a_kernel", c->stream);
     if (gs == 2)
         hipLaunchKernelGGL(interleave_a_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
@@ -1202,6 +1407,7 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
 {
     const dim3 g((unsigned) ((rs->n_reads + 255) / 256)), b(256);
     const size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
+    KScope ks(c, "search_group_kernel", c->stream);
     if (d_probes) {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
@@ -1230,6 +1436,7 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     if (gs == 8) {   // register masks, no LDS (group8_ok)
         const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
         const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;   // mask words per strand and filter
+        KScope ks(c, "search_group8_kernel", c->stream);
         if (c->k <= 32) {
             if (three)
                 hipLaunchKernelGGL((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
@@ -1382,8 +1589,11 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             c->plansum_cap = nblk;
         }
         if (index_select && upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
-        hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt,
-                           index_select ? index_rs->d_sel : nullptr, index_rs->n_reads, c->d_plansum);
+        {
+            KScope ks(c, "block_kmer_sums_kernel", c->stream);
+            hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt,
+                               index_select ? index_rs->d_sel : nullptr, index_rs->n_reads, c->d_plansum);
+        }
         HIP_OK(hipGetLastError());
         blk_sums.resize(nblk);
         HIP_OK(hipMemcpyAsync(blk_sums.data(), c->d_plansum, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1496,7 +1706,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         }
         // two lanes: when every chunk of the group takes the bucketed construction (which writes all of its filter
         // slot itself), odd chunks are built on the second stream with the second workspace, beside the even ones
-        bool lanes = g > 1 && c->index_lanes > 1;
+        bool lanes = g > 1 && c->index_lanes > 1 && !c->kclock.on;   // per-kernel times are additive on one stream only
         for (int i = 0; i < g && lanes; ++i) {
             const Chunk &ch = plan.chunks[ci + i];
             lanes = ch.n_reads && would_partition(c, index_rs, ch.kmers);
@@ -1575,6 +1785,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 rc = fail("tag copy failed");
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    c->kclock.collect();
     lap(ph_wait);
 
     if (!rc) {
@@ -1661,6 +1872,14 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->chunk_group = (int) value;
         return 0;
     }
+    if (!strcmp(name, "kernel_timing")) {     // 1: time every kernel of the following commet_index_and_search calls (totals reset)
+        HIP_OK(hipSetDevice(c->device));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        c->kclock.collect();
+        c->kclock.on = value != 0;
+        if (value) c->kclock.reset();
+        return 0;
+    }
     if (!strcmp(name, "max_kmer")) {          // chunk size in k-mers (0 = the reference's constant); changes the chunking
         if (value < 0) return fail("max_kmer must be >= 0");
         c->max_kmer_test = (uint64_t) value;
@@ -1730,6 +1949,21 @@ int commet_last_kernel_ms(commet_ctx *c, double *index_ms, double *search_ms)
             HIP_OK(hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1));
             *search_ms = ms;
         }
+    }
+    return 0;
+}
+
+int commet_kernel_times(commet_ctx *c, commet_kernel_time *out, int cap, int *n_out)
+{
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->kclock.collect();
+    const int n = (int) c->kclock.names.size();
+    if (n_out) *n_out = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        snprintf(out[i].name, sizeof out[i].name, "%s", c->kclock.names[i].c_str());
+        out[i].launches = c->kclock.launches[i];
+        out[i].total_ms = c->kclock.total_ms[i];
     }
     return 0;
 }

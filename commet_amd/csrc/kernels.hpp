@@ -235,6 +235,30 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restri
     atomicMax(&len_minmax[2], cnt);   // largest per-read k-mer count of the set
 }
 
+// complete k-mers per read from the validity plane alone: a packed read set is independent of k, the counts are not
+// (commet_readset_load); also the set's largest count (len_minmax[2], as pack_reads_kernel leaves it)
+__global__ __launch_bounds__(256) void kmer_counts_kernel(ReadsView rv, int k, uint32_t *__restrict__ kcnt,
+                                                          uint32_t *__restrict__ len_minmax)
+{
+    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    if (r >= rv.n) return;
+    uint64_t t0;
+    uint32_t len;
+    read_extent(rv, r, t0, len);
+    const uint32_t *p = rv.planes + 3 * t0;
+    uint32_t run = 0, cnt = 0;
+    for (uint32_t w = 0; w * 32u < len; ++w) {
+        const uint32_t va = p[3 * w + 2];
+        const uint32_t nb = min(32u, len - w * 32u);
+        for (uint32_t j = 0; j < nb; ++j) {
+            run = ((va >> j) & 1u) ? run + 1 : 0;
+            cnt += (run >= (uint32_t) k);
+        }
+    }
+    kcnt[r] = cnt;
+    atomicMax(&len_minmax[2], cnt);
+}
+
 // sums[b] = k-mers of the selected reads (bitmap sel, 64 reads per word) among reads [b * 4096, (b + 1) * 4096):
 // what the host's selection planner walks instead of the reads (read_iter.hpp, plan_index_blocks)
 constexpr uint32_t PLAN_BLOCK_READS = 4096;

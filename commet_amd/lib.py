@@ -26,6 +26,10 @@ class JobInfo(C.Structure):
                 ("index_kernel_ms", C.c_double), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
 # name -> (restype, argtypes); the test-suite checks that every symbol declared
 # in include/commet_hip.h is exported by the library and listed here.
 SIGNATURES = {
@@ -46,6 +50,8 @@ SIGNATURES = {
     "commet_readset_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_readset_from_fasta": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int]),
     "commet_readset_from_buffers": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_char_p), u64p, C.c_int]),
+    "commet_readset_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "commet_readset_load": (C.c_void_p, [C.c_void_p, C.c_char_p]),
     "commet_readset_file_reads": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "commet_readset_finalize": (C.c_int, [C.c_void_p]),
     "commet_readset_num_reads": (C.c_uint64, [C.c_void_p]),
@@ -60,6 +66,7 @@ SIGNATURES = {
     "commet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "commet_filter_export_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_last_kernel_ms": (C.c_int, [C.c_void_p, f64p, f64p]),
+    "commet_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
     "commet_membench": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, f64p]),
     "commet_ldsbench": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, f64p]),
 }

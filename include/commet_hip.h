@@ -94,6 +94,13 @@ uint64_t        commet_readset_file_reads(const commet_readset *rs, uint64_t fil
 /* Ends loading: waits for the uploads, fetches the per-read counts of complete
  * k-mers (what index_reads.h:55-57 would feed) needed for exact chunking. */
 int             commet_readset_finalize(commet_readset *rs);
+/* Packed image of a finalized read set (the bit-planes as they lie in HBM + file spans; independent of k): written
+ * once by whoever parsed the files, loaded by every other context that needs the set — other GPUs of the node in the
+ * N x N driver (one parse per set instead of one per GPU), or a later process.  load returns a set that still has to
+ * be finalized; its per-read k-mer counts are recomputed on the device for the loading context's k.  The reference
+ * has no counterpart: every index_and_search process re-parses its files (file_manager.h:117-171). */
+int             commet_readset_save(const commet_readset *rs, const char *path);
+commet_readset *commet_readset_load(commet_ctx *ctx, const char *path);
 uint64_t        commet_readset_num_reads(const commet_readset *rs);
 uint64_t        commet_readset_num_files(const commet_readset *rs);
 /* kmers_out[n_reads]: complete k-mers of each read (valid after finalize) */
@@ -174,6 +181,7 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        for read sets with at most 96 first-hit windows per read, else 4)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
+ *   kernel_timing (0/1)  time every kernel launch of commet_index_and_search (commet_kernel_times)
  *   max_kmer             TEST HOOK: k-mers per index chunk instead of the reference's constant (0 = reference; the
  *                        results are then those of a reference built with that constant, index_and_search.cpp:73) */
 int commet_set_option(commet_ctx *ctx, const char *name, int64_t value);
@@ -184,6 +192,15 @@ int commet_filter_export_reference(commet_ctx *ctx, uint8_t *out, uint64_t out_b
 /* Device time in ms of the most recent index / search kernel launch on this
  * ctx, measured with hipEvents on the ctx's stream (synchronises). */
 int commet_last_kernel_ms(commet_ctx *ctx, double *index_ms, double *search_ms);
+/* Per-kernel device times of the commet_index_and_search calls made since option "kernel_timing" was set to 1:
+ * a hipEvent pair around every launch, on the stream the kernel runs on (the chunks of a group are then built on
+ * one stream, so that the durations add up).  Fills at most cap entries, *n_out = kernels seen.  Synchronises. */
+typedef struct {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+} commet_kernel_time;
+int commet_kernel_times(commet_ctx *ctx, commet_kernel_time *out, int cap, int *n_out);
 /* Random 4-byte-gather / atomic-OR microbenchmarks over a table of
  * table_bytes (practical random-access ceilings): n_access
  * accesses, returns elapsed device ms in *ms.  atomic: 0 plain gather, 1 atomic
