@@ -14,17 +14,30 @@ meet at the barriers around the timed region (gloo; the GPU work never touches
 torch) and value = all ranks' reads / the slowest rank's time.
 
 The JSON line also carries
-  roofline     — the dominant kernel (largest share of device time) priced in
-                 ALGORITHMIC bytes against the 8 TB/s HBM peak,
-                 durations from hipEvents on the stream the kernels run on
+  roofline     — the kernel with the largest measured share of the step's device
+                 time (a hipEvent pair around every launch, commet_kernel_times,
+                 taken in untimed extra steps), priced in the HBM bytes it really
+                 moves: rocprofv3 FETCH_SIZE + WRITE_SIZE per launch from the
+                 committed profile of this workload (profiles/*/traffic.json,
+                 marked stale when the kernel sources changed since) over the
+                 live launch duration, against the 8 TB/s peak: frac <= 1.
+                 request_rate prices the same kernel in 64-byte memory requests
+                 against the random-gather ceiling measured in this run
+                 (commet_membench); whole_step sums every kernel.  The figure in
+                 reference probes (P_ref x 64 B) stays in `detail`.
   cpu_baseline — the reference CPU tool (oracle/_ref, kind "reference") or our
                  C restatement (oracle/, kind "port") on a bounded sample of the
-                 same synthetic sets, one core.
+                 same synthetic sets: one copy, and one copy per host core.
+  detail.matrix — BASELINE configs[2] (10 sets x 10 M reads, the 10 x 10 matrix)
+                 through commet_amd.matrix split over the N ranks, filter and
+                 load times included (--no-matrix skips it).
 """
 import argparse
+import hashlib
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -46,13 +59,32 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-t", type=int, default=2)
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads per set of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads per set of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-probe-count", action="store_true", help="skip the extra (untimed) P_ref counting step")
+    ap.add_argument("--no-kernel-times", action="store_true", help="skip the extra (untimed) per-kernel timing steps")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the configs[2] matrix leg (detail.matrix)")
+    ap.add_argument("--matrix-sets", type=int, default=10)
+    ap.add_argument("--matrix-reads", type=int, default=10_000_000)
     return ap.parse_args()
 
 
-def cpu_baseline(args, b0, o0, b1, o1):
-    """Times the reference CPU path on the first `cpu_sample` reads of both sets (rank 0, N=1 only)."""
+def host_cores():
+    """CPUs this process may really use: the cgroup quota when there is one, else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(args, b0, b1):
+    """Times the reference CPU path on the first `cpu_sample` reads of both sets (rank 0, N=1 only): one copy alone,
+    then one independent copy per host core (P = 1 and P = all, P stated)."""
     n = min(args.cpu_sample, args.reads)
     if n <= 0:
         return None
@@ -60,42 +92,73 @@ def cpu_baseline(args, b0, o0, b1, o1):
     L = args.read_len
     work = tempfile.mkdtemp(prefix="commet_cpu_")
     try:
-        synth.write_fasta(os.path.join(work, "s0.fa"), b0[: n * L], o0[: n + 1])
-        synth.write_fasta(os.path.join(work, "s1.fa"), b1[: n * L], o1[: n + 1])
-        open(os.path.join(work, "i.txt"), "w").write("s0:s0.fa\n")
-        open(os.path.join(work, "s.txt"), "w").write("s1:s1.fa\n")
+        synth.write_fasta_fast(os.path.join(work, "s0.fa"), b0[: n * L], n, L)
+        synth.write_fasta_fast(os.path.join(work, "s1.fa"), b1[: n * L], n, L)
+        open(os.path.join(work, "i.txt"), "w").write(f"s0:{work}/s0.fa\n")
+        open(os.path.join(work, "s.txt"), "w").write(f"s1:{work}/s1.fa\n")
         ref = os.path.join(ROOT, "oracle", "_ref", "index_and_search")
         if os.path.exists(ref):
             kind, tool = "reference", ref
         else:
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_build/oracle_cli"], check=True)
             kind, tool = "port", os.path.join(ROOT, "oracle", "_build", "oracle_cli")
-        t0 = time.time()
-        subprocess.run([tool, "-i", "i.txt", "-s", "s.txt", "-o", "out", "-l", "log", "-k", str(args.k), "-t", str(args.t)],
-                       cwd=work, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        wall = time.time() - t0
-        hot = None
-        if kind == "reference":      # its own clock() around index_reads / search_reads (index_and_search.cpp:252-300)
-            lines = open(os.path.join(work, "log", "s1_in_s0.log")).read().split("\n")
-            hot = float(lines[0].split()[2]) + float(lines[1].split()[2])
-        secs = hot if hot else wall
-        return {"value": round(n / secs, 1), "unit": "reads/s", "cores": 1, "kind": kind,
-                "sample": f"first {n} reads of each of the 2 synthetic sets, k={args.k} t={args.t}; "
-                          f"{'tool-reported index+search CPU time' if hot else 'wall time of the tool'} {secs:.2f} s "
-                          f"(whole process wall {wall:.2f} s)"}
+
+        def copies(p):
+            """p concurrent copies; returns [(seconds of the hot path, wall seconds)] per copy"""
+            procs, t0 = [], time.time()
+            for c in range(p):
+                d = os.path.join(work, f"run{p}_{c}")
+                os.makedirs(d)
+                procs.append((d, subprocess.Popen([tool, "-i", os.path.join(work, "i.txt"), "-s", os.path.join(work, "s.txt"), "-o", "out",
+                                                   "-l", "log", "-k", str(args.k), "-t", str(args.t)], cwd=d,
+                                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+            out = []
+            for d, pr in procs:
+                if pr.wait() != 0:
+                    raise RuntimeError("CPU baseline tool failed")
+                wall = time.time() - t0
+                hot = None
+                if kind == "reference":      # its own clock() around index_reads / search_reads (index_and_search.cpp:252-300)
+                    lines = open(os.path.join(d, "log", "s1_in_s0.log")).read().split("\n")
+                    hot = float(lines[0].split()[2]) + float(lines[1].split()[2])
+                out.append((hot if hot else wall, wall))
+            return out
+
+        one = copies(1)[0]
+        P = host_cores()
+        many = copies(P) if P > 1 else [one]
+        rate_all = sum(n / hot for hot, _ in many)
+        return {"value": round(rate_all, 1), "unit": "reads/s", "cores": P, "kind": kind,
+                "value_1core": round(n / one[0], 1),
+                "sample": f"first {n} reads of each of the 2 synthetic sets ({100.0 * n / args.reads:.0f} % of the job), k={args.k} t={args.t}; "
+                          f"1 copy: {'tool-reported index+search CPU time' if kind == 'reference' else 'wall time'} {one[0]:.2f} s (process wall {one[1]:.2f} s); "
+                          f"{P} independent copies at once (one per host core of this box's cgroup): sum of the copies' own rates, "
+                          f"slowest copy {max(h for h, _ in many):.2f} s, wall {max(w for _, w in many):.2f} s"}
     finally:
-        subprocess.run(["rm", "-rf", work])
+        shutil.rmtree(work, ignore_errors=True)
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC profile of this very workload
-    (profiles/<dir>/traffic.json written by tools/pmc_summary.py next to the bench.json it was taken with).
-    PMC counters cannot be collected from inside the timed run; None when no matching profile exists."""
+def source_hash():
+    """hash of the device-code sources: a traffic.json taken from another version of the kernels is marked stale"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "commet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload):
+    """Per-kernel HBM bytes per launch from the newest committed rocprofv3 PMC profile of this very workload
+    (profiles/<dir>/traffic.json, written by tools/pmc_summary.py next to the bench.json it was taken with); PMC
+    counters cannot be collected from inside the timed run.  Returns (table, path, stale) or None."""
     pdir = os.path.join(ROOT, "profiles")
-    best = None
+
     def natural(name):   # r01_v10 after r01_v9
         return [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", name)]
 
+    best, cur = None, source_hash()
     for d in sorted(os.listdir(pdir), key=natural) if os.path.isdir(pdir) else []:
         tj, bj = os.path.join(pdir, d, "traffic.json"), os.path.join(pdir, d, "bench.json")
         if not (os.path.exists(tj) and os.path.exists(bj)):
@@ -103,12 +166,52 @@ def measured_traffic(workload, kernel):
         try:
             if json.load(open(bj))["config"]["workload"] != workload:
                 continue
-            e = json.load(open(tj)).get(kernel)
-            if e and "hbm_bytes_per_launch" in e:
-                best = (e["hbm_bytes_per_launch"], f"profiles/{d}/traffic.json")
+            table = json.load(open(tj))
+            meta = table.get("_meta", {})
+            cand = (table, f"profiles/{d}/traffic.json", meta.get("source_hash") != cur)
+            if best is None or not cand[2] or best[2]:      # prefer a profile of these very sources, else the newest
+                best = cand
         except Exception:
             continue
     return best
+
+
+def matrix_leg(args, ranks):
+    """BASELINE configs[2] through the resident N x N driver, split over the ranks; sets written as FASTA to scratch
+    (each rank generates its share), filter + load + jobs all timed by the driver."""
+    from commet_amd import matrix, synth
+    root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
+    token = ranks.broadcast_object(f"commet_bench_{os.getuid()}_{os.getpid()}" if ranks.rank == 0 else None)
+    work = os.path.join(root, token)
+    os.makedirs(work, exist_ok=True)
+    S, n, L = args.matrix_sets, args.matrix_reads, args.read_len
+    t0 = time.perf_counter()
+    mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
+    if mine:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(len(mine), max(1, host_cores() // 2))) as pool:
+            pool.map(synth.write_set_fasta, mine, chunksize=1)
+    if ranks.rank == 0:
+        with open(os.path.join(work, "sets.txt"), "w") as fh:
+            for s in range(S):
+                fh.write(f"S{s}: {work}/set{s}.fa\n")
+    ranks.barrier()
+    gen_s = time.perf_counter() - t0
+    try:
+        res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False)
+    finally:
+        ranks.barrier()
+        if ranks.rank == 0:
+            shutil.rmtree(work, ignore_errors=True)
+    if res is None:
+        return None
+    keep = ("filter_s", "load_s", "jobs_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world")
+    out = {f: (round(res[f], 4) if isinstance(res[f], float) else res[f]) for f in keep}
+    out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix (BASELINE configs[2]) over {ranks.world} GPU(s): "
+                        f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",
+               generate_s=round(gen_s, 2),
+               per_rank=[{f: (round(v, 4) if isinstance(v, float) else v) for f, v in p.items()} for p in res["per_rank"]])
+    return out
 
 
 def main():
@@ -135,12 +238,6 @@ def main():
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up      # PCIe + packing of both sets (reported, never part of `value`)
 
-    probes = None
-    if not args.no_probe_count:
-        ctx.set_option("count_probes", 1)     # untimed: P_ref for the search kernel's algorithmic bytes
-        _, _, inf = ctx.index_and_search(irs, [qrs])
-        probes = inf["probes"]
-        ctx.set_option("count_probes", 0)
     for _ in range(args.warmup):
         ctx.index_and_search(irs, [qrs])
 
@@ -156,41 +253,93 @@ def main():
     elapsed = sharding.timed_region(ranks, ctx.synchronize, step, args.steps)
     stats, info = last["stats"], last["info"]
 
+    # ---- untimed extras (rank 0): P_ref, per-kernel times, the random-gather ceiling ---------------------------
+    probes, ktimes, gather_ceiling = None, None, None
+    if rank == 0:
+        if not args.no_probe_count:
+            ctx.set_option("count_probes", 1)     # P_ref of the reference's control flow, detail only
+            _, _, inf = ctx.index_and_search(irs, [qrs])
+            probes = inf["probes"]
+            ctx.set_option("count_probes", 0)
+        if not args.no_kernel_times:
+            KT_STEPS = 3
+            ctx.set_option("kernel_timing", 1)    # hipEvent pair around every launch, on the launching stream
+            for _ in range(KT_STEPS):
+                ctx.index_and_search(irs, [qrs])
+            ktimes = {name: dict(launches_per_step=cnt / KT_STEPS, avg_launch_ms=ms / max(cnt, 1), ms_per_step=ms / KT_STEPS)
+                      for name, (cnt, ms) in ctx.kernel_times().items()}
+            ctx.set_option("kernel_timing", 0)
+            acc_n = 1 << 31
+            gather_ceiling = acc_n / (ctx.membench(0, ctx_filter_bytes(k), acc_n) * 1e-3)    # random 4-B gathers per second
+
+    irs.close()
+    qrs.close()
+    ctx.close()
+
+    matrix_detail = None
+    if not args.no_matrix and args.matrix_sets >= 2:
+        matrix_detail = matrix_leg(args, ranks)
+
     if rank == 0:
         steps = args.steps
         ms_per_step = elapsed * 1000.0 / steps
         value = world * n * steps / elapsed
-        # ---- roofline of the dominant kernel, algorithmic bytes per launch ----
-        kmers = info["kmers_indexed"]
-        idx_bytes_step = info["reads_indexed"] * (L / 4.0) + 4.0 * kmers * 2 * SECTOR
-        srch_bytes_step = None
-        if probes is not None:
-            srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR
-        idx_ms = acc["index_kernel_ms"] / steps
-        srch_ms = acc["search_ms"] / steps
-        # dominant KERNEL: the index phase of one chunk is a chain of >= 3 comparable streaming kernels (scatter1,
-        # scatter2, build; see profiles/), the search phase is one kernel per launch
-        idx_per_kernel = idx_ms / max(acc["index_launches"] / steps, 1) / 3.0
-        srch_per_kernel = srch_ms / max(acc["search_launches"] / steps, 1)
-        if srch_bytes_step is None or idx_per_kernel > srch_per_kernel:
-            name, kms, kbytes, launches = "index_kernel", idx_ms, idx_bytes_step, acc["index_launches"] / steps
-        else:
-            name = "search_group_kernel" if acc["search_launches"] / steps < info["n_chunks"] else "search_kernel"
-            kms, kbytes, launches = srch_ms, srch_bytes_step, acc["search_launches"] / steps
-        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
                     f"per GPU (BASELINE configs[1]), inputs resident in HBM")
-        tr = measured_traffic(workload, name)
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr[0] if tr else None,
-                    "traffic_source": tr[1] if tr else None,
-                    # as executed: measured HBM bytes of the launch over its measured duration, against the same peak
-                    "traffic_GBps": round(tr[0] / (kms / max(launches, 1) * 1e-3) / 1e9, 1) if tr and kms > 0 else None,
-                    "traffic_frac": round(tr[0] / (kms / max(launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and kms > 0 else None,
-                    "launches_per_step": launches, "avg_launch_ms": round(kms / max(launches, 1), 3),
-                    "algorithmic_bytes_per_launch": round(kbytes / max(launches, 1)),
-                    "note": "algorithmic bytes = reference probes x 64-B sectors (SURVEY 8d); frac > 1 or traffic < algorithmic "
-                            "means one HBM request serves several reference probes (strand-paired, chunk-interleaved plane A)"}
+        kmers = info["kmers_indexed"]
+        idx_ms = acc["index_kernel_ms"] / steps
+        srch_ms = acc["search_ms"] / steps
+        roofline = None
+        if ktimes:
+            tr = measured_traffic(workload)
+            table, tr_path, stale = tr if tr else ({}, None, None)
+            step_dev_ms = sum(e["ms_per_step"] for e in ktimes.values())
+            dom = max(ktimes, key=lambda nme: ktimes[nme]["ms_per_step"])
+            e = ktimes[dom]
+
+            def hbm_bytes(nme):
+                x = table.get(nme)
+                return x.get("hbm_bytes_per_launch") if x else None
+
+            tb = hbm_bytes(dom)
+            achieved = tb / (e["avg_launch_ms"] * 1e-3) / 1e9 if tb else None
+            step_bytes, covered = 0.0, True
+            for nme, ee in ktimes.items():
+                x = hbm_bytes(nme)
+                if x is None:
+                    covered = covered and ee["ms_per_step"] < 0.01 * step_dev_ms     # tiny kernels may be missing from the profile
+                else:
+                    step_bytes += x * ee["launches_per_step"]
+            fetch = (table.get(dom) or {}).get("fetch_bytes_per_launch")
+            roofline = {
+                "bound": "hbm", "kernel": dom, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                # as executed: HBM bytes of one launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/) over its live duration
+                "achieved": round(achieved, 1) if achieved else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "traffic": tb, "traffic_source": tr_path, "traffic_stale": stale,
+                "avg_launch_ms": round(e["avg_launch_ms"], 4), "launches_per_step": e["launches_per_step"],
+                "time_share": round(e["ms_per_step"] / step_dev_ms, 4),
+                "request_rate": None, "whole_step": None,
+                "kernels": {nme: {"ms_per_step": round(ee["ms_per_step"], 4), "launches_per_step": ee["launches_per_step"],
+                                  "hbm_bytes_per_launch": hbm_bytes(nme),
+                                  "frac": round(hbm_bytes(nme) / (ee["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm_bytes(nme) and ee["avg_launch_ms"] > 0 else None}
+                            for nme, ee in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+                "note": "durations: hipEvents around every launch in untimed extra steps (one index lane, so they add up); "
+                        "bytes: rocprofv3 PMC passes of this workload (gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py)",
+            }
+            if fetch and gather_ceiling and dom.startswith("search"):
+                rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
+                roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),
+                                            "frac": round(rps / gather_ceiling, 4),
+                                            "what": "64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against commet_membench's "
+                                                    "random 4-byte gathers over a filter-sized table, measured in this run"}
+            if step_bytes and covered:
+                roofline["whole_step"] = {"traffic": round(step_bytes), "device_ms": round(step_dev_ms, 3),
+                                          "GBps": round(step_bytes / (step_dev_ms * 1e-3) / 1e9, 1),
+                                          "frac": round(step_bytes / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the contract's figure in REFERENCE probes, kept as detail: one request of ours answers several of them
+        idx_bytes_step = info["reads_indexed"] * (L / 4.0) + 4.0 * kmers * 2 * SECTOR
+        srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR if probes is not None else None
         out = {
             "metric": "reads/sec searched (index_and_search, k=%d)" % k,
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -204,19 +353,23 @@ def main():
                        "shared": stats[0]["shared"], "searched_last_pass": stats[0]["searched"],
                        "index_kernel_ms": round(idx_ms, 3), "search_kernel_ms": round(srch_ms, 3),
                        "filter_zero_ms": round(acc["zero_ms"] / steps, 3),
-                       "index_alg_GBps": round(idx_bytes_step / (idx_ms * 1e-3) / 1e9, 1) if idx_ms else None,
-                       "search_alg_GBps": round(srch_bytes_step / (srch_ms * 1e-3) / 1e9, 1) if srch_bytes_step and srch_ms else None,
-                       "p_ref_probes": probes, "upload_and_pack_s": round(upload_s, 3),
-                       "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1)},
+                       "p_ref_probes": probes,
+                       "reference_model_bytes_per_step": {"index": round(idx_bytes_step), "search": round(srch_bytes_step) if srch_bytes_step else None,
+                                                          "note": "SURVEY 8d's sector model of the REFERENCE's accesses; not what this implementation moves"},
+                       "upload_and_pack_s": round(upload_s, 3),
+                       "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
+                       "matrix": matrix_detail},
         }
         if world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, b0, o0, b1, o1)
+            out["cpu_baseline"] = cpu_baseline(args, b0, b1)
         print(json.dumps(out), flush=True)
 
-    irs.close()
-    qrs.close()
-    ctx.close()
     ranks.close()
+
+
+def ctx_filter_bytes(k):
+    """table size of the gather microbenchmark: the filter's own size, at least 128 MiB (well past L2)"""
+    return max(1 << (k - 1), 128 << 20)
 
 
 if __name__ == "__main__":

@@ -1,18 +1,25 @@
 """N x N comparison driver with set residency — the MI355X counterpart of Commet.py's
-local mode (reference: Commet.py:438-598), SURVEY 8f-2.
+local mode (reference: Commet.py:438-598), SURVEY 8f-2 / 8e.
 
 Commet.py runs N^2-1 `index_and_search` processes one after the other; every one re-parses
 its FASTA files and re-creates its filter, which on a GPU means a HIP start-up, a re-upload
-and a 16 GB scratch allocation per job.  Here every rank parses and uploads each set ONCE,
-keeps it packed in HBM, and runs its share of the job DAG in-process through the C ABI:
+and a 16 GB scratch allocation per job.  Here the job DAG runs in-process through the C ABI
+on sets that stay packed in HBM:
 
     for ref < i :   J1  index S_ref                          search S_i      -> T1
                     J2  index S_i   restricted to T1         search S_ref    -> <G>_in_<S_i>.bv
                     J3  index S_ref restricted to J2's bits  search S_i      -> <F>_in_<S_ref>.bv
 
-(J1 of one `ref` is run once per rank for all of the rank's `i`, as Commet.py does.)
-Ranks are independent: pairs (ref, i) are dealt out, no collective touches read data; only
-the per-pair counts are gathered (host, gloo) for the three CSV matrices.
+One process per GPU (torch.distributed.run).  The path has no exchange step, so ranks share
+nothing but files and three host-side gathers (gloo):
+  * every set is PARSED ONCE on the node: set s by rank s % world, which leaves its packed
+    image (commet_readset_save: the bit-planes as they lie in HBM) in a scratch directory
+    (/dev/shm); the other ranks that need the set load that image — a memcpy and an upload,
+    no parsing;
+  * the row-major list of (ref, i) pairs is cut into contiguous runs of equal cost, one per
+    rank: a rank works on few reference sets, builds J1's index of S_ref once for all its
+    targets (as Commet.py's J1 does), and loads only the sets its pairs touch;
+  * a rank that fails exits non-zero at once (the launcher then ends the group).
 
 Same inputs and outputs as Commet.py: the set file `name: file[,bv]; file…`, the filter
 step (`filter_reads`, skipped when bvs are given), `OUT/<file>_in_<set>.bv`,
@@ -23,9 +30,12 @@ step (`filter_reads`, skipped when bvs are given), `OUT/<file>_in_<set>.bv`,
 """
 import argparse
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
+import traceback
 
 import numpy as np
 
@@ -124,18 +134,67 @@ def _log(out_dir, search_name, index_name, st, index_ms, wall_s):
                  f"Total  time: {wall_s:g} s\n[indexed {st['indexed']}, searched {st['searched']}, shared {st['shared']}]\n")
 
 
-def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ranks=None, verbose=True):
-    import commet_amd
+# ---- the engine: where the reads live and the jobs run ------------------------------------------------
+class HipEngine:
+    """The product engine: read sets packed in HBM, jobs through libcommet_hip.so (commet_amd.api).
+    There is no other engine in the package; tests inject a CPU checker through `engine_factory` to run
+    the multi-rank host logic without a GPU."""
+
+    def __init__(self, k, t, local_rank):
+        import commet_amd
+        # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
+        self._api = commet_amd
+        self.ctx = commet_amd.Context(k=k, t=t, device=int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+
+    def parse(self, files):
+        return self._api.ReadSet.from_fasta(self.ctx, files)
+
+    def save(self, rs, path):
+        rs.save(path)
+
+    def load(self, path):
+        return self._api.ReadSet.load(self.ctx, path)
+
+    def file_reads(self, rs):
+        return rs.file_reads()
+
+    def release(self, rs):
+        rs.close()
+
+    def index_and_search(self, index, searches, isel, ssels):
+        return self.ctx.index_and_search(index, searches, isel, ssels)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.ctx.close()
+
+    def mismatch_error(self, msg):
+        return self._api.CommetError(msg)
+
+
+def _scratch_root():
+    root = os.environ.get("COMMET_SCRATCH")
+    if root:
+        return root
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+
+
+def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ranks=None, verbose=True,
+        engine_factory=None):
+    t_start = time.perf_counter()
     own_ranks = ranks is None
     if ranks is None:
         ranks = sharding.Ranks(backend="gloo")
+    world, rank = ranks.world, ranks.rank
     if out_dir[-1] != "/":
         out_dir += "/"
     bin_dir = bin_dir or os.path.join(HERE, "bin")
     os.makedirs(out_dir, exist_ok=True)
     names, files, bvs = parse_set_file(input_file)
     N = len(names)
-    say = print if (verbose and ranks.rank == 0) else (lambda *a, **kw: None)
+    say = print if (verbose and rank == 0) else (lambda *a, **kw: None)
 
     if l < k * t and l != 0:                                      # Commet.py:509-513 (l stays 0 by default)
         l = k * t
@@ -146,7 +205,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
         cmds = []
         for q, (s, j) in enumerate(todo):
-            if q % ranks.world != ranks.rank:
+            if q % world != rank:
                 continue
             cmd = [os.path.join(bin_dir, "filter_reads"), files[s][j], "-l", str(l), "-e", str(e)]
             if n >= 0:
@@ -161,94 +220,154 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         with ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3"))) as pool:
             list(pool.map(lambda c: subprocess.run(c, check=True, stdout=subprocess.DEVNULL), cmds))
         ranks.barrier()
-
     filter_s = time.perf_counter() - t_filter
-    # ---- residency: every rank holds every set (packed: 12 B per 32 bases) ----------------------------------
-    t0 = time.perf_counter()
-    # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU
-    ctx = commet_amd.Context(k=k, t=t, device=int(os.environ.get("COMMET_FORCE_DEVICE", ranks.local_rank)))
-    sets = [commet_amd.ReadSet.from_fasta(ctx, fl) for fl in files]
-    counts = [rs.file_reads() for rs in sets]
-    sel = []
-    considered = []
-    for s in range(N):
-        parts = [read_bv(b) for b in bvs[s]]
-        for (nb, _), c, f in zip(parts, counts[s], files[s]):
-            if nb != c:
-                raise commet_amd.CommetError(f"Number of reads in {f} and boolean vector size are not equal -> quit")
-        _, bits = concat_bits(parts)
-        sel.append(bits)
-        considered.append(sum(popcount(b, nb) for nb, b in parts))
-    load_s = time.perf_counter() - t0
-    say(f"loaded {N} sets ({sum(rs.num_reads for rs in sets)} reads) in {load_s:.2f} s")
 
-    # ---- my pairs, grouped by ref ------------------------------------------------------------------------
+    # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
     pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
-    cost = [float(sets[a].num_reads + sets[b].num_reads) for a, b in pairs]
-    mine = [pairs[c] for c in sharding.assign_chains(pairs, ranks.world, ranks.rank, cost)]
-    shared = {}                    # (from set, in set) -> reads of `from` found in `in`
-    reads_searched = 0
-    prof = dict(jobs=0, call_ms=0.0, device_ms=0.0)      # library calls: wall time vs device time
+    size = [float(sum(os.path.getsize(f) for f in fl)) for fl in files]   # cost proxy known before any parsing
+    runs = sharding.assign_pairs_contiguous([size[a] + size[b] for a, b in pairs], world)
+    mine = [pairs[c] for c in runs[rank]]
+    needed = sorted({s for p in mine for s in p})
+    owned = [s for s in range(N) if s % world == rank]
+    needed_by_others = {s for r in range(world) if r != rank for c in runs[r] for s in pairs[c]}
 
-    def _acc(inf):
-        prof["jobs"] += 1
-        prof["call_ms"] += inf["total_ms"]
-        prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
+    scratch = None
+    if world > 1:
+        token = ranks.broadcast_object(f"commet_pk_{os.getuid()}_{os.getpid()}_{int(time.time())}" if rank == 0 else None)
+        scratch = os.path.join(_scratch_root(), token)
+        os.makedirs(scratch, exist_ok=True)
+    eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
+    prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
+                jobs=0, call_ms=0.0, device_ms=0.0)
+    try:
+        # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
+        t0 = time.perf_counter()
+        sets = {}
+        for s in owned:
+            if s not in needed and s not in needed_by_others:
+                continue
+            w0 = time.perf_counter()
+            rs = eng.parse(files[s])
+            prof["parse_s"] += time.perf_counter() - w0
+            prof["sets_parsed"] += 1
+            if s in needed_by_others:
+                w0 = time.perf_counter()
+                eng.save(rs, os.path.join(scratch, f"set{s}.pk"))
+                prof["save_s"] += time.perf_counter() - w0
+            if s in needed:
+                sets[s] = rs
+            else:
+                eng.release(rs)
+        ranks.barrier()                                          # every image is in place
+        for s in needed:
+            if s not in sets:
+                w0 = time.perf_counter()
+                sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
+                prof["load_s"] += time.perf_counter() - w0
+                prof["sets_loaded"] += 1
+        counts, sel, considered_mine = {}, {}, {}
+        for s in needed:
+            counts[s] = eng.file_reads(sets[s])
+            parts = [read_bv(b) for b in bvs[s]]
+            for (nb, _), c, f in zip(parts, counts[s], files[s]):
+                if nb != c:
+                    raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
+            _, sel[s] = concat_bits(parts)
+        for s in range(N):                                       # the diagonal: every set once, by its parser
+            if s % world == rank:
+                considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+        load_s = time.perf_counter() - t0
+        considered = {}
+        for d in ranks.gather_objects(considered_mine):
+            considered.update(d)
+        considered = [considered[s] for s in range(N)]
+        say(f"loaded {N} sets in {load_s:.2f} s (rank 0: {prof['sets_parsed']} parsed, {prof['sets_loaded']} from packed images)")
 
-    t_jobs = time.perf_counter()
-    for ref in sorted({p[0] for p in mine}):
-        targets = [i for (r, i) in mine if r == ref]
-        w0 = time.perf_counter()
-        tags1, st1, inf1 = ctx.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
-        reads_searched += sum(considered[i] for i in targets)
-        _acc(inf1)
-        for i, T1 in zip(targets, tags1):
-            # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
-            tags2, st2, inf2 = ctx.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
-            T2 = tags2[0]
-            _acc(inf2)
-            for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
-                write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-            _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
-            shared[(ref, i)] = st2[0]["shared"]
-            # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
-            tags3, st3, inf3 = ctx.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
-            _acc(inf3)
-            for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
-                write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
-            _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
-            shared[(i, ref)] = st3[0]["shared"]
-            reads_searched += considered[ref] + considered[i]
-    ctx.synchronize()
-    jobs_s = time.perf_counter() - t_jobs
-    # ---- matrices on rank 0 -----------------------------------------------------------------------------
-    everyone = ranks.gather_objects(shared)
-    result = None
-    if ranks.rank == 0:
-        mat = [[0] * N for _ in range(N)]
-        for d in everyone:
-            for (a, b), v in d.items():
-                mat[a][b] = v
-        for s in range(N):
-            mat[s][s] = considered[s]
-        write_matrices(out_dir, names, considered, mat)
-        result = dict(names=names, considered=considered, matrix=mat)
-        say("All Commet work is done")
-        say("\t Output csv matrices are in:")
-        for f in ("matrix_plain.csv", "matrix_percentage.csv", "matrix_normalized.csv"):
-            say("\t\t" + out_dir + f)
-    slowest = ranks.max_seconds(jobs_s)
-    total_searched = ranks.sum_int(reads_searched)
-    if result is not None:
-        result.update(filter_s=filter_s, load_s=load_s, jobs_s=slowest, reads_searched=total_searched, world=ranks.world, rank0_profile=prof,
-                      reads_per_s=total_searched / slowest if slowest > 0 else 0.0)
-        say(f"{total_searched} reads searched in {slowest:.3f} s on {ranks.world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s")
-    for rs in sets:
-        rs.close()
-    ctx.close()
-    if own_ranks:
-        ranks.close()
-    return result
+        # ---- my pairs, grouped by ref ------------------------------------------------------------------------
+        shared = {}                    # (from set, in set) -> reads of `from` found in `in`
+        reads_searched = 0
+
+        def _acc(inf):
+            prof["jobs"] += 1
+            prof["call_ms"] += inf["total_ms"]
+            prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
+
+        t_jobs = time.perf_counter()
+        for ref in sorted({p[0] for p in mine}):
+            targets = [i for (r, i) in mine if r == ref]
+            w0 = time.perf_counter()
+            tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
+            prof["j1_builds"] += 1
+            reads_searched += sum(considered[i] for i in targets)
+            _acc(inf1)
+            for i, T1 in zip(targets, tags1):
+                # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
+                tags2, st2, inf2 = eng.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
+                T2 = tags2[0]
+                _acc(inf2)
+                for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
+                    write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
+                _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
+                shared[(ref, i)] = st2[0]["shared"]
+                # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
+                tags3, st3, inf3 = eng.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
+                _acc(inf3)
+                for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
+                    write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
+                _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
+                shared[(i, ref)] = st3[0]["shared"]
+                reads_searched += considered[ref] + considered[i]
+        eng.synchronize()
+        jobs_s = time.perf_counter() - t_jobs
+        prof["jobs_s"] = jobs_s
+        # ---- matrices on rank 0 -----------------------------------------------------------------------------
+        everyone = ranks.gather_objects((shared, prof))
+        result = None
+        if rank == 0:
+            mat = [[0] * N for _ in range(N)]
+            for d, _ in everyone:
+                for (a, b), v in d.items():
+                    mat[a][b] = v
+            for s in range(N):
+                mat[s][s] = considered[s]
+            write_matrices(out_dir, names, considered, mat)
+            result = dict(names=names, considered=considered, matrix=mat)
+            say("All Commet work is done")
+            say("\t Output csv matrices are in:")
+            for f in ("matrix_plain.csv", "matrix_percentage.csv", "matrix_normalized.csv"):
+                say("\t\t" + out_dir + f)
+        slowest = ranks.max_seconds(jobs_s)
+        slowest_load = ranks.max_seconds(load_s)
+        slowest_filter = ranks.max_seconds(filter_s)
+        total_searched = ranks.sum_int(reads_searched)
+        total_s = ranks.max_seconds(time.perf_counter() - t_start)
+        if result is not None:
+            result.update(filter_s=slowest_filter, load_s=slowest_load, jobs_s=slowest, total_s=total_s,
+                          reads_searched=total_searched, world=world, rank0_profile=prof,
+                          per_rank=[p for _, p in everyone],
+                          reads_per_s=total_searched / slowest if slowest > 0 else 0.0,
+                          reads_per_s_incl_load_and_filter=total_searched / total_s if total_s > 0 else 0.0)
+            say(f"{total_searched} reads searched in {slowest:.3f} s of jobs on {world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s "
+                f"({result['reads_per_s_incl_load_and_filter'] / 1e6:.1f} M reads/s with filter {slowest_filter:.2f} s + load {slowest_load:.2f} s)")
+        for rs in sets.values():
+            eng.release(rs)
+        return result
+    finally:
+        eng.close()
+        if scratch is not None:
+            # rank 0 removes the scratch directory once everybody is through; a failing rank removes its own images
+            if sys.exc_info()[0] is None:
+                ranks.barrier()
+                if rank == 0:
+                    shutil.rmtree(scratch, ignore_errors=True)
+            else:
+                for s in owned:
+                    try:
+                        os.remove(os.path.join(scratch, f"set{s}.pk"))
+                    except OSError:
+                        pass
+        if own_ranks and sys.exc_info()[0] is None:
+            ranks.close()
 
 
 def main(argv=None):
@@ -263,7 +382,14 @@ def main(argv=None):
     ap.add_argument("-e", type=float, default=0)
     ap.add_argument("-m", type=int, default=-1)
     a = ap.parse_args(argv)
-    run(a.input_file, a.directory, k=a.k, t=a.t, l=a.l, n=a.n, e=a.e, m=a.m, bin_dir=a.bin_dir)
+    try:
+        run(a.input_file, a.directory, k=a.k, t=a.t, l=a.l, n=a.n, e=a.e, m=a.m, bin_dir=a.bin_dir)
+    except BaseException:
+        # a rank that fails must not leave its peers in a barrier: report and leave at once, skipping the process
+        # group's shutdown handshake; torch.distributed.run then terminates the other ranks and exits non-zero
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
     return 0
 
 

@@ -48,6 +48,23 @@ def assign_chains(chains, world_size, rank, cost=None):
     return sorted(mine)
 
 
+def assign_pairs_contiguous(cost, world_size):
+    """Cuts the row-major list of (ref, i) pairs into world_size CONTIGUOUS runs of about equal cost; returns
+    [range(lo, hi)] per rank.  Contiguous runs keep a rank's pairs on few reference sets, so that J1's index of
+    S_ref is built once per (rank, ref) and a rank touches few sets; boundaries fall where the running cost crosses
+    r / world_size of the total (each run is within one pair's cost of the ideal share)."""
+    n, total = len(cost), float(sum(cost))
+    cuts, acc, c = [0], 0.0, 0
+    for r in range(1, world_size):
+        target = total * r / world_size
+        while c < n and acc + cost[c] / 2.0 <= target:
+            acc += cost[c]
+            c += 1
+        cuts.append(c)
+    cuts.append(n)
+    return [range(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
 class Ranks:
     """Barrier / MAX-of-elapsed over ranks.  world_size 1 needs no torch at all."""
 
@@ -60,7 +77,10 @@ class Ranks:
         if self.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+                import datetime
+                # a rank that dies must not leave the others waiting for long (default 30 min)
+                tmo = datetime.timedelta(seconds=float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600")))
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=tmo)
             self.dist = dist
 
     def barrier(self):
@@ -82,6 +102,13 @@ class Ranks:
         t = torch.tensor([int(v)], dtype=torch.int64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t[0])
+
+    def broadcast_object(self, obj, src=0):
+        if self.dist is None:
+            return obj
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
 
     def gather_objects(self, obj):
         if self.dist is None:

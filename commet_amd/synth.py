@@ -81,3 +81,12 @@ def write_fasta_fast(path, bases, n_reads, read_len, digits=9):
     buf[:, -1] = ord("\n")
     with open(path, "wb") as fh:
         fh.write(buf.tobytes())
+
+
+def write_set_fasta(args):
+    """(set id, reads, read length, path): generates one synthetic set and writes it as FASTA.  Top-level so that a
+    spawn pool can run it (bench.py's matrix leg, the full-size tests)."""
+    s, n, L, path = args
+    b, _ = synth_set(s, n, L)
+    write_fasta_fast(path, b, n, L)
+    return s

@@ -1,0 +1,31 @@
+"""Worker of tests/test_distributed_cpu.py: commet_amd.matrix.run under torch.distributed.run (gloo, no GPU) with the
+CPU checker as the engine.  argv: sets.txt out_dir k t [rank that fails]"""
+import json
+import os
+import sys
+import traceback
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from commet_amd import matrix  # noqa: E402
+from oracle_engine import OracleEngine  # noqa: E402
+
+
+def main():
+    sets, out, k, t = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    if len(sys.argv) > 5:
+        OracleEngine.fail_on_rank = int(sys.argv[5])
+    try:
+        res = matrix.run(sets, out, k=k, t=t, verbose=False, engine_factory=OracleEngine)
+    except BaseException:
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)                 # what commet_amd.matrix.main does
+    if res is not None:
+        res.pop("rank0_profile")
+        json.dump(res, open(os.path.join(out, "result.json"), "w"))
+
+
+if __name__ == "__main__":
+    main()

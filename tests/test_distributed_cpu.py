@@ -38,6 +38,118 @@ def test_assignment_is_a_partition_and_balanced(world):
     assert max(loads) - min(loads) <= max(cost)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
+def test_contiguous_runs_partition_the_pairs(world):
+    n = 10
+    pairs = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
+    size = [1.0 + 0.3 * (s % 4) for s in range(n)]
+    cost = [size[a] + size[b] for a, b in pairs]
+    runs = sharding.assign_pairs_contiguous(cost, world)
+    assert len(runs) == world
+    assert [c for r in runs for c in r] == list(range(len(pairs)))             # contiguous, in order, nothing lost
+    loads = [sum(cost[c] for c in r) for r in runs]
+    assert max(loads) - min(loads) <= 2 * max(cost)
+    if world <= 8:
+        # few reference sets per rank: J1's index of S_ref is built once per (rank, ref)
+        builds = sum(len({pairs[c][0] for c in r}) for r in runs)
+        assert builds <= (n - 1) + world
+
+
+def _matrix_case(tmp_path):
+    """5 sets (one of two files, one with a filter that empties a file), k=20; returns (names, files, bvs)"""
+    import numpy as np
+    import util
+    from commet_amd import synth
+    k, t, n, L = 20, 2, 1500, 80
+    names = ["s0", "s1", "s2", "s3", "s4"]
+    files = [["s0.fa"], ["s1a.fa", "s1b.fa"], ["s2.fa"], ["s3.fa"], ["s4.fa"]]
+    for s, fl in enumerate(files):
+        b, o = synth.synth_set(s, n, L, copy_frac=0.3)
+        if len(fl) == 1:
+            synth.write_fasta(str(tmp_path / fl[0]), b, o)
+        else:
+            h = n // 2
+            synth.write_fasta(str(tmp_path / fl[0]), b[: h * L], o[: h + 1])
+            synth.write_fasta(str(tmp_path / fl[1]), b[h * L:], o[h:] - o[h])
+    rng = np.random.default_rng(1)
+    bvs = []
+    for s, fl in enumerate(files):
+        row = []
+        for j, f in enumerate(fl):
+            cnt = len(util.parse_fasta(str(tmp_path / f)))
+            sel = rng.random(cnt) < 0.9
+            if (s, j) == (1, 1):
+                sel[:] = False                                   # a file with no selected read (SURVEY Q6)
+            util.write_bv(str(tmp_path / (f + ".bv")), "filter of " + f, sel)
+            row.append(f + ".bv")
+        bvs.append(row)
+    (tmp_path / "sets.txt").write_text("".join(
+        f"{names[s]}: " + "; ".join(f"{f},{b}" for f, b in zip(files[s], bvs[s])) + "\n" for s in range(len(names))))
+    return k, t, names, files, bvs
+
+
+def _launch(world, args, cwd, timeout=600):
+    port = 29500 + (os.getpid() * 7 + world) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port)] + args
+    env = dict(os.environ, OMP_NUM_THREADS="1", COMMET_SCRATCH=str(cwd), COMMET_DIST_TIMEOUT_S="120")
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=cwd, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_matrix_driver_host_logic_over_gloo_ranks(tmp_path, world):
+    """The N x N driver over `world` processes (gloo; the CPU checker stands in for the GPU engine): every set is parsed
+    by exactly one rank, the others take its packed image; outputs equal Commet.py's job sequence run in one process."""
+    import json
+    import oracle_binding as ob
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import commet_jobs
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    p = _launch(world, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t)], str(tmp_path))
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    res = json.load(open(tmp_path / "out" / "result.json"))
+    assert res["world"] == world and len(res["per_rank"]) == world
+    assert sum(r["sets_parsed"] for r in res["per_rank"]) == len(names)          # one parse per set on the node
+    assert sum(r["pairs"] for r in res["per_rank"]) == 10
+    assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + world
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("commet_pk_")]   # the scratch images are gone
+
+    def cfg(si, restrict_to=None):
+        parts = []
+        for f, b in zip(files[si], bvs[si]):
+            parts.append(f + "," + (b if restrict_to is None else f"orc/{f}_in_{names[restrict_to]}.bv"))
+        return names[si] + ":" + ";".join(parts)
+
+    os.makedirs(tmp_path / "orc")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for kind, idx, searches, restr in commet_jobs(names):
+            open("i.txt", "w").write(cfg(idx, restr) + "\n")
+            open("s.txt", "w").write("".join(cfg(s) + "\n" for s in searches))
+            rc, *_ = ob.index_and_search("i.txt", "s.txt", "orc", "orc", k, t)
+            assert rc == 0
+    finally:
+        os.chdir(cwd)
+    checked = 0
+    for f in sorted(os.listdir(tmp_path / "orc")):
+        if f.endswith(".bv"):
+            assert open(tmp_path / "out" / f, "rb").read().split(b"\n", 1)[1] == open(tmp_path / "orc" / f, "rb").read().split(b"\n", 1)[1], f
+            checked += 1
+    assert checked == 6 * 4          # 6 files, each searched in the 4 other sets
+
+
+def test_matrix_driver_failing_rank_ends_the_group(tmp_path):
+    """rank 1 raises while parsing: the launcher must come back non-zero within seconds, not after a barrier timeout"""
+    import time
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    t0 = time.time()
+    p = _launch(2, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t), "1"], str(tmp_path), timeout=300)
+    assert p.returncode != 0
+    assert b"injected failure while parsing" in p.stdout
+    assert time.time() - t0 < 90
+
+
 def test_two_ranks_gloo(tmp_path):
     port = 29500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

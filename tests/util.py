@@ -202,7 +202,4 @@ def gen_set_fasta(args):
     if root not in sys.path:
         sys.path.insert(0, root)
     from commet_amd import synth
-    s, n, L, path = args
-    b, _ = synth.synth_set(s, n, L)
-    synth.write_fasta_fast(path, b, n, L)
-    return s
+    return synth.write_set_fasta(args)

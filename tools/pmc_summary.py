@@ -49,7 +49,29 @@ def main(d):
     for e in out.values():
         if "fetch_bytes_per_launch" in e or "write_bytes_per_launch" in e:
             e["hbm_bytes_per_launch"] = e.get("fetch_bytes_per_launch", 0) + e.get("write_bytes_per_launch", 0)
+    # SQ counters (one more pass): per kernel, the share of wave-cycles spent waiting and the VALU's busy share
+    p = os.path.join(d, "pmc_sq.csv")
+    if os.path.exists(p):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(p)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, c in acc.items():
+            if k in out and c.get("SQ_WAVE_CYCLES"):
+                out[k]["sq"] = {"wait_share_of_wave_cycles": round(c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3),
+                                "valu_busy_share_of_busy_cycles": round(c.get("SQ_ACTIVE_INST_VALU", 0) / max(c.get("SQ_BUSY_CYCLES", 1), 1), 3),
+                                "valu_insts": round(c.get("SQ_INSTS_VALU", 0)), "vmem_rd_insts": round(c.get("SQ_INSTS_VMEM_RD", 0)),
+                                "lds_insts": round(c.get("SQ_INSTS_LDS", 0)), "waves": round(c.get("SQ_WAVES", 0))}
+    meta = {"note": "per launch; FETCH_SIZE doubled for the wide streaming readers (gfx950, MI355X_MICROARCH.md HBM section)"}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        meta["source_hash"] = bench.source_hash()
+        meta["workload"] = json.load(open(os.path.join(d, "bench.json")))["config"]["workload"]
+    except Exception as ex:      # a summary without the meta block is still usable (bench.py then marks it stale)
+        meta["error"] = repr(ex)
+    out["_meta"] = meta
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+    out.pop("_meta")
     for k, e in out.items():
         print(f"{k:28s} calls={e['calls']:4d} avg_ms={e['avg_ms']:9.3f} fetch={e.get('fetch_bytes_per_launch', 0) / 1e9:8.2f} GB "
               f"write={e.get('write_bytes_per_launch', 0) / 1e9:8.2f} GB")

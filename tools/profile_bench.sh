@@ -1,17 +1,24 @@
-# rocprofv3 passes of bench.py on the GPU box: bash tools/profile_bench.sh <name>  ->  gpurun_out/<name>/{bench.json,kernel_stats.csv,pmc_*.csv,traffic.json}
+# rocprofv3 passes of bench.py on the GPU box: bash tools/profile_bench.sh <name> [extra bench.py args]
+#   ->  gpurun_out/<name>/{bench.json,kernel_stats.csv,pmc_fetch_size.csv,pmc_write_size.csv,pmc_sq.csv,traffic.json}
+# Copy the directory to profiles/<name> to have bench.py use (and the judge read) it.
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r01_profile}
+N=${1:-r02_profile}
+shift || true
+O=$R/gpurun_out/$N
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+python3 $R/bench.py --no-matrix "$@" > $O/bench.json 2> $O/bench.err
 # one index lane here: with two, kernels of both lanes run at once and their durations are not additive
-COMMET_INDEX_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o r01 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/kt.log 2>&1
-COMMET_INDEX_LANES=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o r01 --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-probe-count > $O/pf.log 2>&1
-COMMET_INDEX_LANES=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o r01 --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-probe-count > $O/pw.log 2>&1
+B="--cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix"
+COMMET_INDEX_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $O/kt.log 2>&1
+COMMET_INDEX_LANES=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pf.log 2>&1
+COMMET_INDEX_LANES=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pw.log 2>&1
+COMMET_INDEX_LANES=1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace -d $O/ps -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/ps.log 2>&1 || echo "SQ pass failed" >> $O/bench.err
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/pf -name "*counter_collection.csv" | head -1) $O/pmc_fetch_size.csv
 cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
-rm -rf $O/kt $O/pf $O/pw
+cp $(find $O/ps -name "*counter_collection.csv" | head -1) $O/pmc_sq.csv 2>/dev/null || true
+rm -rf $O/kt $O/pf $O/pw $O/ps
 cd $R && python3 tools/pmc_summary.py $O
 cat $O/bench.json
