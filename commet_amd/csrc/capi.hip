@@ -7,6 +7,7 @@
 
 #include "kernels.hpp"
 #include "index_part.hpp"
+#include "slice_search.hpp"
 #include "read_iter.hpp"
 #include "host/fasta_source.hpp"
 
@@ -161,6 +162,12 @@ struct commet_ctx {
             spare.clear();
         }
     } kclock;
+    // the many-small-chunks regime (slice_search.hpp): staging bit-planes, bit-sliced tables, chunk descriptors
+    uint32_t *slice_stage = nullptr, *slice_tables = nullptr;
+    SliceChunk *d_slice_chunks = nullptr;
+    uint64_t slice_stage_words = 0, slice_table_words = 0, slice_chunks_cap = 0;
+    int slice_mode = 0;               // option: 0 auto, 1 never, 2 whenever k allows it
+    int slice_gw = 0;                 // option: words per bit-sliced entry (32 chunks each); 0 = by the number of chunks
     uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
     int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
@@ -326,6 +333,9 @@ void commet_destroy(commet_ctx *c)
         if (b.done) (void) hipEventDestroy(b.done);
     }
     c->kclock.release();
+    (void) hipFree(c->slice_stage);
+    (void) hipFree(c->slice_tables);
+    (void) hipFree(c->d_slice_chunks);
     (void) hipFree(c->il_a);
     (void) hipFree(c->d_jobcnt);
     (void) hipFree(c->d_plansum);
@@ -1479,6 +1489,89 @@ bool group8_ok(const commet_ctx *c, const commet_readset *rs)
     return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
 }
 
+// words per bit-sliced entry (32 chunk filters per word) for a job of n_chunks chunks; 0 = the job takes the slot path
+int slice_words(const commet_ctx *c, uint64_t n_chunks)
+{
+    if (c->slice_mode == 1 || c->count_probes) return 0;
+    if (c->k < SLICE_MIN_K || c->k > SLICE_MAX_K || n_chunks == 0) return 0;
+    if (c->slice_mode == 0 && n_chunks < 8) return 0;
+    int gw = c->slice_gw ? c->slice_gw : n_chunks > 128 ? 8 : n_chunks > 64 ? 4 : n_chunks > 32 ? 2 : 1;
+    while (gw > 1 && (((uint64_t) 16 * gw) << c->k) > (1ull << 30)) gw /= 2;   // the four tables: at most 1 GiB
+    return gw;
+}
+
+int ensure_slice_buffers(commet_ctx *c, int gw, uint64_t n_chunks)
+{
+    const uint64_t G = 32ull * gw;
+    const uint64_t stage_words = (G * 4) << (c->k - 5), table_words = ((uint64_t) 4 * gw) << c->k;
+    if (c->slice_stage_words < stage_words || c->slice_table_words < table_words || c->slice_chunks_cap < n_chunks) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (c->slice_stage_words < stage_words) {
+            (void) hipFree(c->slice_stage);
+            c->slice_stage = nullptr, c->slice_stage_words = 0;
+            HIP_OK(hipMalloc((void **) &c->slice_stage, stage_words * 4));
+            c->slice_stage_words = stage_words;
+        }
+        if (c->slice_table_words < table_words) {
+            (void) hipFree(c->slice_tables);
+            c->slice_tables = nullptr, c->slice_table_words = 0;
+            HIP_OK(hipMalloc((void **) &c->slice_tables, table_words * 4));
+            c->slice_table_words = table_words;
+        }
+        if (c->slice_chunks_cap < n_chunks) {
+            (void) hipFree(c->d_slice_chunks);
+            c->d_slice_chunks = nullptr, c->slice_chunks_cap = 0;
+            HIP_OK(hipMalloc((void **) &c->d_slice_chunks, n_chunks * sizeof(SliceChunk)));
+            c->slice_chunks_cap = n_chunks;
+        }
+    }
+    return 0;
+}
+
+// filters of chunks [ci, ci + g) of the plan -> bit-sliced tables (slice_search.hpp)
+int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t ci, int g, int gw)
+{
+    const int tile_bits = std::min(c->k, SLICE_TILE_BITS);
+    const uint32_t tiles = 1u << (c->k - tile_bits);
+    const size_t lds = (size_t) 4 << (tile_bits - 5);
+    HIP_OK(hipFuncSetAttribute((const void *) slice_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    {
+        KScope ks(c, "slice_build_kernel", c->stream);
+        hipLaunchKernelGGL(slice_build_kernel, dim3(4 * tiles, (unsigned) g), dim3(1024), lds, c->stream, rs->view(), d_sel,
+                           c->d_slice_chunks + ci, c->k, tile_bits, tiles, c->slice_stage);
+    }
+    HIP_OK(hipGetLastError());
+    const unsigned grid = (unsigned) ((((uint64_t) 4 << (c->k - 5)) + 255) / 256);
+    {
+        KScope ks(c, "slice_transpose_kernel", c->stream);
+        switch (gw) {
+        case 1: hipLaunchKernelGGL(slice_transpose_kernel<1>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
+        case 2: hipLaunchKernelGGL(slice_transpose_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
+        case 4: hipLaunchKernelGGL(slice_transpose_kernel<4>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
+        default: hipLaunchKernelGGL(slice_transpose_kernel<8>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int launch_search_sliced(commet_ctx *c, const commet_readset *rs, int g, int gw, const uint64_t *d_sel, uint64_t *d_tags,
+                         unsigned long long *d_counters, uint32_t cstride)
+{
+    if (rs->n_reads == 0) return 0;
+    if ((rs->n_reads + 255) / 256 >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
+    const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
+    KScope ks(c, "search_sliced_kernel", c->stream);
+    switch (gw) {
+    case 1: hipLaunchKernelGGL(search_sliced_kernel<1>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 2: hipLaunchKernelGGL(search_sliced_kernel<2>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 4: hipLaunchKernelGGL(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    default: hipLaunchKernelGGL(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1671,7 +1764,10 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         evs.push_back(*e);
         return 0;
     };
-    const bool timed = (info != nullptr || stats != nullptr) && n_chunks * (uint64_t) (n_search + 4) <= 16384;
+    // the many-small-chunks regime: the chunk filters of a group live bit-sliced in one set of tables (slice_search.hpp)
+    const int slice_gw = slice_words(c, n_chunks);
+    const bool timed = (info != nullptr || stats != nullptr) &&
+                       (slice_gw ? (n_chunks / (32 * slice_gw) + 1) * (uint64_t) (n_search + 2) : n_chunks * (uint64_t) (n_search + 4)) <= 16384;
     std::vector<hipEvent_t> e_idx0, e_idx1, e_zero0, e_zero1;
     std::vector<std::vector<hipEvent_t>> e_set(n_search);   // end of set s's search, per chunk
     uint64_t n_index_launches = 0, n_search_launches = 0;
@@ -1687,7 +1783,46 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         for (int s = 0; s < n_search && ok8; ++s) ok8 = group8_ok(c, search_rs[s]);
         if (!ok8) group_cap = 4;
     }
-    for (uint64_t ci = 0; ci < n_chunks && !rc;) {
+    if (slice_gw) {
+        std::vector<SliceChunk> hc(n_chunks);
+        for (uint64_t i = 0; i < n_chunks; ++i) {
+            const Chunk &ch = plan.chunks[i];
+            hc[i].first = ch.first;
+            hc[i].count = ch.n_reads ? ch.last - ch.first + 1 : 0;
+        }
+        if (ensure_slice_buffers(c, slice_gw, n_chunks)) rc = 1;
+        if (!rc && hipMemcpy(c->d_slice_chunks, hc.data(), n_chunks * sizeof(SliceChunk), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail("chunk descriptor upload failed");
+        const uint64_t G = 32ull * slice_gw;
+        for (uint64_t ci = 0; ci < n_chunks && !rc; ci += G) {
+            const int g = (int) std::min<uint64_t>(G, n_chunks - ci);
+            hipEvent_t a = nullptr, b = nullptr;
+            if (timed) {
+                if (new_event(&a) || new_event(&b)) { rc = 1; break; }
+                (void) hipEventRecord(a, c->stream);
+            }
+            if (launch_slice_build(c, index_rs, plan.dense ? nullptr : index_rs->d_sel, ci, g, slice_gw)) { rc = 1; break; }
+            n_index_launches += 2;
+            if (timed) {
+                (void) hipEventRecord(b, c->stream);
+                e_idx0.push_back(a);
+                e_idx1.push_back(b);
+            }
+            for (int s = 0; s < n_search && !rc; ++s) {
+                const commet_readset *rs = search_rs[s];
+                if (launch_search_sliced(c, rs, g, slice_gw, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags,
+                                         d_cnt + 2 * (ci * n_search + s), (uint32_t) (2 * n_search))) { rc = 1; break; }
+                if (rs->n_reads) ++n_search_launches;
+                if (timed) {
+                    hipEvent_t d = nullptr;
+                    if (new_event(&d)) { rc = 1; break; }
+                    (void) hipEventRecord(d, c->stream);
+                    e_set[s].push_back(d);
+                }
+            }
+        }
+    }
+    for (uint64_t ci = 0; ci < n_chunks && !rc && !slice_gw;) {
         int g = (int) std::min<uint64_t>((uint64_t) group_cap, n_chunks - ci);
         const int gs = g <= 2 ? 2 : g <= 4 ? 4 : 8;
         if (g > 1 && ensure_slots(c, g, gs)) {   // not enough memory for the group
@@ -1797,7 +1932,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 // an empty search set launches nothing: scanned = visited - found so far
                 last_scanned = visited[s] - shared;
                 scans += last_scanned;
-                if (search_rs[s]->n_reads && p[0] != last_scanned)
+                if (search_rs[s]->n_reads && !slice_gw && p[0] != last_scanned)   // (the sliced kernel counts found reads only)
                     rc = fail("internal error: device scanned %llu reads, host plan says %llu (chunk %llu, set %d)",
                               p[0], (unsigned long long) last_scanned, (unsigned long long) ci, s);
                 shared += p[1];
@@ -1878,6 +2013,16 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->kclock.collect();
         c->kclock.on = value != 0;
         if (value) c->kclock.reset();
+        return 0;
+    }
+    if (!strcmp(name, "slice_mode")) {        // 0 auto (8 chunks or more, 12 <= k <= 24), 1 never, 2 whenever k allows it
+        if (value < 0 || value > 2) return fail("slice_mode must be 0, 1 or 2");
+        c->slice_mode = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "slice_words")) {       // chunk filters per pass / 32 in the sliced regime: 0 auto, 1, 2, 4 or 8
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail("slice_words must be 0, 1, 2, 4 or 8");
+        c->slice_gw = (int) value;
         return 0;
     }
     if (!strcmp(name, "max_kmer")) {          // chunk size in k-mers (0 = the reference's constant); changes the chunking
