@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads per set of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-probe-count", action="store_true", help="skip the extra (untimed) P_ref counting step")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the extra (untimed) per-kernel timing steps")
+    ap.add_argument("--kt-steps", type=int, default=3, help="untimed steps of the per-kernel timing leg")
     ap.add_argument("--no-matrix", action="store_true", help="skip the configs[2] matrix leg (detail.matrix)")
     ap.add_argument("--matrix-sets", type=int, default=10)
     ap.add_argument("--matrix-reads", type=int, default=10_000_000)
@@ -262,7 +263,7 @@ def main():
             probes = inf["probes"]
             ctx.set_option("count_probes", 0)
         if not args.no_kernel_times:
-            KT_STEPS = 3
+            KT_STEPS = max(1, args.kt_steps)
             ctx.set_option("kernel_timing", 1)    # hipEvent pair around every launch, on the launching stream
             for _ in range(KT_STEPS):
                 ctx.index_and_search(irs, [qrs])

@@ -288,6 +288,11 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->k = kmer_size;
     c->t = min_hits < 1 ? 1 : min_hits;
     if (const char *e = getenv("COMMET_INDEX_LANES")) c->index_lanes = atoi(e) == 1 ? 1 : 2;   // 1: one kernel at a time (per-kernel profiles)
+    if (const char *e = getenv("COMMET_SLICE_MODE")) c->slice_mode = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
+    if (const char *e = getenv("COMMET_SLICE_WORDS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) c->slice_gw = v;
+    }
     // 2^k bits per plane, at least one word; 4 planes = 2^(k-1) bytes (bloom_filter.h:73)
     const uint64_t plane_bits = 1ull << kmer_size;
     c->plane_words = plane_bits < 32 ? 1 : plane_bits / 32;

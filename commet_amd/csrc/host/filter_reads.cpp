@@ -180,7 +180,8 @@ int main(int argc, char **argv)
         });
     } else {
         std::vector<size_t> cuts(1, 0);
-        const size_t target = 8u << 20;
+        size_t target = 8u << 20;
+        if (const char *e = getenv("COMMET_FILTER_PIECE_BYTES")) target = (size_t) std::max(64L, atol(e));   // tests: many pieces from small files
         for (size_t at = target; at < n; at += target) {
             const char *q = d + at;
             while (true) {   // next line start that begins with '>'

@@ -25,7 +25,7 @@ def chunks_from_counts(kc, max_kmer):
 
 
 def _one_chunk(args):
-    bases_npy, a, e, L, k, t, sample_npy = args
+    bases_npy, a, e, L, k, t, sample_npy, Ls = args
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
@@ -36,31 +36,39 @@ def _one_chunk(args):
     f = ob.Bloom(k)
     chunk = np.ascontiguousarray(bases[a * L: e * L])
     fed = f.index(chunk, np.arange(e - a + 1, dtype=np.uint64) * np.uint64(L))
-    ns = sb.size // L
-    found, _ = f.search(t, sb, np.arange(ns + 1, dtype=np.uint64) * np.uint64(L))
+    ns = sb.size // Ls
+    found, _ = f.search(t, sb, np.arange(ns + 1, dtype=np.uint64) * np.uint64(Ls))
     f.close()
     return fed, found.tobytes()
 
 
-def search_sample_over_chunks(scratch, tag, index_bases, L, chunks, k, t, sample_bases, workers=None):
+def search_sample_over_chunks(scratch, tag, index_bases, L, chunks, k, t, sample_bases, workers=None, first_chunk=False,
+                              sample_len=None):
     """index_bases: uint8[n * L] of the reads that are fed (already restricted to the selected reads, in order);
-    chunks: [(a, e)] over those reads; sample_bases: uint8[m * L] query reads.  Returns (bool[m] found in any chunk,
-    [k-mers fed per chunk])."""
+    chunks: [(a, e)] over those reads; sample_bases: uint8[m * sample_len] query reads (sample_len defaults to L).
+    Returns (bool[m] found in any chunk, [k-mers fed per chunk]); with first_chunk also int[m], the first chunk that
+    finds each read (-1: none) — what the reference's chunk loop would tag it in."""
     os.makedirs(scratch, exist_ok=True)
     bnpy, snpy = os.path.join(scratch, tag + "_index.npy"), os.path.join(scratch, tag + "_sample.npy")
     np.save(bnpy, np.asarray(index_bases, dtype=np.uint8))
     np.save(snpy, np.asarray(sample_bases, dtype=np.uint8))
-    m = len(sample_bases) // L
-    jobs = [(bnpy, a, e, L, k, t, snpy) for a, e in chunks]
-    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 8))
+    Ls = sample_len or L
+    m = len(sample_bases) // Ls
+    jobs = [(bnpy, a, e, L, k, t, snpy, Ls) for a, e in chunks]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 12))
     if len(jobs) == 1 or workers == 1:
         res = [_one_chunk(j) for j in jobs]
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             res = pool.map(_one_chunk, jobs, chunksize=1)
     found = np.zeros(m, dtype=bool)
-    for _, fb in res:
-        found |= np.unpackbits(np.frombuffer(fb, dtype=np.uint8), bitorder="little")[:m].astype(bool)
+    first = np.full(m, -1, dtype=np.int64)
+    for ci, (_, fb) in enumerate(res):
+        fc = np.unpackbits(np.frombuffer(fb, dtype=np.uint8), bitorder="little")[:m].astype(bool)
+        first[fc & ~found] = ci
+        found |= fc
     os.remove(bnpy)
     os.remove(snpy)
+    if first_chunk:
+        return found, [fed for fed, _ in res], first
     return found, [fed for fed, _ in res]

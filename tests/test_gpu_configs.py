@@ -222,3 +222,40 @@ def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx):
         assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
         assert sg[0]["searched"] == searched_last and sg[0]["indexed"] == sum(e - a for a, e in chunks)
     assert stats[0]["shared"] > 2000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[4]'s regime (k = 21, t = 5, 150-bp reads: 1 MiB filters, ~1 880-read chunks) on a 200 000 x 200 000-read slice
+# ---------------------------------------------------------------------------------------------------------------
+def test_c5_regime_200k_slice_matches_cpu_checker(tmp_path):
+    """107 chunks; the bit-sliced regime (auto: 128 chunk filters per pass) and the slot path must both give the CPU
+    checker's bits and log numbers.  The CPU checker replays every chunk against ALL query reads (workers in parallel);
+    a read belongs to the first chunk that finds it."""
+    import commet_amd
+    from commet_amd import synth
+    k, t, L, n = 21, 5, 150, 200_000
+    b0, o0 = synth.synth_set(0, n, L)
+    b1, o1 = synth.synth_set(1, n, L, copy_frac=0.4)
+    res = {}
+    with commet_amd.Context(k=k, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
+        kc = irs.kmer_counts()
+        res["auto"] = ctx.index_and_search(irs, [qrs])
+        for words in (1, 8):
+            ctx.set_option("slice_words", words)
+            res[words] = ctx.index_and_search(irs, [qrs])
+        ctx.set_option("slice_mode", 1)
+        res["slots"] = ctx.index_and_search(irs, [qrs])
+    chunks = oracle_pool.chunks_from_counts(kc, ob.max_kmer(k))
+    assert len(chunks) > 100
+    found, fed, first = oracle_pool.search_sample_over_chunks(str(tmp_path), "c5", b0, L, chunks, k, t, b1, first_chunk=True)
+    assert fed == [int(kc[a:e].sum()) for a, e in chunks]
+    searched_last = n - int(((first >= 0) & (first < len(chunks) - 1)).sum())
+    assert res["auto"][2]["search_launches"] == 1 and res[1][2]["search_launches"] == (len(chunks) + 31) // 32
+    for name, (tags, stats, info) in res.items():
+        assert info["n_chunks"] == len(chunks), name
+        assert np.array_equal(util.bools_from_bits(tags[0], n), found), name
+        assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == \
+            (sum(e - a for a, e in chunks), searched_last, int(found.sum())), name
+    assert found[: int(0.4 * n)].mean() > 0.5 and found.sum() > 50_000

@@ -57,6 +57,40 @@ def test_job_matches_oracle(tmp_path, seed, index_mode):
             r.close()
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_job_sliced_regime_matches_oracle(tmp_path, seed):
+    """the many-small-chunks regime (slice_search.hpp: chunk filters bit-sliced across 32..256-bit entries, one pass of a
+    search set per group of chunks) forced on the randomised scenarios: multi-file sets, filter bvs incl. all-zero ones,
+    ragged / short / N-rich reads, t = 1..4, 1..many chunks"""
+    import commet_amd as commet
+    scn = Scenario(str(tmp_path / "scn"), 500 + seed, k=[12, 13, 16, 20, 21, 24][seed % 6], n_scale=[1.0, 4.0, 12.0][seed % 3])
+    out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
+    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o)
+    assert rc == 0
+    with commet.Context(k=scn.k, t=scn.t) as ctx:
+        irs, isel = _load_set(commet, ctx, scn.sets[scn.index_name], scn.dir)
+        srs, ssel = [], []
+        for nme in sorted(scn.search_names):
+            r, s = _load_set(commet, ctx, scn.sets[nme], scn.dir)
+            srs.append(r)
+            ssel.append(s)
+        ctx.set_option("slice_mode", 2)
+        ctx.set_option("slice_words", [1, 2, 4, 8][(seed // 6) % 4])
+        tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        if chunks:
+            assert info["index_launches"] == 2 * ((chunks + 32 * [1, 2, 4, 8][(seed // 6) % 4] - 1) // (32 * [1, 2, 4, 8][(seed // 6) % 4]))
+        by_name = {r["name"]: r for r in res}
+        for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
+            o = by_name[nme]
+            assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
+            pos = 0
+            for fa, _, reads, _ in scn.sets[nme]:
+                _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
+                pos += n
+
+
 @pytest.mark.parametrize("k,t,chunk_group", [(20, 2, 4), (24, 3, 2), (33, 2, 4), (16, 2, 1)])
 def test_long_and_ragged_reads(tmp_path, k, t, chunk_group):
     """reads far longer than the fast paths' limits (search masks cover 256 bases, chunk groups need <= 64 KiB of

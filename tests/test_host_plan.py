@@ -13,14 +13,17 @@ import util
 from conftest import ROOT
 from scenarios import GoldenScenario, Scenario, run_oracle
 
-PLAN_LIB = os.path.join(ROOT, "commet_amd", "libcommet_plan.so")
+# COMMET_PLAN_LIB: a prebuilt (e.g. sanitizer-instrumented, tests/test_sanitizers.py) planner library to test instead
+PLAN_LIB = os.environ.get("COMMET_PLAN_LIB") or os.path.join(ROOT, "commet_amd", "libcommet_plan.so")
 PLAN_SRC = os.path.join(ROOT, "commet_amd", "csrc", "host", "plan_capi.cpp")
 
 
 @pytest.fixture(scope="module")
 def plan():
     srcs = [PLAN_SRC, os.path.join(ROOT, "commet_amd", "csrc", "read_iter.hpp")]
-    if not os.path.exists(PLAN_LIB) or any(os.path.getmtime(s) > os.path.getmtime(PLAN_LIB) for s in srcs):
+    if os.environ.get("COMMET_PLAN_LIB"):
+        pass
+    elif not os.path.exists(PLAN_LIB) or any(os.path.getmtime(s) > os.path.getmtime(PLAN_LIB) for s in srcs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", PLAN_LIB, PLAN_SRC], check=True)
     lib = C.CDLL(PLAN_LIB)
     lib.commet_plan_index.restype = C.c_uint64

@@ -10,7 +10,8 @@ import pytest
 import util
 from conftest import ROOT, ref_tool
 
-BIN = os.path.join(ROOT, "commet_amd", "bin")
+# COMMET_BIN_DIR: prebuilt (e.g. sanitizer-instrumented, tests/test_sanitizers.py) tools to test instead
+BIN = os.environ.get("COMMET_BIN_DIR") or os.path.join(ROOT, "commet_amd", "bin")
 
 
 @pytest.fixture(scope="module", autouse=True)
