@@ -285,8 +285,9 @@ def main():
         steps = args.steps
         ms_per_step = elapsed * 1000.0 / steps
         value = world * n * steps / elapsed
+        which = {(10_000_000, 100, 32, 2): "BASELINE configs[1]", (20_000_000, 150, 21, 5): "BASELINE configs[4]"}.get((n, L, k, t), "custom size")
         workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
-                    f"per GPU (BASELINE configs[1]), inputs resident in HBM")
+                    f"per GPU ({which}), inputs resident in HBM")
         kmers = info["kmers_indexed"]
         idx_ms = acc["index_kernel_ms"] / steps
         srch_ms = acc["search_ms"] / steps
