@@ -10,6 +10,7 @@
 #include "slice_search.hpp"
 #include "read_iter.hpp"
 #include "host/fasta_source.hpp"
+#include "host/ingest_pack.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -172,10 +173,8 @@ struct commet_ctx {
     int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
     struct IngestBuf {
-        uint8_t *h_bases = nullptr;
-        uint64_t *h_offs = nullptr;
-        uint8_t *d_bases = nullptr;
-        uint64_t *d_offs = nullptr;
+        uint32_t *h_planes = nullptr;
+        uint64_t *h_goff = nullptr;
         hipEvent_t done = nullptr;
     };
     std::vector<IngestBuf> ingest_pool;
@@ -221,6 +220,8 @@ struct commet_readset {
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
     uint32_t max_len = 0, min_len = 0;
+    bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
+    uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;
     bool finalized = false;
 
     ReadsView view() const
@@ -331,10 +332,8 @@ void commet_destroy(commet_ctx *c)
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->filter) (void) hipFree(c->filter);
     for (commet_ctx::IngestBuf &b : c->ingest_pool) {
-        if (b.h_bases) (void) hipHostFree(b.h_bases);
-        if (b.h_offs) (void) hipHostFree(b.h_offs);
-        (void) hipFree(b.d_bases);
-        (void) hipFree(b.d_offs);
+        if (b.h_planes) (void) hipHostFree(b.h_planes);
+        if (b.h_goff) (void) hipHostFree(b.h_goff);
         if (b.done) (void) hipEventDestroy(b.done);
     }
     c->kclock.release();
@@ -505,266 +504,111 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
     return 0;
 }
 
-// memcpy with a few host threads (COMMET_INGEST_THREADS, default 8) for large blocks
-static void parallel_copy(uint8_t *dst, const uint8_t *src, uint64_t n)
-{
-    static const int nt = [] {
-        const char *e = getenv("COMMET_INGEST_THREADS");
-        int t = e ? atoi(e) : 8;
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw && t > (int) hw) t = (int) hw;
-        return t < 1 ? 1 : t;
-    }();
-    if (nt == 1 || n < (8u << 20)) {
-        memcpy(dst, src, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    const uint64_t per = ((n + nt - 1) / nt + 63) & ~63ull;
-    for (int i = 1; i < nt; ++i) {
-        const uint64_t a = std::min<uint64_t>(n, (uint64_t) i * per), b = std::min<uint64_t>(n, a + per);
-        if (b > a) th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
-    }
-    memcpy(dst, src, std::min<uint64_t>(n, per));
-    for (std::thread &t : th) t.join();
-}
-
-int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads)
-{
-    uint64_t done = 0;
-    while (done < n_reads) {
-        uint8_t *hb;
-        uint64_t *ho;
-        uint64_t bcap, rcap;
-        if (commet_readset_stage_acquire(rs, &hb, &bcap, &ho, &rcap)) return 1;
-        uint64_t take = 0;
-        const uint64_t b0 = offsets[done];
-        while (done + take < n_reads && take < rcap && offsets[done + take + 1] - b0 <= bcap) ++take;
-        if (take == 0) {
-            rs->acquired = false;
-            return fail("read %llu does not fit the staging buffer (%llu bases)", (unsigned long long) done,
-                        (unsigned long long) bcap);
-        }
-        for (uint64_t i = 0; i <= take; ++i) ho[i] = offsets[done + i] - b0;
-        // the copy into the pinned staging buffer is what bounds this path (one thread: ~8 GB/s): several threads
-        parallel_copy(hb, bases + b0, ho[take]);
-        if (commet_readset_stage_commit(rs, take)) return 1;
-        done += take;
-    }
-    return 0;
-}
-
 }  // extern "C"
 
 namespace {
 
-// ---- parallel host ingest (commet_readset_from_fasta) -------------------------------------------------------
-// A piece = a run of whole records of one file.  FASTA files are cut into pieces at lines starting with '>'
-// (a record boundary by the reference's own rule, fasta_file.h:61-68); FASTQ files stay one piece ('@' may also
-// start a quality line).  Pass A counts records and sequence bytes per piece (so that every piece knows its
-// set-wide read number and base offset), pass B parses the pieces into per-thread pinned staging buffers and
-// queues hipMemcpyAsync + the packing kernel at those explicit positions, in any order.
-struct Piece {
-    int file = 0;
-    commet_host::ReadFormat fmt = commet_host::ReadFormat::Fasta;
-    const char *d = nullptr;
-    size_t n = 0;
-    uint64_t n_reads = 0, n_bases = 0;     // pass A
-    uint64_t read0 = 0, base0 = 0;         // prefix
+// ---- host ingest: records are 2-bit packed by the ingest threads (host/ingest_pack.hpp) and uploaded as planes ----
+constexpr uint64_t INGEST_STAGE_BYTES = 16ull << 20;      // one pinned staging buffer of planes (12 bytes per triple)
+constexpr uint64_t INGEST_STAGE_READS = 1ull << 18;       // base offsets per staging buffer
+
+// the upload side of host/ingest_pack.hpp: two pinned staging buffers per worker out of the context's pool; a flush
+// queues hipMemcpyAsync of the planes (and the reads' base offsets) straight to their final place in the read set
+struct HipPackSink {
+    commet_readset *rs = nullptr;
+    std::vector<int> cur;                    // which of its two buffers a worker fills next
+    std::vector<char> inflight;              // per pool buffer
+
+    bool prepare(commet_readset *set, int workers)
+    {
+        rs = set;
+        commet_ctx *c = rs->ctx;
+        if (hipSetDevice(c->device) != hipSuccess) return false;
+        while (c->ingest_pool.size() < (size_t) workers * 2) {   // hipHostMalloc is slow: buffers stay with the context
+            commet_ctx::IngestBuf b;
+            const bool ok = hipHostMalloc((void **) &b.h_planes, INGEST_STAGE_BYTES) == hipSuccess &&
+                            hipHostMalloc((void **) &b.h_goff, INGEST_STAGE_READS * sizeof(uint64_t)) == hipSuccess &&
+                            hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {   // a half-made entry must not stay in the pool
+                if (b.h_planes) (void) hipHostFree(b.h_planes);
+                if (b.h_goff) (void) hipHostFree(b.h_goff);
+                if (b.done) (void) hipEventDestroy(b.done);
+                (void) hipGetLastError();
+                return false;
+            }
+            c->ingest_pool.push_back(b);
+        }
+        cur.assign(workers, 0);
+        inflight.assign((size_t) workers * 2, 0);
+        return true;
+    }
+    bool acquire(int worker, commet_host::PackStage &st)
+    {
+        const size_t bi = (size_t) worker * 2 + cur[worker];
+        commet_ctx::IngestBuf &b = rs->ctx->ingest_pool[bi];
+        if (inflight[bi]) {
+            if (hipEventSynchronize(b.done) != hipSuccess) return false;
+            inflight[bi] = 0;
+        }
+        st.planes = b.h_planes;
+        st.goff = b.h_goff;
+        st.cap_triples = INGEST_STAGE_BYTES / 12;
+        st.cap_reads = INGEST_STAGE_READS;
+        return true;
+    }
+    bool flush(int worker, const commet_host::PackStage &st, uint64_t triple0, uint64_t n_triples, uint64_t read0, uint64_t n_reads)
+    {
+        commet_ctx *c = rs->ctx;
+        const size_t bi = (size_t) worker * 2 + cur[worker];
+        if (triple0 + n_triples > (rs->max_bases >> 5) + rs->max_reads + 1 || read0 + n_reads > rs->max_reads) return false;
+        if (hipSetDevice(c->device) != hipSuccess) return false;
+        if (n_triples && hipMemcpyAsync(rs->d_planes + 3 * triple0, st.planes, n_triples * 12, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+        if (n_reads && hipMemcpyAsync(rs->d_goff + read0, st.goff, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+        if (hipEventRecord(c->ingest_pool[bi].done, c->stream) != hipSuccess) return false;
+        inflight[bi] = 1;
+        cur[worker] ^= 1;
+        return true;
+    }
 };
 
-struct IngestStage {
-    uint8_t *h_bases = nullptr;
-    uint64_t *h_offs = nullptr;
-    uint8_t *d_bases = nullptr;
-    uint64_t *d_offs = nullptr;
-    hipEvent_t done = nullptr;
-    bool inflight = false;
-};
-
-constexpr uint64_t INGEST_STAGE_BASES = 16ull << 20;
-constexpr uint64_t INGEST_STAGE_READS = 1ull << 18;
-
-void count_piece(Piece &p)
+void absorb_summary(commet_readset *rs, const commet_host::PackSummary &sm)
 {
-    if (p.fmt == commet_host::ReadFormat::Fastq) {
-        p.n_reads = commet_host::count_fastq_records(p.d, p.n);
-        commet_host::for_each_fastq_record(p.d, p.n, p.n_reads, [&](const char *, size_t len) { p.n_bases += len; });
-        return;
-    }
-    const char *d = p.d;
-    const size_t n = p.n;
-    size_t i = 0;
-    while (i < n && d[i] != '>') {   // bytes before the first header line belong to no record
-        const char *nl = (const char *) memchr(d + i, '\n', n - i);
-        i = nl ? (size_t) (nl - d) + 1 : n;
-    }
-    while (i < n) {
-        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header
-        size_t j = nl ? (size_t) (nl - d) + 1 : n;
-        ++p.n_reads;
-        while (j < n && d[j] != '>') {
-            nl = (const char *) memchr(d + j, '\n', n - j);
-            const size_t e = nl ? (size_t) (nl - d) : n;
-            p.n_bases += e - j;
-            j = nl ? e + 1 : n;
-        }
-        i = j;
-    }
-}
-
-struct IngestShared {
-    commet_readset *rs;
-    std::mutex mu;
-    std::string err;
-    std::atomic<bool> failed{false};
-};
-
-int commit_at(IngestShared &sh, IngestStage &st, uint64_t n, uint64_t read0, uint64_t base0)
-{
-    commet_readset *rs = sh.rs;
-    commet_ctx *c = rs->ctx;
-    const uint64_t nbases = st.h_offs[n];
-    for (uint64_t i = 0; i < n; ++i) {
-        if (st.h_offs[i + 1] - st.h_offs[i] > 0x7FFFFFFFull) return 1;
-        if (st.h_offs[i + 1] == st.h_offs[i]) {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            rs->empty_reads.push_back(read0 + i);
-        }
-    }
-    if (hipSetDevice(c->device) != hipSuccess) return 1;
-    if (nbases && hipMemcpyAsync(st.d_bases, st.h_bases, nbases, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
-    if (hipMemcpyAsync(st.d_offs, st.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
-    const unsigned grid = (unsigned) ((n + 1 + 255) / 256);
-    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->stream, st.d_bases, st.d_offs, n, read0, base0, rs->d_planes,
-                       rs->d_goff, rs->d_kcnt, rs->d_lenmm, c->k);
-    if (hipGetLastError() != hipSuccess) return 1;
-    if (hipEventRecord(st.done, c->stream) != hipSuccess) return 1;
-    st.inflight = true;
-    return 0;
-}
-
-// parses one piece into the worker's two staging buffers
-int ingest_piece(IngestShared &sh, const Piece &p, IngestStage st[2])
-{
-    int cur = 0;
-    uint64_t used = 0, nreads = 0, read_pos = p.read0, base_pos = p.base0;
-    bool have = false;
-    auto flush = [&]() -> int {
-        if (!have || nreads == 0) return 0;
-        if (commit_at(sh, st[cur], nreads, read_pos, base_pos)) return 1;
-        read_pos += nreads;
-        base_pos += used;
-        cur ^= 1;
-        have = false;
-        return 0;
-    };
-    auto begin = [&]() -> int {
-        if (st[cur].inflight) {
-            if (hipEventSynchronize(st[cur].done) != hipSuccess) return 1;
-            st[cur].inflight = false;
-        }
-        st[cur].h_offs[0] = 0;
-        used = 0;
-        nreads = 0;
-        have = true;
-        return 0;
-    };
-    // a record longer than a staging buffer (a contig or a genome used as a set: the reference takes any length) goes
-    // through a one-off pinned / device buffer pair of its own size
-    auto add_long_read = [&](const char *const *segs, const size_t *lens, int nseg, size_t total) -> int {
-        if (total > 0x7FFFFFFFull) return 2;
-        if (flush()) return 1;
-        IngestStage big;
-        int rc = 1;
-        if (hipSetDevice(sh.rs->ctx->device) == hipSuccess && hipHostMalloc((void **) &big.h_bases, total) == hipSuccess &&
-            hipHostMalloc((void **) &big.h_offs, 2 * sizeof(uint64_t)) == hipSuccess &&
-            hipMalloc((void **) &big.d_bases, total) == hipSuccess && hipMalloc((void **) &big.d_offs, 2 * sizeof(uint64_t)) == hipSuccess &&
-            hipEventCreateWithFlags(&big.done, hipEventDisableTiming) == hipSuccess) {
-            size_t at = 0;
-            for (int q = 0; q < nseg; ++q) {
-                memcpy(big.h_bases + at, segs[q], lens[q]);
-                at += lens[q];
-            }
-            big.h_offs[0] = 0, big.h_offs[1] = total;
-            if (commit_at(sh, big, 1, read_pos, base_pos) == 0 && hipEventSynchronize(big.done) == hipSuccess) {
-                read_pos += 1;
-                base_pos += total;
-                rc = 0;
-            }
-        }
-        if (big.h_bases) (void) hipHostFree(big.h_bases);
-        if (big.h_offs) (void) hipHostFree(big.h_offs);
-        (void) hipFree(big.d_bases);
-        (void) hipFree(big.d_offs);
-        if (big.done) (void) hipEventDestroy(big.done);
-        return rc;
-    };
-    auto add_read = [&](const char *const *segs, const size_t *lens, int nseg, size_t total) -> int {
-        if (total > INGEST_STAGE_BASES) return add_long_read(segs, lens, nseg, total);
-        if (have && (nreads >= INGEST_STAGE_READS || used + total > INGEST_STAGE_BASES))
-            if (flush()) return 1;
-        if (!have && begin()) return 1;
-        for (int q = 0; q < nseg; ++q) {
-            memcpy(st[cur].h_bases + used, segs[q], lens[q]);
-            used += lens[q];
-        }
-        st[cur].h_offs[++nreads] = used;
-        return 0;
-    };
-    if (p.fmt == commet_host::ReadFormat::Fastq) {
-        int rc = 0;
-        commet_host::for_each_fastq_record(p.d, p.n, p.n_reads, [&](const char *s, size_t len) {
-            if (rc) return;
-            rc = add_read(&s, &len, 1, len);
-        });
-        if (rc) return rc;
-        return flush();
-    }
-    const char *d = p.d;
-    const size_t n = p.n;
-    size_t i = 0;
-    while (i < n && d[i] != '>') {
-        const char *nl = (const char *) memchr(d + i, '\n', n - i);
-        i = nl ? (size_t) (nl - d) + 1 : n;
-    }
-    std::vector<const char *> segs;
-    std::vector<size_t> lens;
-    while (i < n) {
-        const char *nl = (const char *) memchr(d + i, '\n', n - i);   // header line
-        size_t j = nl ? (size_t) (nl - d) + 1 : n;
-        segs.clear();
-        lens.clear();
-        size_t total = 0;
-        while (j < n && d[j] != '>') {
-            nl = (const char *) memchr(d + j, '\n', n - j);
-            const size_t e = nl ? (size_t) (nl - d) : n;
-            if (e > j) {
-                segs.push_back(d + j);
-                lens.push_back(e - j);
-                total += e - j;
-            }
-            j = nl ? e + 1 : n;
-        }
-        const int rc = add_read(segs.data(), lens.data(), (int) segs.size(), total);
-        if (rc) return rc;
-        i = j;
-    }
-    return flush();
-}
-
-int ingest_threads()
-{
-    const char *e = getenv("COMMET_INGEST_THREADS");
-    int t = e ? atoi(e) : 8;
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw && t > (int) hw) t = (int) hw;
-    return t < 1 ? 1 : t;
+    rs->host_packed = true;
+    rs->host_min_len = std::min(rs->host_min_len, sm.min_len);
+    rs->host_max_len = std::max(rs->host_max_len, sm.max_len);
+    rs->empty_reads.insert(rs->empty_reads.end(), sm.empty_reads.begin(), sm.empty_reads.end());
 }
 
 }  // namespace
 
 extern "C" {
+
+int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    if (rs->finalized) return fail("read set already finalized");
+    if (rs->files.empty()) return fail("commet_readset_begin_file must be called first");
+    if (rs->acquired) return fail("append with an uncommitted staging buffer");
+    if (n_reads == 0) return 0;
+    if (offsets[0] != 0) return fail("offsets[0] must be 0");
+    const uint64_t nbases = offsets[n_reads];
+    if (rs->n_reads + n_reads > rs->max_reads || rs->n_bases + nbases > rs->max_bases)
+        return fail("read set capacity exceeded (%llu reads / %llu bases reserved)", (unsigned long long) rs->max_reads,
+                    (unsigned long long) rs->max_bases);
+    HipPackSink sink;
+    const int T = commet_host::ingest_threads();
+    if (!sink.prepare(rs, T)) return fail("cannot allocate the ingest staging buffers");
+    commet_host::PackSummary sm;
+    std::string err;
+    const bool ok = commet_host::ingest_arrays(bases, offsets, n_reads, rs->n_reads, rs->n_bases, T, sink, sm, err);
+    // the staging buffers go back to the pool only once their copies are done
+    if (hipStreamSynchronize(rs->ctx->stream) != hipSuccess && ok) return fail("upload failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!ok) return fail("%s", err.empty() ? "read set ingest failed" : err.c_str());
+    absorb_summary(rs, sm);
+    rs->n_reads += n_reads;
+    rs->n_bases += nbases;
+    rs->files.back().count += n_reads;
+    return 0;
+}
 
 commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *paths, int n_paths)
 {
@@ -800,160 +644,55 @@ commet_readset *commet_readset_from_fasta(commet_ctx *c, const char *const *path
 
 commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *data, const uint64_t *sizes, int n_paths)
 {
-    struct Buf {
-        const char *d;
-        size_t n;
-        commet_host::ReadFormat fmt;
-        const char *data() const { return d; }
-        size_t size() const { return n; }
-        commet_host::ReadFormat format() const { return fmt; }
-    };
-    std::vector<std::unique_ptr<Buf>> maps;
+    std::vector<const char *> d(data, data + n_paths);
+    std::vector<size_t> n(sizes, sizes + n_paths);
+    std::vector<commet_host::ReadFormat> fmts;
     for (int i = 0; i < n_paths; ++i) {
-        std::unique_ptr<Buf> b(new Buf{data[i], (size_t) sizes[i], commet_host::sniff_format(data[i], (size_t) sizes[i])});
-        if (b->fmt == commet_host::ReadFormat::Unknown) {
+        fmts.push_back(commet_host::sniff_format(data[i], (size_t) sizes[i]));
+        if (fmts.back() == commet_host::ReadFormat::Unknown) {
             fail("Unknown format: file %d of the set is neither FASTA nor FASTQ text", i);
             return nullptr;
         }
-        maps.push_back(std::move(b));
     }
-    const int T = ingest_threads();
     const bool verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
     const auto tv0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (verbose)
-            fprintf(stderr, "[ingest] %-18s %8.1f ms\n", what,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
-    };
-    // pieces
-    std::vector<Piece> pieces;
-    for (int f = 0; f < n_paths; ++f) {
-        const char *d = maps[f]->data();
-        const size_t n = maps[f]->size();
-        const int want = (maps[f]->format() == commet_host::ReadFormat::Fasta && n > (8u << 20)) ? T * 4 : 1;
-        size_t b = 0;
-        for (int q = 0; q < want && b < n; ++q) {
-            size_t e = (q == want - 1) ? n : std::min(n, (size_t) ((double) n * (q + 1) / want));
-            if (e < n) {   // advance to the next line that starts with '>'
-                const char *x = d + e;
-                for (;;) {
-                    const char *nl = (const char *) memchr(x, '\n', (size_t) (d + n - x));
-                    if (!nl || nl + 1 >= d + n) { e = n; break; }
-                    if (nl[1] == '>') { e = (size_t) (nl + 1 - d); break; }
-                    x = nl + 1;
-                }
-            }
-            if (e > b) {
-                Piece p;
-                p.file = f;
-                p.fmt = maps[f]->format();
-                p.d = d + b;
-                p.n = e - b;
-                pieces.push_back(p);
-            }
-            b = e;
-        }
-    }
-    auto run_parallel = [&](const std::function<void(size_t)> &fn) {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        const int nt = (int) std::min<size_t>((size_t) T, pieces.size());
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back([&, t]() {
-                (void) t;
-                for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) fn(i);
-            });
-        for (std::thread &x : th) x.join();
-    };
-    // pass A: counts
-    lap("split");
-    run_parallel([&](size_t i) { count_piece(pieces[i]); });
-    lap("count");
+    commet_readset *rs = nullptr;
+    HipPackSink sink;
+    std::vector<uint64_t> file_reads;
     uint64_t total_reads = 0, total_bases = 0;
-    std::vector<uint64_t> file_reads(n_paths, 0);
-    for (Piece &p : pieces) {
-        p.read0 = total_reads;
-        p.base0 = total_bases;
-        total_reads += p.n_reads;
-        total_bases += p.n_bases;
-        file_reads[p.file] += p.n_reads;
-    }
-    commet_readset *rs = commet_readset_create(c, total_reads, total_bases);
-    if (!rs) return nullptr;
-    {
-        uint64_t pos = 0;
-        for (int f = 0; f < n_paths; ++f) {
-            rs->files.push_back(FileSpan{pos, file_reads[f]});
-            pos += file_reads[f];
-        }
-    }
-    lap("readset_create");
-    // pass B: parse + upload, T workers with two pinned staging buffers each
-    IngestShared sh;
-    sh.rs = rs;
-    const int nt = (int) std::min<size_t>((size_t) T, std::max<size_t>(pieces.size(), 1));
-    std::vector<IngestStage> stages((size_t) nt * 2);
-    bool ok = hipSetDevice(c->device) == hipSuccess;
-    while (ok && c->ingest_pool.size() < stages.size()) {   // grow the context's pool of staging buffers
-        commet_ctx::IngestBuf b;
-        ok = hipHostMalloc((void **) &b.h_bases, INGEST_STAGE_BASES) == hipSuccess &&
-             hipHostMalloc((void **) &b.h_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
-             hipMalloc((void **) &b.d_bases, INGEST_STAGE_BASES) == hipSuccess &&
-             hipMalloc((void **) &b.d_offs, (INGEST_STAGE_READS + 1) * sizeof(uint64_t)) == hipSuccess &&
-             hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {   // a half-made entry must not stay in the pool: the next ingest would take its null pointers
-            if (b.h_bases) (void) hipHostFree(b.h_bases);
-            if (b.h_offs) (void) hipHostFree(b.h_offs);
-            (void) hipFree(b.d_bases);
-            (void) hipFree(b.d_offs);
-            if (b.done) (void) hipEventDestroy(b.done);
-            (void) hipGetLastError();
-            sh.err = "cannot allocate the ingest staging buffers";
-            break;
-        }
-        c->ingest_pool.push_back(b);
-    }
-    for (size_t i = 0; ok && i < stages.size(); ++i) {
-        const commet_ctx::IngestBuf &b = c->ingest_pool[i];
-        stages[i].h_bases = b.h_bases;
-        stages[i].h_offs = b.h_offs;
-        stages[i].d_bases = b.d_bases;
-        stages[i].d_offs = b.d_offs;
-        stages[i].done = b.done;
-        stages[i].inflight = false;
-    }
-    lap("staging alloc");
-    if (ok) {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back([&, t]() {
-                (void) hipSetDevice(c->device);
-                for (size_t i = next.fetch_add(1); i < pieces.size() && !sh.failed; i = next.fetch_add(1)) {
-                    const int rc = ingest_piece(sh, pieces[i], &stages[(size_t) t * 2]);
-                    if (rc) {
-                        std::lock_guard<std::mutex> lk(sh.mu);
-                        sh.err = rc == 2 ? "read longer than 2^31-1 bases" : "upload failed";
-                        sh.failed = true;
-                    }
-                }
-            });
-        for (std::thread &x : th) x.join();
-        ok = !sh.failed;
-    }
-    lap("parse+upload");
-    (void) hipStreamSynchronize(c->stream);
-    lap("stream sync");
+    commet_host::PackSummary sm;
+    std::string err;
+    const bool ok = commet_host::ingest_files<HipPackSink>(
+        d, n, fmts, commet_host::ingest_threads(),
+        [&](uint64_t reads, uint64_t bases, int workers) -> HipPackSink * {
+            if (verbose)
+                fprintf(stderr, "[ingest] counted            %8.1f ms\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
+            rs = commet_readset_create(c, reads, bases);
+            if (!rs || !sink.prepare(rs, workers)) return nullptr;
+            return &sink;
+        },
+        file_reads, total_reads, total_bases, sm, err);
+    if (rs) (void) hipStreamSynchronize(c->stream);
+    if (verbose)
+        fprintf(stderr, "[ingest] packed + uploaded  %8.1f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
     if (!ok) {
-        fail("%s", sh.err.empty() ? "read set ingest failed" : sh.err.c_str());
-        commet_readset_destroy(rs);
+        if (rs) fail("%s", err.empty() ? "read set ingest failed" : err.c_str());   // (else the failing call has set the message)
+        if (rs) commet_readset_destroy(rs);
         return nullptr;
+    }
+    uint64_t pos = 0;
+    for (int f = 0; f < n_paths; ++f) {
+        rs->files.push_back(FileSpan{pos, file_reads[f]});
+        pos += file_reads[f];
     }
     rs->n_reads = total_reads;
     rs->n_bases = total_bases;
-    std::sort(rs->empty_reads.begin(), rs->empty_reads.end());
+    absorb_summary(rs, sm);
     return rs;
 }
+
 
 uint64_t commet_readset_file_reads(const commet_readset *rs, uint64_t file_index)
 {
@@ -980,14 +719,28 @@ int commet_readset_finalize(commet_readset *rs)
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     rs->st[0].inflight = rs->st[1].inflight = false;
-    // shortest / longest read and largest k-mer count come from the packing kernel; the host copy of the per-read
-    // counts and their prefix sums (chunk planning) are made when the set is first used as an index set (host_counts)
-    uint32_t mm[3] = {0, 0, 0};
+    // shortest / longest read: from the packing kernel (reads that came through the staging API) and from the host
+    // packer (append / from_fasta); the host copy of the per-read counts and their prefix sums (chunk planning) are made
+    // when the set is first used as an index set (host_counts)
+    uint32_t mm[3] = {0xFFFFFFFFu, 0, 0};
     if (rs->n_reads) HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
+    mm[0] = std::min(mm[0], rs->host_min_len);
+    mm[1] = std::max(mm[1], rs->host_max_len);
     rs->uniform_len = (rs->n_reads && mm[0] == mm[1] && mm[0] != 0) ? mm[0] : 0;
     rs->max_len = rs->n_reads ? mm[1] : 0;
     rs->min_len = rs->n_reads ? mm[0] : 0;
+    if (rs->host_packed && rs->n_reads) {
+        // host-packed reads have no counts yet: complete k-mers of every read from its validity plane, on the device
+        const uint64_t nb = rs->n_bases;
+        HIP_OK(hipMemcpyAsync(rs->d_goff + rs->n_reads, &nb, sizeof nb, hipMemcpyHostToDevice, c->stream));   // closes the offsets
+        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((rs->n_reads + 255) / 256)), dim3(256), 0, c->stream, rs->view(), c->k,
+                           rs->d_kcnt, rs->d_lenmm);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
+    }
     rs->max_kcnt = rs->n_reads ? mm[2] : 0;
+    std::sort(rs->empty_reads.begin(), rs->empty_reads.end());
     // the staging buffers are no longer needed: give the memory back
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);

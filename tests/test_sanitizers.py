@@ -52,3 +52,13 @@ def test_threaded_filter_reads_under_tsan():
     for tool in ("bvop", "filter_reads", "extract_reads"):
         _gxx(os.path.join(d, tool), TSAN_FLAGS + [os.path.join(HOST, tool + ".cpp"), "-lz"])
     _child_pytest(["tests/test_host_tools.py"], dict(COMMET_BIN_DIR=d, COMMET_INGEST_THREADS="4", COMMET_FILTER_PIECE_BYTES="1500"), select="filter or extract")
+
+
+def test_ingest_parser_and_packer_under_asan_ubsan_and_tsan():
+    """the threaded parser + 2-bit packer libcommet_hip.so runs in front of hipMemcpyAsync (host/ingest_pack.hpp), through
+    its CPU-only driver: out-of-order pieces, staging buffers that end inside reads, 8 workers"""
+    src = os.path.join(HOST, "ingest_check.cpp")
+    exe = _gxx(os.path.join(SAN, "asan", "bin", "ingest_check"), ASAN_FLAGS + [src, "-lz"])
+    _child_pytest(["tests/test_ingest_pack.py"], dict(COMMET_INGEST_CHECK=exe))
+    exe = _gxx(os.path.join(SAN, "tsan", "bin", "ingest_check"), TSAN_FLAGS + [src, "-lz"])
+    _child_pytest(["tests/test_ingest_pack.py"], dict(COMMET_INGEST_CHECK=exe))
