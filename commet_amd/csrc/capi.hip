@@ -509,8 +509,9 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
 namespace {
 
 // ---- host ingest: records are 2-bit packed by the ingest threads (host/ingest_pack.hpp) and uploaded as planes ----
-constexpr uint64_t INGEST_STAGE_BYTES = 16ull << 20;      // one pinned staging buffer of planes (12 bytes per triple)
-constexpr uint64_t INGEST_STAGE_READS = 1ull << 18;       // base offsets per staging buffer
+constexpr uint64_t INGEST_STAGE_BYTES = 3ull << 20;       // one pinned staging buffer of planes (12 bytes per triple): 8 M bases;
+                                                          // small, because pinning memory costs ~0.2 ms per MiB on first use
+constexpr uint64_t INGEST_STAGE_READS = 1ull << 17;       // base offsets per staging buffer
 
 // the upload side of host/ingest_pack.hpp: two pinned staging buffers per worker out of the context's pool; a flush
 // queues hipMemcpyAsync of the planes (and the reads' base offsets) straight to their final place in the read set

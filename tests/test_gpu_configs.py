@@ -194,6 +194,7 @@ def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx):
     with commet_amd.Context(k=k, t=t) as ctx:
         if max_kmer:
             ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("slice_mode", 1)                                    # k <= 24 with 8 chunks or more would take the bit-sliced regime
         irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
         qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
         kc = irs.kmer_counts()
