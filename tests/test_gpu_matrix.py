@@ -113,19 +113,56 @@ def test_matrix_driver_matches_oracle_on_synthetic_sets(tmp_path, monkeypatch):
                 assert res["matrix"][a][b] == int(tot)
 
 
-def test_matrix_driver_two_ranks_share_the_pairs(abcde, monkeypatch):
-    """N > 1: two processes (torch.distributed.run, gloo) deal the pair chains between them, write their .bv
-    files side by side and rank 0 assembles the matrices.  Both ranks use GPU 0 here (COMMET_FORCE_DEVICE);
+@pytest.mark.parametrize("world", [2, 4])
+def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world):
+    """N > 1: `world` processes (torch.distributed.run, gloo) take contiguous runs of the pair list, every set is
+    parsed by one rank only and reaches the others as a packed image (commet_readset_save / _load), the ranks write
+    their .bv files side by side and rank 0 assembles the matrices.  All ranks use GPU 0 here (COMMET_FORCE_DEVICE);
     outputs must equal Commet.py's."""
     import subprocess
     gold = os.path.join(GOLD, "abcde", "commet_py", "five_sets")
     monkeypatch.chdir(abcde)
     open("sets.txt", "w").write(open(os.path.join(gold, "sets.txt")).read())
     env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), "-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + (os.getpid() + world) % 300), "-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     for f in sorted(os.listdir(gold)):
         if f.endswith((".csv", ".bv")):
             assert open(os.path.join("out2", f), "rb").read() == open(os.path.join(gold, f), "rb").read(), f
+
+
+def test_packed_image_round_trip(tmp_path):
+    """commet_readset_save / _load: a set parsed from three files (ragged reads, N, lowercase, FASTQ + gzip) and its
+    packed image loaded into a context with ANOTHER k give the same per-file read counts, k-mer counts and job results"""
+    import commet_amd
+    import util
+    rng = np.random.default_rng(9)
+    reads = [util.random_reads(rng, n, 5, 260, n_rate=0.02) for n in (700, 1, 1300)]
+    files = []
+    for i, (r, fmt) in enumerate(zip(reads, ("fa", "fq.gz", "fa"))):
+        p = str(tmp_path / f"s{i}.{fmt}")
+        util.write_reads(p, r, fmt, rng=rng, multiline=(i == 2))
+        files.append(p)
+    q = util.related_reads(rng, [x for r in reads for x in r], 1500, 20, 200, share=0.6)
+    qb, qo = util.to_batch(q)
+    with commet_amd.Context(k=25, t=2) as c1:
+        a = commet_amd.ReadSet.from_fasta(c1, files)
+        a.save(str(tmp_path / "a.pk"))
+        counts, kc25 = a.file_reads(), a.kmer_counts()
+        b = commet_amd.ReadSet.load(c1, str(tmp_path / "a.pk"))
+        assert b.file_reads() == counts and np.array_equal(b.kmer_counts(), kc25)
+        qs = commet_amd.ReadSet.from_files(c1, [(qb, qo)])
+        ra, rb = c1.index_and_search(a, [qs]), c1.index_and_search(b, [qs])
+        assert np.array_equal(ra[0][0], rb[0][0]) and ra[1][0]["shared"] == rb[1][0]["shared"] > 100
+        rq = c1.index_and_search(qs, [b])                      # the loaded set as the search set
+        assert np.array_equal(rq[0][0], c1.index_and_search(qs, [a])[0][0])
+    with commet_amd.Context(k=16, t=1) as c2:                   # the image does not depend on k
+        a = commet_amd.ReadSet.from_fasta(c2, files)
+        b = commet_amd.ReadSet.load(c2, str(tmp_path / "a.pk"))
+        assert np.array_equal(a.kmer_counts(), b.kmer_counts()) and not np.array_equal(b.kmer_counts(), kc25)
+        qs = commet_amd.ReadSet.from_files(c2, [(qb, qo)])
+        assert np.array_equal(c2.index_and_search(a, [qs])[0][0], c2.index_and_search(b, [qs])[0][0])
+    with commet_amd.Context(k=16, t=1) as c3, pytest.raises(commet_amd.CommetError):
+        commet_amd.ReadSet.load(c3, files[0])                  # not a packed image
