@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "index_part.hpp"
 #include "slice_search.hpp"
+#include "tile_search.hpp"
 #include "read_iter.hpp"
 #include "host/fasta_source.hpp"
 #include "host/ingest_pack.hpp"
@@ -167,6 +168,9 @@ struct commet_ctx {
     uint32_t *slice_stage = nullptr, *slice_tables = nullptr;
     SliceChunk *d_slice_chunks = nullptr;
     uint64_t slice_stage_words = 0, slice_table_words = 0, slice_chunks_cap = 0;
+    uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
+    uint64_t qres_cap = 0;
+    int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
     int slice_mode = 0;               // option: 0 auto, 1 never, 2 whenever k allows it
     int slice_gw = 0;                 // option: words per bit-sliced entry (32 chunks each); 0 = by the number of chunks
     uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
@@ -220,6 +224,21 @@ struct commet_readset {
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
     uint32_t max_len = 0, min_len = 0;
+    // query list of the tiled search (tile_search.hpp): the set's lane-a addresses sorted by address slice, made on first use
+    struct QueryList {
+        unsigned long long *d_tile_off = nullptr;
+        uint32_t *d_qaddr = nullptr, *d_qwho = nullptr;
+        uint64_t n_records = 0;
+        uint32_t n_slices = 0, n_pieces = 0;
+        int sbits = 0;
+        bool built = false, failed = false;
+        void release()
+        {
+            (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho);
+            *this = QueryList();
+        }
+    };
+    mutable QueryList ql;
     bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
     uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;
     bool finalized = false;
@@ -289,6 +308,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->k = kmer_size;
     c->t = min_hits < 1 ? 1 : min_hits;
     if (const char *e = getenv("COMMET_INDEX_LANES")) c->index_lanes = atoi(e) == 1 ? 1 : 2;   // 1: one kernel at a time (per-kernel profiles)
+    if (const char *e = getenv("COMMET_TILED")) c->tiled_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("COMMET_SLICE_MODE")) c->slice_mode = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
     if (const char *e = getenv("COMMET_SLICE_WORDS")) {
         const int v = atoi(e);
@@ -337,6 +357,7 @@ void commet_destroy(commet_ctx *c)
         if (b.done) (void) hipEventDestroy(b.done);
     }
     c->kclock.release();
+    (void) hipFree(c->d_qres);
     (void) hipFree(c->slice_stage);
     (void) hipFree(c->slice_tables);
     (void) hipFree(c->d_slice_chunks);
@@ -424,6 +445,7 @@ void commet_readset_destroy(commet_readset *rs)
     (void) hipFree(rs->d_sel);
     (void) hipFree(rs->d_tags);
     (void) hipFree(rs->d_found);
+    rs->ql.release();
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
         if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);
@@ -1248,6 +1270,115 @@ bool group8_ok(const commet_ctx *c, const commet_readset *rs)
     return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
 }
 
+// ---- tiled search (tile_search.hpp) ----------------------------------------------------------------------------
+constexpr int TQ_SBITS = 23;          // slice = 2^23 bits of plane A's address space: 1 MiB per chunk filter, 2 MiB for a group of two
+
+bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
+{
+    if (c->tiled_mode == 1 || c->count_probes || rs->ql.failed) return false;
+    if (c->k <= TQ_SBITS || c->k > 32 || g < 1 || g > 2) return false;
+    const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
+    if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
+    if (rs->n_reads >= (1ull << 32)) return false;
+    return c->tiled_mode == 2 || rs->n_reads >= (1ull << 20);
+}
+
+// the set's query list for this context's (k, t): counted, scanned, filled; kept with the set
+int build_query_list(commet_ctx *c, const commet_readset *rs)
+{
+    commet_readset::QueryList &ql = rs->ql;
+    if (ql.built) return 0;
+    ql.sbits = TQ_SBITS;
+    ql.n_slices = 1u << (c->k - ql.sbits);
+    ql.n_pieces = (uint32_t) ((rs->n_reads + TQ_PIECE - 1) / TQ_PIECE);
+    const uint64_t entries = (uint64_t) ql.n_slices * ql.n_pieces;
+    const uint32_t nb = (uint32_t) ((entries + 4095) / 4096);
+    unsigned long long *d_totals = nullptr;
+    hipError_t e = hipMalloc((void **) &ql.d_tile_off, (entries + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        const int t = t_eff(c, rs);
+        const size_t lds = (size_t) ql.n_slices * 4;
+        {
+            KScope ks(c, "tq_count_kernel", c->stream);
+            hipLaunchKernelGGL(tq_count_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                               ql.n_pieces, ql.d_tile_off);
+        }
+        {
+            KScope ks(c, "tq_scan_kernels", c->stream);
+            hipLaunchKernelGGL(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals);
+            hipLaunchKernelGGL(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, c->stream, d_totals, nb, d_totals + nb);
+            hipLaunchKernelGGL(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals, d_totals + nb);
+        }
+        e = hipGetLastError();
+        unsigned long long total = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_totals + nb, sizeof total, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        ql.n_records = total;
+        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 4);
+        if (e == hipSuccess) {
+            KScope ks(c, "tq_fill_kernel", c->stream);
+            hipLaunchKernelGGL(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                               ql.n_pieces, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+            e = hipGetLastError();
+        }
+    }
+    (void) hipFree(d_totals);
+    if (e != hipSuccess) {   // no room for the list (or a launch failed): this set keeps the gather kernels
+        (void) hipGetLastError();
+        ql.release();
+        ql.failed = true;
+        return 1;
+    }
+    ql.built = true;
+    return 0;
+}
+
+// one pass of rs over the g <= 2 chunk filters in slots slot0 .. slot0 + g - 1 (g == 2: slots 0, 1 with interleaved A planes)
+int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot0, const uint64_t *d_sel, uint64_t *d_tags,
+                        unsigned long long *d_counters, uint32_t cstride)
+{
+    if (rs->n_reads == 0) return 0;
+    const commet_readset::QueryList &q = rs->ql;
+    if (c->qres_cap < q.n_records) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) hipFree(c->d_qres);
+        c->d_qres = nullptr, c->qres_cap = 0;
+        HIP_OK(hipMalloc((void **) &c->d_qres, std::max<uint64_t>(q.n_records, 1)));
+        c->qres_cap = q.n_records;
+    }
+    QueryListView v;
+    v.tile_off = q.d_tile_off, v.qaddr = q.d_qaddr, v.qwho = q.d_qwho, v.n_slices = q.n_slices, v.n_pieces = q.n_pieces, v.sbits = q.sbits;
+    FilterGroupView fg;
+    fg.slot0 = c->slot_ptr(slot0);
+    fg.il_a = g == 1 ? c->slot_ptr(slot0) : c->il_a;   // one filter: its own plane A (stride 1)
+    fg.slot_words = 4 * c->plane_words;
+    fg.plane_words = c->plane_words;
+    fg.g = g;
+    {
+        KScope ks(c, "tq_probe_kernel", c->stream);
+        if (g == 1) hipLaunchKernelGGL(tq_probe_kernel<1>, dim3(8 * 256), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+        else hipLaunchKernelGGL(tq_probe_kernel<2>, dim3(8 * 256), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+    }
+    HIP_OK(hipGetLastError());
+    const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;
+    const int t = t_eff(c, rs);
+    {
+        KScope ks(c, "tq_replay_kernel", c->stream);
+        const dim3 grid(q.n_pieces), block(TQ_PIECE);
+        if (g == 1) {
+            if (three) hipLaunchKernelGGL((tq_replay_kernel<1, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            else hipLaunchKernelGGL((tq_replay_kernel<1, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+        } else {
+            if (three) hipLaunchKernelGGL((tq_replay_kernel<2, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            else hipLaunchKernelGGL((tq_replay_kernel<2, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 // words per bit-sliced entry (32 chunk filters per word) for a job of n_chunks chunks; 0 = the job takes the slot path
 int slice_words(const commet_ctx *c, uint64_t n_chunks)
 {
@@ -1647,12 +1778,19 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         for (int s = 0; s < n_search && !rc; ++s) {
             const commet_readset *rs = search_rs[s];
             unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
-            if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
+            if (g == 2 && tiled_ok(c, rs, g) && build_query_list(c, rs) == 0) {
+                // large set, two chunk filters: lane-a gathers served from L2, slice by slice (tile_search.hpp)
+                if (launch_search_tiled(c, rs, 2, 0, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search))) { rc = 1; break; }
+                if (rs->n_reads) ++n_search_launches;
+            } else if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
                 if (launch_search_group(c, rs, g, gs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
                     c->cur_slot = i;
+                    if (tiled_ok(c, rs, 1) && build_query_list(c, rs) == 0) {   // the same, one filter at a time
+                        if (launch_search_tiled(c, rs, 1, i, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt + 2 * (uint64_t) i * n_search, (uint32_t) (2 * n_search))) rc = 1;
+                    } else
                     if (launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
                     if (rs->n_reads) ++n_search_launches;
                 }
@@ -1772,6 +1910,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->kclock.collect();
         c->kclock.on = value != 0;
         if (value) c->kclock.reset();
+        return 0;
+    }
+    if (!strcmp(name, "tiled_search")) {      // 0 auto, 1 never, 2 whenever the set and the group allow it (tests)
+        if (value < 0 || value > 2) return fail("tiled_search must be 0, 1 or 2");
+        c->tiled_mode = (int) value;
         return 0;
     }
     if (!strcmp(name, "slice_mode")) {        // 0 auto (8 chunks or more, 12 <= k <= 24), 1 never, 2 whenever k allows it
@@ -1898,6 +2041,35 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         (void) hipEventDestroy(e1);
         (void) hipFree(a);
         (void) hipFree(b);
+        return 0;
+    }
+    if (atomic >= 100) {   // windowed gathers: atomic = 100 + log2(window bytes), +1000 = XCD-aware sweep; n_access gathers in all
+        const int xcd = atomic >= 1000 ? 1 : 0;
+        const uint32_t win_words = (1u << ((atomic % 1000) - 100)) / 4;
+        const uint64_t n_windows = table_bytes / 4 / win_words;
+        uint32_t *table = nullptr, *sink = nullptr;
+        HIP_OK(hipMalloc((void **) &table, n_windows * win_words * 4));
+        HIP_OK(hipMalloc((void **) &sink, 4));
+        HIP_OK(hipMemsetAsync(table, 0, n_windows * win_words * 4, c->stream));
+        // one resident set of workgroups (8 per CU); every thread does `iters` gathers in each window of its XCD's eighth
+        const uint32_t grid = 256 * 8;
+        const uint32_t iters = (uint32_t) std::max<uint64_t>(1, n_access / (grid * 256ull) / std::max<uint64_t>(n_windows / 8, 1));
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_OK(hipEventRecord(e0, c->stream));
+            hipLaunchKernelGGL(membench_window_kernel, dim3(grid), dim3(256), 0, c->stream, table, n_windows, win_words, iters, xcd, sink);
+            HIP_OK(hipEventRecord(e1, c->stream));
+        }
+        HIP_OK(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms_out) *ms_out = ms / ((double) iters * (double) (n_windows / 8) * grid * 256.0) * (double) n_access;
+        (void) hipEventDestroy(e0);
+        (void) hipEventDestroy(e1);
+        (void) hipFree(table);
+        (void) hipFree(sink);
         return 0;
     }
     uint64_t words = 1;

@@ -940,6 +940,29 @@ __global__ __launch_bounds__(256) void membench_kernel(uint32_t *__restrict__ ta
     if (MODE != 1 && acc == 0x12345678u) sink[0] = acc;   // keep the loads alive
 }
 
+// Windowed gathers: what the tiled search's probe pass would see.  The table is cut into windows of win_words words;
+// workgroup b works on XCD b % 8 (workgroups are dealt to the XCDs round-robin) and sweeps that XCD's eighth of the
+// windows in order, so that at any time the workgroups of one XCD gather from one or two windows — which then live in
+// that XCD's L2.  `xcd_aware` = 0 lets consecutive workgroups take consecutive windows instead (windows spread over the XCDs).
+__global__ __launch_bounds__(256) void membench_window_kernel(const uint32_t *__restrict__ table, uint64_t n_windows, uint32_t win_words,
+                                                              uint32_t per_window, int xcd_aware, uint32_t *__restrict__ sink)
+{
+    // persistent sweep: the workgroups of XCD x (b % 8 == x) walk windows x * n/8 .. (x+1) * n/8 - 1 together, every
+    // thread doing per_window gathers in each; xcd_aware = 0: workgroup b starts b windows further on (no sharing)
+    const uint64_t per_xcd = n_windows / 8;
+    uint64_t s = (blockIdx.x * 256ull + threadIdx.x) * 0x100000001B3ull + 777;
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < per_xcd; ++i) {
+        const uint64_t win = xcd_aware ? (blockIdx.x % 8) * per_xcd + i : (blockIdx.x * 7919ull + i) % n_windows;
+        const uint32_t *w = table + win * win_words;
+        for (uint32_t j = 0; j < per_window; ++j) {
+            s = splitmix64(s);
+            acc ^= w[s % win_words];
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // LDS microbenchmark: what one CU's LDS pipeline does per cycle for this path's access shapes (index_part.hpp).
 // MODE 0: atomic add, no return; 1: atomic add, rank returned; 2: atomic OR, no return; 3: plain store; 4: plain load;
 // 5: atomic add with return, conflict-free addresses (lane-private counters).  Addresses: uniform over n_words.
