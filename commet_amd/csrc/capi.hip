@@ -1197,16 +1197,22 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
                           uint64_t *d_tags, unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes)
 {
     const dim3 g((unsigned) ((rs->n_reads + 255) / 256)), b(256);
-    const size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
+    size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
+    // the lanes' reads staged in LDS too (3 * nw_max words each) when that still fits 64 KiB
+    uint32_t rw_nw = 0;
+    if (!d_probes && nw_max <= 8 && lds + (size_t) 3 * nw_max * 256 * sizeof(uint32_t) <= (64u << 10) && !getenv("COMMET_NO_STAGE_READS")) {
+        rw_nw = nw_max;
+        lds += (size_t) 3 * nw_max * 256 * sizeof(uint32_t);
+    }
     KScope ks(c, "search_group_kernel", c->stream);
     if (d_probes) {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
-                           d_counters, cstride, d_probes);
+                           d_counters, cstride, d_probes, rw_nw);
     } else {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
-                           d_counters, cstride, d_probes);
+                           d_counters, cstride, d_probes, rw_nw);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -1271,7 +1277,8 @@ bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 }
 
 // ---- tiled search (tile_search.hpp) ----------------------------------------------------------------------------
-constexpr int TQ_SBITS = 23;          // slice = 2^23 bits of plane A's address space: 1 MiB per chunk filter, 2 MiB for a group of two
+constexpr int TQ_SBITS = 24;          // slice = 2^24 bits of plane A's address space: 2 MiB per chunk filter, 4 MiB for a group of two
+                                      // (measured on configs[1]: 22 / 23 / 24 -> probe 2.43 / 2.56 / 2.35 ms, gpurun_out/r02_tq_ab2.log)
 
 bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
 {
@@ -1280,7 +1287,9 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
     if (rs->n_reads >= (1ull << 32)) return false;
-    return c->tiled_mode == 2 || rs->n_reads >= (1ull << 20);
+    if (c->tiled_mode == 2) return true;
+    // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB
+    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= (4ull << 30);
 }
 
 // the set's query list for this context's (k, t): counted, scanned, filled; kept with the set
@@ -1289,6 +1298,7 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
     commet_readset::QueryList &ql = rs->ql;
     if (ql.built) return 0;
     ql.sbits = TQ_SBITS;
+    if (const char *e = getenv("COMMET_TQ_SBITS")) ql.sbits = std::max(c->k - 10, std::min(c->k - 1, atoi(e)));   // A/B runs
     ql.n_slices = 1u << (c->k - ql.sbits);
     ql.n_pieces = (uint32_t) ((rs->n_reads + TQ_PIECE - 1) / TQ_PIECE);
     const uint64_t entries = (uint64_t) ql.n_slices * ql.n_pieces;
@@ -1358,8 +1368,12 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
     fg.g = g;
     {
         KScope ks(c, "tq_probe_kernel", c->stream);
-        if (g == 1) hipLaunchKernelGGL(tq_probe_kernel<1>, dim3(8 * 256), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
-        else hipLaunchKernelGGL(tq_probe_kernel<2>, dim3(8 * 256), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+        static const unsigned wpx = [] {
+            const char *e = getenv("COMMET_TQ_WPX");   // workgroups per XCD (A/B runs); a multiple of the 32 CUs of an XCD keeps the sweep even
+            return e ? (unsigned) std::max(1, atoi(e)) : 64u;   // measured: 32 or 64 (1 or 2 per CU) 2.3-2.6 ms, 128: 3.7, 256: 4.8
+        }();
+        if (g == 1) hipLaunchKernelGGL(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+        else hipLaunchKernelGGL(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
     }
     HIP_OK(hipGetLastError());
     const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;

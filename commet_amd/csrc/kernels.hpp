@@ -155,6 +155,13 @@ template <> struct ItemWords<uint32_t> {
         if (w) hi[0] = p[3 * w - 3], lo[0] = p[3 * w - 2], va[0] = p[3 * w - 1];
         else hi[0] = lo[0] = va[0] = 0;
     }
+    // the same through get(i) = word i of the read's triples (a copy of the read kept in LDS, see ReadWords)
+    template <typename G> __device__ __forceinline__ void load_with(G &&get, uint32_t w)
+    {
+        hi[1] = get(3 * w), lo[1] = get(3 * w + 1), va[1] = get(3 * w + 2);
+        if (w) hi[0] = get(3 * w - 3), lo[0] = get(3 * w - 2), va[0] = get(3 * w - 1);
+        else hi[0] = lo[0] = va[0] = 0;
+    }
     // window of the k bases ending at bit j of word w; false if any is not ACGT
     __device__ __forceinline__ bool window(uint32_t j, int k, uint32_t mask, uint32_t &wh, uint32_t &wl) const
     {
@@ -173,6 +180,14 @@ template <> struct ItemWords<uint64_t> {
         if (w) hi[1] = p[3 * w - 3], lo[1] = p[3 * w - 2], va[1] = p[3 * w - 1];
         else hi[1] = lo[1] = va[1] = 0;
         if (w > 1) hi[0] = p[3 * w - 6], lo[0] = p[3 * w - 5], va[0] = p[3 * w - 4];
+        else hi[0] = lo[0] = va[0] = 0;
+    }
+    template <typename G> __device__ __forceinline__ void load_with(G &&get, uint32_t w)
+    {
+        hi[2] = get(3 * w), lo[2] = get(3 * w + 1), va[2] = get(3 * w + 2);
+        if (w) hi[1] = get(3 * w - 3), lo[1] = get(3 * w - 2), va[1] = get(3 * w - 1);
+        else hi[1] = lo[1] = va[1] = 0;
+        if (w > 1) hi[0] = get(3 * w - 6), lo[0] = get(3 * w - 5), va[0] = get(3 * w - 4);
         else hi[0] = lo[0] = va[0] = 0;
     }
     __device__ __forceinline__ static uint64_t ext(const uint32_t *x, uint32_t s, uint64_t mask)
@@ -465,6 +480,54 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 }
 
 // ---------------------------------------------------------------------------
+// Lane-a bits of up to 32 consecutive windows of one strand, fetched with INDEPENDENT loads (eight in flight at a time):
+// bit j of the result = the complete window ending at q_lo + j (q_lo + j <= q_hi) has its lane-a bit set in the A plane
+// `plane_a` (words interleaved with stride `stride`, this chunk at offset `ci`).  Used for the windows behind the first-
+// hit ones: a scan that already has a hit needs them, and probing them one after the other (load, test, next window)
+// puts up to (t - 1) * k dependent HBM round trips into the wave — measured 8.6 ms of a 10.2 ms kernel on configs[1].
+// ---------------------------------------------------------------------------
+template <typename W>
+__device__ __forceinline__ uint32_t lane_a_bits32(const uint32_t *__restrict__ p, uint32_t len, int q_lo, int q_hi, int k, int strand,
+                                                  const uint32_t *__restrict__ plane_a, int stride, int ci)
+{
+    using T = KeyTraits<W>;
+    const int sh = T::BITS - k;
+    const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+    q_hi = min(q_hi, min(q_lo + 31, (int) len - 1));
+    if (q_hi < q_lo) return 0u;
+    // roll up to q_lo - 1 (the k - 1 bases before the first window are enough)
+    W wh = 0;
+    uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
+    auto roll = [&](int pos) {
+        const uint32_t w = (uint32_t) pos >> 5, j = (uint32_t) pos & 31u;
+        if (w != cw) hi = p[3 * w], va = p[3 * w + 2], cw = w;
+        wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+        run = ((va >> j) & 1u) ? run + 1 : 0;
+    };
+    for (int pos = max(0, q_lo - (k - 1)); pos < q_lo; ++pos) roll(pos);
+    uint32_t bits = 0;
+    for (int q0 = q_lo; q0 <= q_hi; q0 += 8) {
+        uint32_t v[8], b[8];
+        bool on[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            on[u] = false, v[u] = 0, b[u] = 0;
+            if (q0 + u > q_hi) continue;
+            roll(q0 + u);
+            if (run < (uint32_t) k) continue;
+            const W ka = strand ? (W) (~wh & mask) : (W) (T::brev(wh) >> sh);
+            const W addr = psi_a<W>(ka, k);
+            on[u] = true, b[u] = (uint32_t) addr & 31u;
+            v[u] = plane_a[(uint64_t) (addr >> 5) * stride + ci];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (on[u]) bits |= ((v[u] >> b[u]) & 1u) << (q0 + u - q_lo);
+    }
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
 // search against a GROUP of chunk filters in one pass over the reads.
 // The reference re-scans the search set once per index chunk (index_and_search.cpp:
 // 255-277); a read's result is found_1 | found_2 | ... with found_c depending on
@@ -506,10 +569,14 @@ template <typename W, int GS, bool COUNT>
 __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterGroupView fg, int k, int t, uint32_t nw_max,
                                                            const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                            unsigned long long *__restrict__ counters, uint32_t cstride,
-                                                           unsigned long long *__restrict__ probe_counter)
+                                                           unsigned long long *__restrict__ probe_counter, uint32_t rw_nw)
 {
     using T = KeyTraits<W>;
     extern __shared__ uint32_t gmask[];   // [chunk][strand][word][thread]
+    // rw_nw != 0: the lane's read (3 * rw_nw words) is copied to LDS once, [word][thread]; the gather and every window
+    // extraction of the replay then read LDS.  The kernel is bound by memory REQUESTS (L2 hits count too, at ~270 G/s):
+    // ~100 of the ~150 requests per read were re-reads of these 12 words.
+    uint32_t *const rw = gmask + (uint32_t) fg.g * 2u * nw_max * 256u;
     auto mask_at = [&](int i, int strand, uint32_t w) -> uint32_t & {
         return gmask[(((uint32_t) i * 2u + (uint32_t) strand) * nw_max + w) * 256u + threadIdx.x];
     };
@@ -533,6 +600,11 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
         const uint32_t *p = rv.planes + 3 * t0;
         const int sh = T::BITS - k;
         const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+        if (rw_nw && !COUNT) {
+            const uint32_t n3 = 3u * ((len + 31u) >> 5);
+            for (uint32_t i = 0; i < n3; ++i) rw[i * 256u + threadIdx.x] = p[i];
+        }
+        auto getw = [&](uint32_t i) -> uint32_t { return (rw_nw && !COUNT) ? rw[i * 256u + threadIdx.x] : p[i]; };
         // Pruning (exact, see search_kernel): with `seen` hits a window ending at q matters only if
         // q + (t-seen-1)*k <= len-1.  The gather therefore covers the windows that can be a FIRST hit,
         // q <= pe = len-1-(t-1)*k (all of them in COUNT builds); later windows are needed only after a real
@@ -544,7 +616,7 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
             W wh = 0;
             uint32_t run = 0;
             for (uint32_t w = 0; w * 32u < len && (int) (w * 32u) <= pe; ++w) {
-                const uint32_t hi = p[3 * w], va = p[3 * w + 2];
+                const uint32_t hi = getw(3 * w), va = getw(3 * w + 2);
                 const uint32_t nb = min(min(32u, len - w * 32u), (uint32_t) (pe - (int) (w * 32u) + 1));
                 uint32_t fm[GS], rm[GS];
 #pragma unroll
@@ -599,7 +671,7 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                         uint32_t m = mask_at(i, strand, w);
                         if (!m) continue;
                         ItemWords<W> it;
-                        it.load(p, w);
+                        it.load_with(getw, w);
                         while (m && !found) {
                             const uint32_t j = (uint32_t) __ffs((int) m) - 1u;
                             m &= m - 1u;
@@ -618,21 +690,29 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                             }
                         }
                     }
-                    // windows behind the gathered ones matter only after a first full hit (pruning, see above)
+                    // windows behind the gathered ones matter only after a first full hit (pruning, see above); their lane-a
+                    // bits come 32 windows at a time with independent loads (lane_a_bits32), then only the set ones are probed
                     if (!found && !dead && seen >= 1) {
-                        for (int q = max(pe + 1, next_ok); q <= last && !found; ++q) {
-                            if (q + (t - seen - 1) * k > last) break;
-                            ItemWords<W> it;
-                            it.load(p, (uint32_t) q >> 5);
-                            W wh, wl;
-                            if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;   // a base of the window is not ACGT
-                            const W ka = strand == 0 ? (W) (T::brev(wh) >> sh) : (W) (~wh & mask);
-                            const W addr = psi_a<W>(ka, k);
-                            if (!((fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> ((uint32_t) addr & 31u)) & 1u)) continue;
-                            if (probe_bcd(wh, wl)) {
-                                ++seen;
-                                q += k - 1;   // the next complete window ends k bases later
-                                if (seen >= t) found = true;
+                        for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                            if (qb + (t - seen - 1) * k > last) break;
+                            uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i);
+                            while (m && !found) {
+                                const int q = qb + (__ffs((int) m) - 1);
+                                m &= m - 1u;
+                                if (q < next_ok) continue;
+                                if (q + (t - seen - 1) * k > last) {
+                                    dead = true;
+                                    break;
+                                }
+                                ItemWords<W> it;
+                                it.load_with(getw, (uint32_t) q >> 5);
+                                W wh, wl;
+                                (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
+                                if (probe_bcd(wh, wl)) {
+                                    ++seen;
+                                    next_ok = q + k;   // the next complete window ends k bases later
+                                    if (seen >= t) found = true;
+                                }
                             }
                         }
                     }
@@ -835,20 +915,27 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                         }
                     }
                 }
-                if (!found && !dead && seen >= 1) {   // windows behind the gathered ones, after a first full hit only
-                    for (int q = max(pe + 1, next_ok); q <= last && !found; ++q) {
-                        if (q + (t - seen - 1) * k > last) break;
-                        ItemWords<W> it;
-                        it.load(p, (uint32_t) q >> 5);
-                        W wh, wl;
-                        if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;
-                        const W ka = strand == 0 ? (W) (T::brev(wh) >> sh) : (W) (~wh & mask);
-                        const W addr = psi_a<W>(ka, k);
-                        if (!((fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> ((uint32_t) addr & 31u)) & 1u)) continue;
-                        if (probe_bcd(wh, wl)) {
-                            ++seen;
-                            q += k - 1;
-                            if (seen >= t) found = true;
+                if (!found && !dead && seen >= 1) {   // windows behind the gathered ones, after a first full hit only (lane_a_bits32)
+                    for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                        if (qb + (t - seen - 1) * k > last) break;
+                        uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i);
+                        while (m && !found) {
+                            const int q = qb + (__ffs((int) m) - 1);
+                            m &= m - 1u;
+                            if (q < next_ok) continue;
+                            if (q + (t - seen - 1) * k > last) {
+                                dead = true;
+                                break;
+                            }
+                            ItemWords<W> it;
+                            it.load(p, (uint32_t) q >> 5);
+                            W wh, wl;
+                            (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
+                            if (probe_bcd(wh, wl)) {
+                                ++seen;
+                                next_ok = q + k;
+                                if (seen >= t) found = true;
+                            }
                         }
                     }
                 }

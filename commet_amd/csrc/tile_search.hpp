@@ -24,10 +24,15 @@
 #pragma once
 
 #include "kernels.hpp"
+#include "index_part.hpp"   // block_scan
+
+#ifndef COMMET_TQ_ABLATE
+#define COMMET_TQ_ABLATE 0   // timing ablations exist only in builds made with -DCOMMET_TQ_ABLATE=<mask> (512: no gather, 1024: no replay)
+#endif
 
 namespace commet {
 
-constexpr uint32_t TQ_PIECE = 1024;       // reads per piece = threads of the replay workgroup
+constexpr uint32_t TQ_PIECE = 256;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
 constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
 
 struct QueryListView {
@@ -182,30 +187,59 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
 // Persistent grid of 8 * WPX workgroups: workgroup b belongs to XCD b % 8 and sweeps slices [x * S / 8, (x + 1) * S / 8)
 // together with the other workgroups of that XCD.  planes_a: the group's A planes, word-interleaved with stride GS.
 template <int GS>
+__device__ __forceinline__ uint32_t tq_probe_one(const uint32_t *__restrict__ base, uint32_t q)
+{
+    const uint32_t addr = q & 0x7FFFFFFFu, bit = addr & 31u;
+    const bool selfp = q >> 31;
+    if constexpr (GS == 1) {
+        const uint32_t wd = base[addr >> 5];
+        const uint32_t fb = (wd >> bit) & 1u;
+        return fb | ((selfp ? fb : (wd >> (bit ^ 1u)) & 1u) << 1);
+    } else {
+        const uint2 wd = *(const uint2 *) (base + (uint64_t) (addr >> 5) * 2);
+        const uint32_t f0 = (wd.x >> bit) & 1u, f1 = (wd.y >> bit) & 1u;
+        const uint32_t r0 = selfp ? f0 : (wd.x >> (bit ^ 1u)) & 1u, r1 = selfp ? f1 : (wd.y >> (bit ^ 1u)) & 1u;
+        return f0 | (f1 << 1) | (r0 << 2) | (r1 << 3);
+    }
+}
+
+template <int GS>
 __global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const uint32_t *__restrict__ planes_a, uint8_t *__restrict__ qres)
 {
     const uint32_t x = blockIdx.x % 8, j = blockIdx.x / 8, wpx = gridDim.x / 8;
     const uint32_t s_lo = (uint32_t) ((uint64_t) x * ql.n_slices / 8), s_hi = (uint32_t) ((uint64_t) (x + 1) * ql.n_slices / 8);
+    unsigned long long a = ql.tile_off[(uint64_t) s_lo * ql.n_pieces];
     for (uint32_t s = s_lo; s < s_hi; ++s) {
-        const unsigned long long a = ql.tile_off[(uint64_t) s * ql.n_pieces], e = ql.tile_off[(uint64_t) (s + 1) * ql.n_pieces];
+        const unsigned long long e = ql.tile_off[(uint64_t) (s + 1) * ql.n_pieces];
         const uint32_t *base = planes_a + (((uint64_t) s << ql.sbits) >> 5) * GS;
-        for (unsigned long long i = a + (unsigned long long) j * 256 + threadIdx.x; i < e; i += (unsigned long long) wpx * 256) {
-            const uint32_t q = ql.qaddr[i];
-            const uint32_t addr = q & 0x7FFFFFFFu, bit = addr & 31u;
-            const bool selfp = q >> 31;
-            uint32_t res = 0;
-            if constexpr (GS == 1) {
-                const uint32_t wd = base[addr >> 5];
-                const uint32_t fb = (wd >> bit) & 1u;
-                res = fb | ((selfp ? fb : (wd >> (bit ^ 1u)) & 1u) << 1);
-            } else {
-                const uint2 wd = *(const uint2 *) (base + (uint64_t) (addr >> 5) * 2);
-                const uint32_t f0 = (wd.x >> bit) & 1u, f1 = (wd.y >> bit) & 1u;
-                const uint32_t r0 = selfp ? f0 : (wd.x >> (bit ^ 1u)) & 1u, r1 = selfp ? f1 : (wd.y >> (bit ^ 1u)) & 1u;
-                res = f0 | (f1 << 1) | (r0 << 2) | (r1 << 3);
+        // whole groups of four records [4m, 4m + 4) inside [a, e): one 16-byte load of addresses, four gathers, one 4-byte
+        // store of results.  The address and result streams are read / written once: non-temporal, so that they do not
+        // push the slice's filter words out of L2.
+        const unsigned long long a4 = (a + 3) & ~3ull, e4 = e & ~3ull;
+        if (a4 < e4) {
+            for (unsigned long long m = a4 / 4 + (unsigned long long) j * 256 + threadIdx.x; m < e4 / 4; m += (unsigned long long) wpx * 256) {
+                const uint32_t *qp = ql.qaddr + 4 * m;
+                const uint32_t q0 = __builtin_nontemporal_load(qp), q1 = __builtin_nontemporal_load(qp + 1),
+                               q2 = __builtin_nontemporal_load(qp + 2), q3 = __builtin_nontemporal_load(qp + 3);
+                const uint32_t r = tq_probe_one<GS>(base, q0) | (tq_probe_one<GS>(base, q1) << 8) | (tq_probe_one<GS>(base, q2) << 16) |
+                                   (tq_probe_one<GS>(base, q3) << 24);
+                __builtin_nontemporal_store(r, (uint32_t *) (qres + 4 * m));
             }
-            qres[i] = (uint8_t) res;
         }
+        // the up to three records before a4 and after e4 (all of the slice when it has no whole group)
+        if (j == 0 && threadIdx.x < 8) {
+            unsigned long long i;
+            bool mine;
+            if (a4 < e4) {
+                i = threadIdx.x < 4 ? a + threadIdx.x : e4 + (threadIdx.x - 4);
+                mine = threadIdx.x < 4 ? i < a4 : i < e;
+            } else {                              // fewer than eight records and no aligned group among them
+                i = a + threadIdx.x;
+                mine = i < e;
+            }
+            if (mine) qres[i] = (uint8_t) tq_probe_one<GS>(base, ql.qaddr[i]);
+        }
+        a = e;
     }
 }
 
@@ -220,15 +254,48 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
     auto mask_at = [&](int c, int strand, int h, uint32_t rd) -> uint32_t & { return masks[(((c * 2 + strand) * MW) + h) * TQ_PIECE + rd]; };
     for (uint32_t i = threadIdx.x; i < GS * 2 * MW * TQ_PIECE; i += TQ_PIECE) masks[i] = 0;
     __syncthreads();
-    // (1) the piece's results, slice by slice: wave w takes slices w, w + 16, ...
+#if !(COMMET_TQ_ABLATE & 512)
+    // (1) the piece's results.  Wave w takes slices w, w + 16, ... in batches of 64 tiles: every lane fetches the bounds of
+    // one tile, the batch's records then form one flat list that the wave walks 64 at a time (tile of a record: by
+    // counting the tile ends at or below it) — independent loads, no chain of small dependent ones.
     {
         const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (uint32_t s = wave; s < ql.n_slices; s += TQ_PIECE / 64) {
-            const unsigned long long a = ql.tile_off[(uint64_t) s * ql.n_pieces + blockIdx.x], e = ql.tile_off[(uint64_t) s * ql.n_pieces + blockIdx.x + 1];
-            for (unsigned long long i = a + lane; i < e; i += 64) {
-                const uint32_t res = qres[i];
+        constexpr uint32_t NWAVE = TQ_PIECE / 64;
+        for (uint32_t s0 = wave; s0 < ql.n_slices; s0 += 64 * NWAVE) {
+            const uint32_t sl = s0 + lane * NWAVE;                       // this lane's tile of the batch
+            unsigned long long ta = 0, te = 0;
+            if (sl < ql.n_slices) {
+                const unsigned long long *to = ql.tile_off + (uint64_t) sl * ql.n_pieces + blockIdx.x;
+                ta = to[0], te = to[1];
+            }
+            const uint32_t len = (uint32_t) (te - ta);
+            uint32_t inc = len;                                           // inclusive prefix of the tile lengths over the lanes
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(inc, o, 64);
+                if ((int) lane >= o) inc += x;
+            }
+            const uint32_t total = __shfl(inc, 63, 64);
+            for (uint32_t f0 = 0; f0 < total; f0 += 64) {              // (uniform trip count: every lane takes part in the shuffles)
+                const uint32_t f = f0 + lane;
+                // tile of flat record f = number of lanes whose inclusive prefix is <= f (binary search over the 64 prefixes)
+                uint32_t lo = 0, hi = 64;
+#pragma unroll
+                for (int step = 0; step < 7; ++step) {
+                    const uint32_t mid = min((lo + hi) >> 1, 63u);
+                    const uint32_t pm = __shfl(inc, (int) mid, 64);
+                    if (lo < hi) {
+                        if (pm <= f) lo = mid + 1;
+                        else hi = mid;
+                    }
+                }
+                const uint32_t src = min(lo, 63u);
+                const uint32_t before_raw = __shfl(inc, (int) (src ? src - 1 : 0), 64);
+                const unsigned long long tbase = __shfl((unsigned long long) ta, (int) src, 64);
+                if (f >= total) continue;
+                const unsigned long long i = tbase + (f - (src ? before_raw : 0u));
+                const uint32_t res = __builtin_nontemporal_load(qres + i);
                 if (!res) continue;
-                const uint32_t who = ql.qwho[i], rd = who & 1023u, win = who >> 10;
+                const uint32_t who = __builtin_nontemporal_load(ql.qwho + i), rd = who & 1023u, win = who >> 10;
 #pragma unroll
                 for (int c = 0; c < GS; ++c) {
                     if ((res >> c) & 1u) atomicOr(&mask_at(c, 0, (int) (win >> 5), rd), 1u << (win & 31u));
@@ -237,8 +304,21 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
             }
         }
     }
+#endif
     __syncthreads();
-    // (2) the sparse replay of search_group8_kernel on the LDS masks (search_reads.h:45-83 on the set bits only)
+    // (2) planes B, C, D for the lane-a candidates, balanced over the workgroup.  A read has ~11 candidates on average but
+    // the count varies from lane to lane, and every probe is a dependent HBM round trip; walking them per read leaves
+    // most lanes idle in most of ~150 serialised loads per wave.  So the candidates of the whole piece are numbered
+    // (prefix sums of the masks' popcounts) and thread f takes candidates f, f + 1024, ...: one plane-B probe per lane and
+    // round, all lanes busy.  Survivors (A & B) are collected in a second mask array and go through planes C and D the same
+    // way; what is left are the full four-lane hits.
+    __shared__ uint32_t pass[GS * 2 * MW * TQ_PIECE];
+    __shared__ uint32_t pre[TQ_PIECE];
+    __shared__ uint32_t scan_ws[TQ_PIECE / 64];
+    __shared__ unsigned int wg_cnt[2 * GS];
+    constexpr int NS = 2 * GS;                           // scan index = chunk * 2 + strand
+    auto word_at = [&](uint32_t *arr, int i, int h, uint32_t rd) -> uint32_t & { return arr[((i * MW) + h) * TQ_PIECE + rd]; };
+    if (threadIdx.x < 2 * GS) wg_cnt[threadIdx.x] = 0;
     const uint64_t r = (uint64_t) blockIdx.x * TQ_PIECE + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
@@ -249,37 +329,196 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         if (tags) tagw = tags[word];
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
-    bool found = false;
+    const int sh = 32 - k;
+    const uint32_t kmask = k == 32 ? ~0u : ((1u << k) - 1u);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int h = 0; h < MW; ++h) {
+            if (!active || (i >> 1) >= fg.g) word_at(masks, i, h, threadIdx.x) = 0;   // reads that are not searched have no candidates
+            word_at(pass, i, h, threadIdx.x) = 0;
+        }
+    __syncthreads();
+    // A read that shares sequence with the index set has a lane-a bit on (nearly) every window of one strand; the
+    // reference leaves it after t hits, i.e. after ~4 t probes.  Such "heavy" reads (more than TQ_HEAVY candidates in one
+    // scan) keep their masks in registers and walk them themselves in step (3), stopping at t; probing all their windows in
+    // the balanced sweeps would multiply their probes by ten.
+    constexpr uint32_t TQ_HEAVY = 12;
+    uint32_t am[NS][MW];
+    bool heavy = false;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int h = 0; h < MW; ++h) am[i][h] = word_at(masks, i, h, threadIdx.x), n += __popc(am[i][h]);
+        heavy |= n > TQ_HEAVY;
+    }
+    // words of another read of the piece around window end q
+    auto keys_of = [&](uint32_t owner, int strand, int q, uint32_t &ka, uint32_t &kb) {
+        uint64_t t0;
+        uint32_t len;
+        read_extent(rv, (uint64_t) blockIdx.x * TQ_PIECE + owner, t0, len);
+        ItemWords<uint32_t> it;
+        it.load(rv.planes + 3 * t0, (uint32_t) q >> 5);
+        uint32_t wh, wl;
+        (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);           // complete: only complete windows are in the list
+        if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
+        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+    };
+    // one balanced sweep over the set bits of `src` (heavy reads excluded), four candidates per thread and round so that
+    // four probes are in flight per lane: word_of(owner, scan, window end) -> {filter word address, bit} of the first plane
+    // to test; on_set(owner, scan, mask word, bit, ka, kb) is called for the candidates whose bit is set
+    auto sweep = [&](uint32_t *src, auto &&word_of, auto &&on_set) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int h = 0; h < MW; ++h) cnt += heavy ? 0u : __popc(word_at(src, i, h, threadIdx.x));
+        uint32_t total;
+        const uint32_t ex = block_scan<TQ_PIECE>(cnt, scan_ws, &total);
+        pre[threadIdx.x] = ex + cnt;                      // inclusive
+        __syncthreads();
+        constexpr int U = 4;
+        for (uint32_t f0 = threadIdx.x; f0 < total; f0 += U * TQ_PIECE) {
+            uint32_t owner[U], bitn[U], ka[U], kb[U], fw[U], fbit[U];
+            int sc[U], hw[U];
+            bool have[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t f = f0 + (uint32_t) u * TQ_PIECE;
+                have[u] = f < total;
+                owner[u] = 0, bitn[u] = 0, sc[u] = 0, hw[u] = 0;
+                if (!have[u]) continue;
+                uint32_t lo = 0, hi = TQ_PIECE - 1;       // first read whose inclusive prefix exceeds f
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[mid] <= f) lo = mid + 1;
+                    else hi = mid;
+                }
+                uint32_t local = f - (lo ? pre[lo - 1] : 0u), wd = 0;
+                bool got = false;
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int h = 0; h < MW; ++h) {
+                        if (got) continue;
+                        const uint32_t x = word_at(src, i, h, lo);
+                        const uint32_t c = __popc(x);
+                        if (local < c) sc[u] = i, hw[u] = h, wd = x, got = true;
+                        else local -= c;
+                    }
+                for (uint32_t v = 0; v < local; ++v) wd &= wd - 1u;        // drop the `local` lowest set bits
+                owner[u] = lo, bitn[u] = (uint32_t) __ffs((int) wd) - 1u;
+            }
+            const uint32_t *wp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // keys: the owners' read words (L1 / L2)
+                ka[u] = kb[u] = 0;
+                if (have[u]) keys_of(owner[u], sc[u] & 1, (int) (32 * hw[u] + bitn[u]) + (k - 1), ka[u], kb[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // the filter words: up to four HBM probes in flight
+                fw[u] = 0, fbit[u] = 0;
+                if (have[u]) {
+                    wp[u] = word_of(sc[u], ka[u], kb[u], fbit[u]);
+                    fw[u] = *wp[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (have[u] && ((fw[u] >> fbit[u]) & 1u)) on_set(owner[u], sc[u], hw[u], bitn[u], ka[u], kb[u]);
+        }
+        __syncthreads();
+    };
+    if (!(COMMET_TQ_ABLATE & 1024)) {
+        // plane B of every candidate
+        sweep(masks,
+              [&](int i, uint32_t, uint32_t kb, uint32_t &bit) -> const uint32_t * {
+                  bit = kb & 31u;
+                  return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words + (kb >> 5);
+              },
+              [&](uint32_t owner, int i, int h, uint32_t b, uint32_t, uint32_t) { atomicOr(&word_at(pass, i, h, owner), 1u << b); });
+        // masks := full hits (A & B & C & D): plane C of the survivors in the sweep, plane D behind it (one in a hundred)
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int h = 0; h < MW; ++h) word_at(masks, i, h, threadIdx.x) = 0;
+        __syncthreads();
+        if (!(COMMET_TQ_ABLATE & 16384))
+        sweep(pass,
+              [&](int i, uint32_t ka, uint32_t kb, uint32_t &bit) -> const uint32_t * {
+                  bit = (ka ^ kb) & 31u;
+                  return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 2 * fg.plane_words + ((ka ^ kb) >> 5);
+              },
+              [&](uint32_t owner, int i, int h, uint32_t b, uint32_t ka, uint32_t kb) {
+                  const uint32_t *pd = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 3 * fg.plane_words;
+                  if (test_bit<uint32_t>(pd, ka | kb)) atomicOr(&word_at(masks, i, h, owner), 1u << b);
+              });
+    }
+    // (3) the reference's control flow (search_reads.h:45-83) on the full hits of this thread's read: per chunk, strand 0
+    // then strand 1; greedy non-overlapping hits; the windows behind the first-hit ones are probed one by one, and only
+    // for a scan that already has a hit (exact pruning, see search_kernel)
     int found_chunk = -1;
-    if (active) {
+    if (active && !(COMMET_TQ_ABLATE & (1024 | 8192))) {
         uint64_t t0;
         uint32_t len;
         read_extent(rv, r, t0, len);
         const uint32_t *p = rv.planes + 3 * t0;
-        const int sh = 32 - k;
-        const uint32_t mask = k == 32 ? ~0u : ((1u << k) - 1u);
         const int last = (int) len - 1;
         const int pe = last - (t - 1) * k;
         const int q0 = k - 1;
-        for (int i = 0; i < fg.g && !found; ++i) {
-            const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
-            const uint32_t *pc = pb + fg.plane_words;
-            const uint32_t *pd = pc + fg.plane_words;
-            for (int strand = 0; strand < 2 && !found; ++strand) {
-                int seen = 0, next_ok = 0;
-                bool dead = false;
-                auto probe_bcd = [&](uint32_t wh, uint32_t wl) -> bool {
-                    uint32_t ka, kb;
-                    if (strand == 0) ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
-                    else ka = ~wh & mask, kb = ~wl & mask;
-                    return test_bit<uint32_t>(pb, kb) && test_bit<uint32_t>(pc, ka ^ kb) && test_bit<uint32_t>(pd, ka | kb);
-                };
-                for (int h = 0; h < MW && !found && !dead; ++h) {
-                    uint32_t m = mask_at(i, strand, h, threadIdx.x);
-                    while (m && !found && !dead) {
-                        const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;
+        bool found = false;
+        for (int i = 0; i < 2 * fg.g && !found; ++i) {
+            const int strand = i & 1;
+            const uint32_t *pb = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words;
+            const uint32_t *pc = pb + fg.plane_words, *pd = pc + fg.plane_words;
+            int seen = 0, next_ok = 0;
+            bool dead = false;
+            for (int h = 0; h < MW && !found && !dead; ++h) {
+                uint32_t m = masks[((i * MW) + h) * TQ_PIECE + threadIdx.x];   // light reads: full hits (steps above)
+                if (heavy) {                                                     // heavy reads: lane-a candidates, probed here
+                    m = 0;
+#pragma unroll
+                    for (int ii = 0; ii < NS; ++ii)
+#pragma unroll
+                        for (int hh = 0; hh < MW; ++hh)
+                            if (ii == i && hh == h) m = am[ii][hh];
+                }
+                while (m) {
+                    const int q = q0 + 32 * h + (__ffs((int) m) - 1);
+                    m &= m - 1u;
+                    if (q < next_ok) continue;
+                    if (q + (t - seen - 1) * k > last) {
+                        dead = true;
+                        break;
+                    }
+                    if (heavy) {
+                        ItemWords<uint32_t> it;
+                        it.load(p, (uint32_t) q >> 5);
+                        uint32_t wh, wl, ka, kb;
+                        (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);
+                        if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
+                        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                        // three independent loads, one round trip: a heavy read's candidates are almost all true k-mers of the
+                        // index set, the short circuit b -> c -> d would only serialise them
+                        const uint32_t vb = pb[kb >> 5], vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
+                        if (!((vb >> (kb & 31u)) & (vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u)) continue;
+                    }
+                    ++seen;
+                    next_ok = q + k;
+                    if (seen >= t) {
+                        found = true;
+                        break;
+                    }
+                }
+            }
+            if (!found && !dead && seen >= 1 && !(COMMET_TQ_ABLATE & 32768) && !((COMMET_TQ_ABLATE & 65536) && heavy) && !((COMMET_TQ_ABLATE & 131072) && !heavy)) {   // windows behind the first-hit ones (lane_a_bits32)
+                for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                    if (qb + (t - seen - 1) * k > last) break;
+                    uint32_t m = lane_a_bits32<uint32_t>(p, len, qb, last, k, strand, fg.il_a, GS, i >> 1);
+                    while (m && !found) {
+                        const int q = qb + (__ffs((int) m) - 1);
                         m &= m - 1u;
-                        const int q = q0 + 32 * h + (int) jj;
                         if (q < next_ok) continue;
                         if (q + (t - seen - 1) * k > last) {
                             dead = true;
@@ -287,47 +526,39 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                         }
                         ItemWords<uint32_t> it;
                         it.load(p, (uint32_t) q >> 5);
-                        uint32_t wh, wl;
-                        (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);   // valid: only complete windows are in the list
-                        if (probe_bcd(wh, wl)) {
+                        uint32_t wh, wl, ka, kb;
+                        (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);
+                        if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
+                        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                        const uint32_t vb = pb[kb >> 5], vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];   // one round trip
+                        if ((vb >> (kb & 31u)) & (vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u) {
                             ++seen;
                             next_ok = q + k;
                             if (seen >= t) found = true;
                         }
                     }
                 }
-                if (!found && !dead && seen >= 1) {   // windows behind the first-hit ones, after a first full hit only
-                    for (int q = max(pe + 1, next_ok); q <= last && !found; ++q) {
-                        if (q + (t - seen - 1) * k > last) break;
-                        ItemWords<uint32_t> it;
-                        it.load(p, (uint32_t) q >> 5);
-                        uint32_t wh, wl;
-                        if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;
-                        const uint32_t ka = strand == 0 ? (__brev(wh) >> sh) : (~wh & mask);
-                        const uint32_t addr = psi_a<uint32_t>(ka, k);
-                        if (!((fg.il_a[(uint64_t) (addr >> 5) * GS + i] >> (addr & 31u)) & 1u)) continue;
-                        if (probe_bcd(wh, wl)) {
-                            ++seen;
-                            q += k - 1;
-                            if (seen >= t) found = true;
-                        }
-                    }
-                }
             }
-            if (found) found_chunk = i;
+            if (found) found_chunk = i >> 1;
         }
     }
+    const bool found = found_chunk >= 0;
     const uint64_t fb = __ballot(found);
     if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
+    __syncthreads();
     if (counters) {
+        // per workgroup in LDS first: every wave adding to the same two global words costs milliseconds of serialised atomics
         for (int i = 0; i < fg.g; ++i) {
             const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
             const uint64_t fd = __ballot(found_chunk == i);
             if (lane == 0) {
-                if (sc) atomicAdd(&counters[(uint64_t) i * cstride + 0], (unsigned long long) __popcll(sc));
-                if (fd) atomicAdd(&counters[(uint64_t) i * cstride + 1], (unsigned long long) __popcll(fd));
+                if (sc) atomicAdd(&wg_cnt[2 * i], (unsigned int) __popcll(sc));
+                if (fd) atomicAdd(&wg_cnt[2 * i + 1], (unsigned int) __popcll(fd));
             }
         }
+        __syncthreads();
+        if (threadIdx.x < 2 * (unsigned) fg.g && wg_cnt[threadIdx.x])
+            atomicAdd(&counters[(uint64_t) (threadIdx.x >> 1) * cstride + (threadIdx.x & 1)], (unsigned long long) wg_cnt[threadIdx.x]);
     }
 }
 
