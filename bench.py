@@ -331,7 +331,7 @@ def main():
                 "note": "durations: hipEvents around every launch in untimed extra steps (one index lane, so they add up); "
                         "bytes: rocprofv3 PMC passes of this workload (gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py)",
             }
-            if fetch and gather_ceiling and dom.startswith("search"):
+            if fetch and gather_ceiling and dom.startswith(("search", "tq_")):
                 rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
                 roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),
                                             "frac": round(rps / gather_ceiling, 4),

@@ -995,6 +995,9 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
         HIP_OK(hipMalloc((void **) &ws.bufA, cap * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **) &ws.bufB, cap * sizeof(uint32_t)));
+        // first touch here, not inside the first scatter2 launch (measured: 15.6 ms instead of 2.5 ms for that one launch)
+        HIP_OK(hipMemsetAsync(ws.bufA, 0, cap * sizeof(uint32_t), stream));
+        HIP_OK(hipMemsetAsync(ws.bufB, 0, cap * sizeof(uint32_t), stream));
         ws.cap_keys = cap;
     }
     const bool wide = c->k > 32;

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --no-matrix "$@" > $O/bench.json 2> $O/bench.err
 # one index lane here: with two, kernels of both lanes run at once and their durations are not additive
 B="--cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix"
-COMMET_INDEX_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $O/kt.log 2>&1
+COMMET_INDEX_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 $B "$@" > $O/kt.log 2>&1
 COMMET_INDEX_LANES=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pf.log 2>&1
 COMMET_INDEX_LANES=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pw.log 2>&1
 COMMET_INDEX_LANES=1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace -d $O/ps -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/ps.log 2>&1 || echo "SQ pass failed" >> $O/bench.err
