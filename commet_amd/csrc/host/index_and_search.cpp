@@ -10,8 +10,12 @@
 //
 // Extra (non-reference) controls: env COMMET_DEVICE=<n> picks the GPU.
 
+#include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <sys/un.h>
+#include <csignal>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -22,7 +26,9 @@
 #include <fstream>
 #include <future>
 #include <iostream>
+#include <map>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -34,6 +40,45 @@
 using namespace commet_host;
 
 static const std::string version = "2.1";   // index_and_search.cpp:44 (interface version we mirror)
+
+// The tool's exits become exceptions so that one process can serve many invocations (resident mode below).
+struct ToolExit {
+    int code;
+};
+#define TOOL_EXIT(c) throw ToolExit{c}
+
+// ---- resident mode ---------------------------------------------------------------------------------------------
+// Commet.py starts one index_and_search process per job (Commet.py:197,220,233): N^2 - 1 HIP start-ups, and every set is
+// parsed and uploaded again each time it takes part in a job (2(N - 1) + ... times).  `index_and_search --serve SOCKET`
+// keeps ONE process with its contexts and the read sets it has loaded (keyed by path, size and mtime of their files) in
+// HBM; an ordinary invocation with COMMET_SERVER=SOCKET in its environment forwards argv and its working directory,
+// and prints what comes back: same stdout / stderr bytes, same files, same exit code, Commet.py unchanged.
+struct CachedSet {
+    commet_readset *rs = nullptr;
+    std::vector<uint64_t> file_reads;
+    uint64_t bytes = 0, last_use = 0;
+    bool in_use = false;
+};
+struct ServerState {
+    std::map<std::pair<int, int>, commet_ctx *> ctxs;                            // (k, t) -> context
+    std::map<std::pair<commet_ctx *, std::string>, CachedSet> sets;              // (context, files key) -> resident set
+    uint64_t tick = 0, hits = 0, loads = 0, evictions = 0, requests = 0;
+    uint64_t cached_bytes = 0, budget_bytes = 0;                                 // budget: COMMET_SERVER_CACHE_GB (default 96)
+    void evict_until(uint64_t need)
+    {
+        while (cached_bytes + need > budget_bytes) {
+            auto victim = sets.end();
+            for (auto it = sets.begin(); it != sets.end(); ++it)
+                if (!it->second.in_use && (victim == sets.end() || it->second.last_use < victim->second.last_use)) victim = it;
+            if (victim == sets.end()) return;
+            commet_readset_destroy(victim->second.rs);
+            cached_bytes -= victim->second.bytes;
+            sets.erase(victim);
+            ++evictions;
+        }
+    }
+};
+static ServerState *g_server = nullptr;
 
 static void print_usage()
 {
@@ -60,7 +105,7 @@ static void ensure_dir(const std::string &p)
     if (stat(p.c_str(), &info) != 0) mkdir(p.c_str(), S_IRWXU | S_IRGRP | S_IXGRP);
     else if (!(info.st_mode & S_IFDIR)) {
         std::cerr << "Error: " << p << " already exists and is not a directory\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
 }
 
@@ -77,13 +122,78 @@ struct LoadedSet {
     std::vector<uint8_t> select;   // set-wide input-filter bits
     bool any_bv = false;
     uint64_t n_reads = 0;
+    CachedSet *cached = nullptr;   // resident mode: the set belongs to the server's cache
 };
+
+static void build_select(LoadedSet &out);
+
+// a loaded set is given back: destroyed, or (resident mode) left in the cache for the next invocation
+static void release_set(LoadedSet &ls)
+{
+    if (ls.cached) ls.cached->in_use = false;
+    else if (ls.rs) commet_readset_destroy(ls.rs);
+    ls.rs = nullptr;
+    ls.cached = nullptr;
+}
 
 // FileManager::addFile for every entry of one set (file_manager.h:117-216),
 // FastaFile ctors (fasta_file.h:49-116), then streams the reads to HBM.
 static void load_set(commet_ctx *ctx, const std::string &nickname, const std::vector<SetEntry> &entries, LoadedSet &out)
 {
     out.nickname = nickname;
+    // resident mode: a set whose files (path, size, mtime) are the ones of a cached set is not opened again
+    std::string files_key;
+    CachedSet *hit = nullptr;
+    if (g_server) {
+        bool all = true;
+        for (const SetEntry &en : entries) {
+            struct stat sb;
+            char rp[PATH_MAX];
+            if (stat(en.file.c_str(), &sb) != 0 || !realpath(en.file.c_str(), rp)) {
+                all = false;
+                break;
+            }
+            files_key += std::string(rp) + "|" + std::to_string((unsigned long long) sb.st_size) + "|" +
+                         std::to_string((long long) sb.st_mtim.tv_sec) + "." + std::to_string((long) sb.st_mtim.tv_nsec) + ";";
+        }
+        if (!all) files_key.clear();
+        else {
+            auto it = g_server->sets.find(std::make_pair(ctx, files_key));
+            if (it != g_server->sets.end() && !it->second.in_use) hit = &it->second;
+        }
+    }
+    if (hit) {
+        std::vector<bool> given;
+        for (const SetEntry &en : entries) {
+            if (en.bv.empty()) std::cout << "open " << en.file << "\n";
+            else std::cout << "open " << en.file << "," << en.bv << "\n";
+            LoadedFile lf;
+            lf.name = en.file;
+            if (!en.bv.empty()) {
+                if (!read_bv(en.bv, lf.filter)) TOOL_EXIT(1);
+                out.any_bv = true;
+            }
+            out.files.push_back(lf);
+            given.push_back(!en.bv.empty());
+        }
+        out.rs = hit->rs;
+        out.cached = hit;
+        hit->in_use = true;
+        hit->last_use = ++g_server->tick;
+        ++g_server->hits;
+        out.n_reads = commet_readset_num_reads(out.rs);
+        for (size_t i = 0; i < out.files.size(); ++i) {
+            LoadedFile &lf = out.files[i];
+            lf.nb_reads = hit->file_reads[i];
+            if (!given[i]) lf.filter.init_true(lf.nb_reads);
+            else if (lf.nb_reads != lf.filter.size) {   // fasta_file.h:108-111
+                std::cerr << "Number of reads in " << lf.name << " and boolean vector size are not equal -> quit\n";
+                TOOL_EXIT(1);
+            }
+        }
+        build_select(out);
+        return;
+    }
     std::vector<std::unique_ptr<ReadFileData>> maps;
     std::vector<bool> bv_given;
     // the files of a set are opened (mapped, or inflated when gzipped: one zlib stream each) by one thread per file;
@@ -106,19 +216,19 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
             if (en.bv.empty()) {
                 std::cerr << "Cannot open file file " << en.file << " -> ignore\n";   // file_manager.h:121-123
                 std::cerr << "Cannot open file " << en.file << " -> ignore\n";        // gz path, :144-147
-                exit(1);
+                TOOL_EXIT(1);
             }
             std::cerr << "Cannot open file " << en.file << " -> ignore\n";            // file_manager.h:177-180
             continue;
         }
         if (mf->format() == ReadFormat::Unknown) {   // neither '>' nor '@', plain or gzipped (file_manager.h:154-156)
             std::cerr << "Unknown format: " << en.file << " -> ignore\n";
-            exit(1);
+            TOOL_EXIT(1);
         }
         LoadedFile lf;
         lf.name = en.file;
         if (!en.bv.empty()) {
-            if (!read_bv(en.bv, lf.filter)) exit(1);
+            if (!read_bv(en.bv, lf.filter)) TOOL_EXIT(1);
             out.any_bv = true;
         }
         out.files.push_back(lf);
@@ -135,23 +245,44 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     out.rs = commet_readset_from_buffers(ctx, data.data(), sizes.data(), (int) maps.size());
     if (!out.rs) {
         std::cerr << "Error: " << commet_last_error() << "\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
     if (commet_readset_finalize(out.rs)) {
         std::cerr << "Error: " << commet_last_error() << "\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
     out.n_reads = commet_readset_num_reads(out.rs);
+    if (g_server && !files_key.empty() && maps.size() == entries.size() &&
+        g_server->sets.find(std::make_pair(ctx, files_key)) == g_server->sets.end()) {
+        // the set stays resident for later invocations (bytes: planes + offsets + counts + bitmaps, roughly)
+        uint64_t bases = 0;
+        for (uint64_t sz : sizes) bases += sz;
+        CachedSet cs;
+        cs.rs = out.rs;
+        cs.bytes = bases / 2 + out.n_reads * 40 + (1u << 20);
+        for (size_t i = 0; i < out.files.size(); ++i) cs.file_reads.push_back(commet_readset_file_reads(out.rs, i));
+        g_server->evict_until(cs.bytes);
+        cs.in_use = true;
+        cs.last_use = ++g_server->tick;
+        g_server->cached_bytes += cs.bytes;
+        ++g_server->loads;
+        out.cached = &(g_server->sets[std::make_pair(ctx, files_key)] = cs);
+    }
     for (size_t i = 0; i < out.files.size(); ++i) {
         LoadedFile &lf = out.files[i];
         lf.nb_reads = commet_readset_file_reads(out.rs, i);
         if (!bv_given[i]) lf.filter.init_true(lf.nb_reads);
         else if (lf.nb_reads != lf.filter.size) {   // fasta_file.h:108-111
             std::cerr << "Number of reads in " << lf.name << " and boolean vector size are not equal -> quit\n";
-            exit(1);
+            TOOL_EXIT(1);
         }
     }
-    // set-wide select bits = the per-file filters, concatenated
+    build_select(out);
+}
+
+// set-wide select bits = the per-file filters, concatenated
+static void build_select(LoadedSet &out)
+{
     out.select.assign(out.n_reads / 8 + 1, 0);
     if (!out.any_bv) {   // every read of every file: whole bytes at once
         std::fill(out.select.begin(), out.select.begin() + out.n_reads / 8, (uint8_t) 0xFF);
@@ -166,7 +297,7 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
     }
 }
 
-int main(int argc, char **argv)
+static int run_tool(int argc, char **argv)
 {
     std::string search_file_list, index_file_list;
     int kmer_size = 33;   // index_and_search.cpp:71-72
@@ -186,7 +317,7 @@ int main(int argc, char **argv)
             if (arg_pos >= argc) {
                 std::cerr << "Error, flag " << argv[arg_pos - 1] << " needs an argument\n";
                 print_usage();
-                exit(1);
+                TOOL_EXIT(1);
             }
         };
         if (flag == "-i") {
@@ -232,10 +363,10 @@ int main(int argc, char **argv)
     const auto start_time = std::chrono::steady_clock::now();
 
     SetMap index_sets, search_sets;
-    if (!read_sets(index_file_list, index_sets)) exit(1);
+    if (!read_sets(index_file_list, index_sets)) TOOL_EXIT(1);
     if (index_sets.size() != 1) {   // index_and_search.cpp:197-200
         std::cerr << "Only one set of files is allowed for indexing\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
 
     // COMMET_INGEST_VERBOSE: wall time of the tool's phases on stderr
@@ -247,17 +378,25 @@ int main(int argc, char **argv)
         phase_t = now;
     };
     const char *dev_env = getenv("COMMET_DEVICE");
-    commet_ctx *ctx = commet_create(dev_env ? atoi(dev_env) : 0, kmer_size, min_hits);
+    commet_ctx *ctx = nullptr;
+    if (g_server) {   // resident mode: one context per (k, t), kept
+        commet_ctx *&slot = g_server->ctxs[std::make_pair(kmer_size, min_hits)];
+        if (!slot) slot = commet_create(dev_env ? atoi(dev_env) : 0, kmer_size, min_hits);
+        ctx = slot;
+        if (!ctx) g_server->ctxs.erase(std::make_pair(kmer_size, min_hits));
+    } else {
+        ctx = commet_create(dev_env ? atoi(dev_env) : 0, kmer_size, min_hits);
+    }
     phase("context (HIP start-up)");
     if (!ctx) {
         std::cerr << commet_last_error() << "\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
 
     LoadedSet index_set;
     load_set(ctx, index_sets.begin()->first, index_sets.begin()->second, index_set);
 
-    if (!read_sets(search_file_list, search_sets)) exit(1);
+    if (!read_sets(search_file_list, search_sets)) TOOL_EXIT(1);
     // -f: only the first search set is opened (index_and_search.cpp:231-233)
     std::vector<LoadedSet> searches(full && !search_sets.empty() ? 1 : search_sets.size());
     {
@@ -269,7 +408,7 @@ int main(int argc, char **argv)
     if (searches.empty()) {
         // the reference dereferences search_sets[0] here (index_and_search.cpp:247): undefined
         std::cerr << "Error: no set to search\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
 
     // the chunk loop (index_and_search.cpp:241-277) on the device
@@ -289,7 +428,7 @@ int main(int argc, char **argv)
     if (commet_index_and_search(ctx, index_set.rs, index_set.any_bv ? index_set.select.data() : nullptr, ns, rs.data(),
                                 sel.data(), tag_ptr.data(), stats.data(), &info)) {
         std::cerr << "Error: " << commet_last_error() << "\n";
-        exit(1);
+        TOOL_EXIT(1);
     }
 
     phase("index_and_search");
@@ -320,7 +459,7 @@ int main(int argc, char **argv)
         std::ofstream log_file(fname.c_str());
         if (!log_file.good()) {
             std::cerr << "Cannot open log file : " << fname << "\n";
-            exit(1);
+            TOOL_EXIT(1);
         }
         log_file << "Index  time: " << index_s << " s\n";
         log_file << "Search time: " << search_s << " s\n";
@@ -341,7 +480,7 @@ int main(int argc, char **argv)
             pos += lf.nb_reads;
             const std::string base = lf.name.substr(lf.name.rfind("/") + 1);
             bv.comment = lf.name + " in " + suffix;
-            if (!write_bv(out_path + "/" + base + "_in_" + suffix + ".bv", bv)) exit(1);
+            if (!write_bv(out_path + "/" + base + "_in_" + suffix + ".bv", bv)) TOOL_EXIT(1);
         }
     };
 
@@ -364,7 +503,7 @@ int main(int argc, char **argv)
             std::ofstream log_file(log_name.c_str());
             if (!log_file.good()) {
                 std::cerr << "Cannot open log file " << log_name << " -> exit\n";
-                exit(1);
+                TOOL_EXIT(1);
             }
             std::cout << "\n------------------------------------------------------------------\n";
             std::cout << banner << "\n";
@@ -377,7 +516,7 @@ int main(int argc, char **argv)
             commet_job_info inf;
             if (commet_index_and_search(ctx, idx.rs, idx_sel, 1, &q, &srch_sel, &tp, &st, &inf)) {
                 std::cerr << "Error: " << commet_last_error() << "\n";
-                exit(1);
+                TOOL_EXIT(1);
             }
             if (save_now) save_bv(srch, out_tags, save_suffix);
             const float tot = (float) std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -406,9 +545,182 @@ int main(int argc, char **argv)
 
     // (ending the process without this teardown was tried: the driver then reclaims the memory while the next job's
     // HIP start-up waits for it — same wall time per job)
-    for (LoadedSet &ls : searches) commet_readset_destroy(ls.rs);
-    commet_readset_destroy(index_set.rs);
-    commet_destroy(ctx);
+    for (LoadedSet &ls : searches) release_set(ls);
+    release_set(index_set);
+    if (!g_server) commet_destroy(ctx);
     phase("teardown");
     return 0;
+}
+
+// ---- resident mode: protocol ------------------------------------------------------------------------------------
+// request : u32 n, then n strings (u32 length + bytes): working directory, argv[0], argv[1], ...
+// reply   : i32 exit code, u64 + bytes of stdout, u64 + bytes of stderr
+static bool read_all(int fd, void *buf, size_t n)
+{
+    char *p = (char *) buf;
+    while (n) {
+        const ssize_t r = read(fd, p, n);
+        if (r <= 0) return false;
+        p += r, n -= (size_t) r;
+    }
+    return true;
+}
+static bool write_all(int fd, const void *buf, size_t n)
+{
+    const char *p = (const char *) buf;
+    while (n) {
+        const ssize_t r = write(fd, p, n);
+        if (r <= 0) return false;
+        p += r, n -= (size_t) r;
+    }
+    return true;
+}
+
+static int serve(const char *sock_path)
+{
+    signal(SIGPIPE, SIG_IGN);
+    ServerState state;
+    const char *gb = getenv("COMMET_SERVER_CACHE_GB");
+    state.budget_bytes = (uint64_t) (gb ? atof(gb) : 96.0) * (1ull << 30);
+    g_server = &state;
+    const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    if (ls < 0 || strlen(sock_path) >= sizeof addr.sun_path) {
+        std::cerr << "Error: cannot create the server socket " << sock_path << "\n";
+        return 1;
+    }
+    strcpy(addr.sun_path, sock_path);
+    unlink(sock_path);
+    if (bind(ls, (sockaddr *) &addr, sizeof addr) != 0 || listen(ls, 16) != 0) {
+        std::cerr << "Error: cannot listen on " << sock_path << "\n";
+        return 1;
+    }
+    char home[PATH_MAX];
+    if (!getcwd(home, sizeof home)) strcpy(home, "/");
+    std::cerr << "index_and_search: serving on " << sock_path << "\n";
+    for (;;) {
+        const int fd = accept(ls, nullptr, nullptr);
+        if (fd < 0) continue;
+        uint32_t n = 0;
+        std::vector<std::string> strs;
+        bool ok = read_all(fd, &n, 4) && n >= 2 && n < 4096;
+        for (uint32_t i = 0; ok && i < n; ++i) {
+            uint32_t len = 0;
+            ok = read_all(fd, &len, 4) && len < (1u << 20);
+            if (!ok) break;
+            std::string x(len, '\0');
+            ok = len == 0 || read_all(fd, &x[0], len);
+            strs.push_back(x);
+        }
+        if (!ok) {
+            close(fd);
+            continue;
+        }
+        int code = 0;
+        std::ostringstream out, err;
+        if (strs.size() == 3 && strs[2] == "--server-stop") {
+            close(fd);
+            break;
+        }
+        std::streambuf *old_out = std::cout.rdbuf(out.rdbuf()), *old_err = std::cerr.rdbuf(err.rdbuf());
+        if (strs.size() == 3 && strs[2] == "--server-stats") {
+            std::cout << "requests " << state.requests << ", sets resident " << state.sets.size() << " (" << state.cached_bytes / (1 << 20)
+                      << " MiB), cache hits " << state.hits << ", loads " << state.loads << ", evictions " << state.evictions
+                      << ", contexts " << state.ctxs.size() << "\n";
+        } else {
+            ++state.requests;
+            std::vector<char *> av;
+            for (size_t i = 1; i < strs.size(); ++i) av.push_back(&strs[i][0]);
+            if (chdir(strs[0].c_str()) != 0) {
+                std::cerr << "Error: cannot enter " << strs[0] << "\n";
+                code = 1;
+            } else {
+                try {
+                    code = run_tool((int) av.size(), av.data());
+                } catch (const ToolExit &e) {
+                    code = e.code;
+                } catch (const std::exception &e) {
+                    std::cerr << "Error: " << e.what() << "\n";
+                    code = 1;
+                }
+            }
+            for (auto &kv : state.sets) kv.second.in_use = false;   // (a request that failed half-way gives its sets back here)
+            if (chdir(home) != 0) {}
+        }
+        std::cout.rdbuf(old_out);
+        std::cerr.rdbuf(old_err);
+        const std::string so = out.str(), se = err.str();
+        const int32_t c32 = code;
+        const uint64_t lo = so.size(), le = se.size();
+        (void) (write_all(fd, &c32, 4) && write_all(fd, &lo, 8) && write_all(fd, so.data(), lo) && write_all(fd, &le, 8) &&
+                write_all(fd, se.data(), le));
+        close(fd);
+    }
+    for (auto &kv : state.sets) commet_readset_destroy(kv.second.rs);
+    for (auto &kv : state.ctxs) commet_destroy(kv.second);
+    close(ls);
+    unlink(sock_path);
+    g_server = nullptr;
+    return 0;
+}
+
+// forwards this invocation to a resident server; -1 = no server there (run locally)
+static int forward(const char *sock_path, int argc, char **argv)
+{
+    const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    if (fd < 0 || strlen(sock_path) >= sizeof addr.sun_path) return -1;
+    strcpy(addr.sun_path, sock_path);
+    if (connect(fd, (sockaddr *) &addr, sizeof addr) != 0) {
+        close(fd);
+        return -1;
+    }
+    char cwd[PATH_MAX];
+    if (!getcwd(cwd, sizeof cwd)) strcpy(cwd, ".");
+    std::vector<std::string> strs(1, cwd);
+    for (int i = 0; i < argc; ++i) strs.push_back(argv[i]);
+    const uint32_t n = (uint32_t) strs.size();
+    bool ok = write_all(fd, &n, 4);
+    for (const std::string &x : strs) {
+        const uint32_t len = (uint32_t) x.size();
+        ok = ok && write_all(fd, &len, 4) && write_all(fd, x.data(), len);
+    }
+    int32_t code = 1;
+    uint64_t lo = 0, le = 0;
+    std::string so, se;
+    ok = ok && read_all(fd, &code, 4) && read_all(fd, &lo, 8);
+    if (ok) so.resize(lo), ok = lo == 0 || read_all(fd, &so[0], lo);
+    ok = ok && read_all(fd, &le, 8);
+    if (ok) se.resize(le), ok = le == 0 || read_all(fd, &se[0], le);
+    close(fd);
+    if (!ok) {
+        if (argc >= 2 && !strcmp(argv[1], "--server-stop")) return 0;
+        std::cerr << "Error: the index_and_search server at " << sock_path << " closed the connection\n";
+        return 1;
+    }
+    fwrite(so.data(), 1, so.size(), stdout);
+    fwrite(se.data(), 1, se.size(), stderr);
+    return code;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc == 3 && !strcmp(argv[1], "--serve")) return serve(argv[2]);
+    if (const char *srv = getenv("COMMET_SERVER")) {
+        const int rc = forward(srv, argc, argv);
+        if (rc >= 0) return rc;
+        if (argc == 2 && (!strcmp(argv[1], "--server-stats") || !strcmp(argv[1], "--server-stop"))) {
+            std::cerr << "Error: no index_and_search server at " << srv << "\n";
+            return 1;
+        }
+    }
+    try {
+        return run_tool(argc, argv);
+    } catch (const ToolExit &e) {
+        return e.code;
+    }
 }

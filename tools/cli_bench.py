@@ -23,6 +23,13 @@ def main():
             fh.write(f"set{s}: {work}/s{s}.fa\n")
     exe = os.path.join(HERE, "commet_amd", "bin", "index_and_search")
     env = dict(os.environ, COMMET_INGEST_VERBOSE="1")
+    server = None
+    if os.environ.get("CLI_SERVER"):          # the same job through a resident server (index_and_search --serve)
+        sock = os.path.join(work, "s.sock")
+        server = subprocess.Popen([exe, "--serve", sock], stderr=subprocess.DEVNULL)
+        while not os.path.exists(sock):
+            time.sleep(0.05)
+        env["COMMET_SERVER"] = sock
     for rep in range(int(os.environ.get("CLI_REPS", "3"))):
         t0 = time.perf_counter()
         r = subprocess.run([exe, "-i", f"{work}/c0.txt", "-s", f"{work}/c1.txt", "-o", f"{work}/out", "-l", f"{work}/out", "-k", k, "-t", "2"],
@@ -32,6 +39,10 @@ def main():
         for ln in (r.stdout + r.stderr).splitlines():
             if any(w in ln for w in ("time", "ingest", "indexed", "ms", " s")):
                 print("   ", ln)
+    if server:
+        subprocess.run([exe, "--server-stats"], env=env)
+        subprocess.run([exe, "--server-stop"], env=env)
+        server.wait()
     subprocess.run(["rm", "-rf", work])
 
 
