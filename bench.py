@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--no-probe-count", action="store_true", help="skip the extra (untimed) P_ref counting step")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the extra (untimed) per-kernel timing steps")
     ap.add_argument("--kt-steps", type=int, default=3, help="untimed steps of the per-kernel timing leg")
+    ap.add_argument("--traffic", default=None, help="traffic.json to price the roofline with (default: the newest matching one under profiles/)")
     ap.add_argument("--no-matrix", action="store_true", help="skip the configs[2] matrix leg (detail.matrix)")
     ap.add_argument("--matrix-sets", type=int, default=10)
     ap.add_argument("--matrix-reads", type=int, default=10_000_000)
@@ -148,6 +149,13 @@ def source_hash():
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def explicit_traffic(path):
+    """a traffic.json given on the command line (tools/profile_bench.sh: the one just collected)"""
+    table = json.load(open(path))
+    rel = os.path.relpath(os.path.abspath(path), ROOT)
+    return table, rel, table.get("_meta", {}).get("source_hash") != source_hash()
 
 
 def measured_traffic(workload):
@@ -295,7 +303,7 @@ def main():
         srch_ms = acc["search_ms"] / steps
         roofline = None
         if ktimes:
-            tr = measured_traffic(workload)
+            tr = explicit_traffic(args.traffic) if args.traffic else measured_traffic(workload)
             table, tr_path, stale = tr if tr else ({}, None, None)
             step_dev_ms = sum(e["ms_per_step"] for e in ktimes.values())
             dom = max(ktimes, key=lambda nme: ktimes[nme]["ms_per_step"])

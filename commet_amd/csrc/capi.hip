@@ -1290,9 +1290,10 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
     if (rs->n_reads >= (1ull << 32)) return false;
-    if (c->tiled_mode == 2) return true;
-    // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB
-    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= (4ull << 30);
+    // On request only (option tiled_search = 2 / COMMET_TILED=2): with the tail probes of the fused kernels fetched eight
+    // at a time the two paths are level (configs[1]: 9.25 vs 9.39 ms, configs[2] jobs 1.87-1.93 vs 1.88 s), and the
+    // query list costs 8 bytes per first-hit window of HBM and 11 ms per 10 M-read set to build.
+    return c->tiled_mode == 2;
 }
 
 // the set's query list for this context's (k, t): counted, scanned, filled; kept with the set

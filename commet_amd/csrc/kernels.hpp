@@ -480,7 +480,10 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 }
 
 // ---------------------------------------------------------------------------
-// Lane-a bits of up to 32 consecutive windows of one strand, fetched with INDEPENDENT loads (eight in flight at a time):
+constexpr int TAIL_WIN = 8;   // windows behind the first-hit ones are fetched this many at a time: the scan usually ends at
+                              // the first of them that hits, and every extra probe is an L2 miss (what these kernels are bound by)
+
+// Lane-a bits of up to n_win <= 32 consecutive windows of one strand, fetched with INDEPENDENT loads (eight in flight at a time):
 // bit j of the result = the complete window ending at q_lo + j (q_lo + j <= q_hi) has its lane-a bit set in the A plane
 // `plane_a` (words interleaved with stride `stride`, this chunk at offset `ci`).  Used for the windows behind the first-
 // hit ones: a scan that already has a hit needs them, and probing them one after the other (load, test, next window)
@@ -488,12 +491,12 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 // ---------------------------------------------------------------------------
 template <typename W>
 __device__ __forceinline__ uint32_t lane_a_bits32(const uint32_t *__restrict__ p, uint32_t len, int q_lo, int q_hi, int k, int strand,
-                                                  const uint32_t *__restrict__ plane_a, int stride, int ci)
+                                                  const uint32_t *__restrict__ plane_a, int stride, int ci, int n_win = 32)
 {
     using T = KeyTraits<W>;
     const int sh = T::BITS - k;
     const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
-    q_hi = min(q_hi, min(q_lo + 31, (int) len - 1));
+    q_hi = min(q_hi, min(q_lo + n_win - 1, (int) len - 1));
     if (q_hi < q_lo) return 0u;
     // roll up to q_lo - 1 (the k - 1 bases before the first window are enough)
     W wh = 0;
@@ -693,9 +696,9 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                     // windows behind the gathered ones matter only after a first full hit (pruning, see above); their lane-a
                     // bits come 32 windows at a time with independent loads (lane_a_bits32), then only the set ones are probed
                     if (!found && !dead && seen >= 1) {
-                        for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                        for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TAIL_WIN) {
                             if (qb + (t - seen - 1) * k > last) break;
-                            uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i);
+                            uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i, TAIL_WIN);
                             while (m && !found) {
                                 const int q = qb + (__ffs((int) m) - 1);
                                 m &= m - 1u;
@@ -916,9 +919,9 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                     }
                 }
                 if (!found && !dead && seen >= 1) {   // windows behind the gathered ones, after a first full hit only (lane_a_bits32)
-                    for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                    for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TAIL_WIN) {
                         if (qb + (t - seen - 1) * k > last) break;
-                        uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i);
+                        uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i, TAIL_WIN);
                         while (m && !found) {
                             const int q = qb + (__ffs((int) m) - 1);
                             m &= m - 1u;

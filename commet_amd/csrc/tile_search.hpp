@@ -33,6 +33,8 @@
 namespace commet {
 
 constexpr uint32_t TQ_PIECE = 256;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
+constexpr int      TQ_TAIL_WIN = 32;      // tail windows per batch of lane-a probes (the fused kernels take 8: fewer misses; here the
+                                          // replay has no gathers to hide the round trips behind, and 32 measured faster: 6.9 vs 7.3 ms)
 constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
 
 struct QueryListView {
@@ -513,9 +515,9 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                 }
             }
             if (!found && !dead && seen >= 1 && !(COMMET_TQ_ABLATE & 32768) && !((COMMET_TQ_ABLATE & 65536) && heavy) && !((COMMET_TQ_ABLATE & 131072) && !heavy)) {   // windows behind the first-hit ones (lane_a_bits32)
-                for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += 32) {
+                for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TQ_TAIL_WIN) {
                     if (qb + (t - seen - 1) * k > last) break;
-                    uint32_t m = lane_a_bits32<uint32_t>(p, len, qb, last, k, strand, fg.il_a, GS, i >> 1);
+                    uint32_t m = lane_a_bits32<uint32_t>(p, len, qb, last, k, strand, fg.il_a, GS, i >> 1, TQ_TAIL_WIN);
                     while (m && !found) {
                         const int q = qb + (__ffs((int) m) - 1);
                         m &= m - 1u;

@@ -21,4 +21,6 @@ cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
 cp $(find $O/ps -name "*counter_collection.csv" | head -1) $O/pmc_sq.csv 2>/dev/null || true
 rm -rf $O/kt $O/pf $O/pw $O/ps
 cd $R && python3 tools/pmc_summary.py $O
+# the bench line again, now priced with the counters just collected (the first one only named the workload)
+cd /tmp && python3 $R/bench.py --no-matrix --traffic $O/traffic.json "$@" > $O/bench.json 2> $O/bench.err
 cat $O/bench.json
