@@ -1290,10 +1290,10 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
     if (rs->n_reads >= (1ull << 32)) return false;
-    // On request only (option tiled_search = 2 / COMMET_TILED=2): with the tail probes of the fused kernels fetched eight
-    // at a time the two paths are level (configs[1]: 9.25 vs 9.39 ms, configs[2] jobs 1.87-1.93 vs 1.88 s), and the
-    // query list costs 8 bytes per first-hit window of HBM and 11 ms per 10 M-read set to build.
-    return c->tiled_mode == 2;
+    if (c->tiled_mode == 2) return true;
+    // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB.  Measured
+    // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
+    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= (4ull << 30);
 }
 
 // the set's query list for this context's (k, t): counted, scanned, filled; kept with the set
@@ -1332,10 +1332,18 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
         if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 4);
         if (e == hipSuccess) {
-            KScope ks(c, "tq_fill_kernel", c->stream);
-            hipLaunchKernelGGL(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
-                               ql.n_pieces, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
-            e = hipGetLastError();
+            // reads sorted per round in LDS: as many as keep rpr * (first-hit windows per read) within TQ_FILL_CAP records
+            const int64_t fhw = std::max<int64_t>(1, (int64_t) rs->max_len - (int64_t) t * c->k + 1);
+            uint32_t rpr = TQ_PIECE;
+            while (rpr > 1 && (uint64_t) rpr * (uint64_t) fhw > TQ_FILL_CAP) rpr /= 2;
+            const size_t lds_fill = ((size_t) 4 * ql.n_slices + 2 * TQ_FILL_CAP) * 4;
+            e = hipFuncSetAttribute((const void *) tq_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
+            if (e == hipSuccess) {
+                KScope ks(c, "tq_fill_kernel", c->stream);
+                hipLaunchKernelGGL(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                                   ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+                e = hipGetLastError();
+            }
         }
     }
     (void) hipFree(d_totals);

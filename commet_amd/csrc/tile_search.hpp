@@ -163,25 +163,50 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
     if (blockIdx.x == 0 && threadIdx.x == 0) a[n] = *grand_total;   // closes the table
 }
 
-// writes the records of piece blockIdx.x into its tiles (tile_off = the scanned counts)
+// writes the records of piece blockIdx.x into its tiles (tile_off = the scanned counts).  The records of `rpr` reads at a
+// time are sorted by slice in LDS (counting sort) and every tile's share leaves as one run of consecutive lanes: written
+// record by record straight from the window loop, each 4-byte store reached HBM on its own (18.7 GB written for 3 GB of
+// records, 11 ms per 10 M-read set).
+constexpr uint32_t TQ_FILL_CAP = 6144;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
 __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
-                                                      const unsigned long long *__restrict__ tile_off, uint32_t *__restrict__ qaddr,
-                                                      uint32_t *__restrict__ qwho)
+                                                      uint32_t rpr, const unsigned long long *__restrict__ tile_off,
+                                                      uint32_t *__restrict__ qaddr, uint32_t *__restrict__ qwho)
 {
-    extern __shared__ uint32_t cur[];   // n_slices: records of the tile written so far
-    for (uint32_t i = threadIdx.x; i < n_slices; i += 256) cur[i] = 0;
-    __syncthreads();
+    extern __shared__ uint32_t fl[];
+    uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *done = fill + n_slices;   // n_slices each
+    uint32_t *rec_a = done + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
+    __shared__ uint32_t wsum[16];
+    for (uint32_t i = threadIdx.x; i < n_slices; i += 256) done[i] = 0;
     const uint64_t r0 = (uint64_t) blockIdx.x * TQ_PIECE;
     const uint32_t smask = (1u << sbits) - 1u;
-    for (uint32_t i = threadIdx.x; i < TQ_PIECE; i += 256) {
-        const uint64_t r = r0 + i;
-        if (r >= rv.n) break;
-        tq_for_each_window(rv, r, k, t, [&](uint32_t win, uint32_t addr, bool selfp) {
-            const uint32_t s = addr >> sbits;
-            const unsigned long long at = tile_off[(uint64_t) s * n_pieces + blockIdx.x] + atomicAdd(&cur[s], 1u);
-            qaddr[at] = (addr & smask) | (selfp ? 0x80000000u : 0u);
-            qwho[at] = i | (win << 10);
-        });
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t rr = 0; rr < TQ_PIECE; rr += rpr) {
+        for (uint32_t i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0, fill[i] = 0;
+        __syncthreads();
+        const uint32_t i = rr + threadIdx.x;
+        const bool mine = threadIdx.x < rpr && i < TQ_PIECE && r0 + i < rv.n;
+        if (mine) tq_for_each_window(rv, r0 + i, k, t, [&](uint32_t, uint32_t addr, bool) { atomicAdd(&cnt[addr >> sbits], 1u); });
+        __syncthreads();
+        lds_scan<256>(cnt, base, n_slices, wsum);
+        if (mine)
+            tq_for_each_window(rv, r0 + i, k, t, [&](uint32_t win, uint32_t addr, bool selfp) {
+                const uint32_t s = addr >> sbits;
+                const uint32_t at = base[s] + atomicAdd(&fill[s], 1u);
+                rec_a[at] = (addr & smask) | (selfp ? 0x80000000u : 0u);
+                rec_w[at] = i | (win << 10);
+            });
+        __syncthreads();
+        for (uint32_t s = wave; s < n_slices; s += 4) {
+            const uint32_t n = cnt[s];
+            if (!n) continue;
+            const unsigned long long dst = tile_off[(uint64_t) s * n_pieces + blockIdx.x] + done[s];
+            for (uint32_t j = lane; j < n; j += 64) {
+                qaddr[dst + j] = rec_a[base[s] + j];
+                qwho[dst + j] = rec_w[base[s] + j];
+            }
+            if (lane == 0) done[s] += n;
+        }
+        __syncthreads();
     }
 }
 
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
     // reference leaves it after t hits, i.e. after ~4 t probes.  Such "heavy" reads (more than TQ_HEAVY candidates in one
     // scan) keep their masks in registers and walk them themselves in step (3), stopping at t; probing all their windows in
     // the balanced sweeps would multiply their probes by ten.
-    constexpr uint32_t TQ_HEAVY = 12;
+    constexpr uint32_t TQ_HEAVY = 20;   // 4 / 12 / 18 / 24 / 32 / 40 -> 8.2 / 6.9 / 6.3 / 6.3 / 6.6 / 8.9 ms on configs[1]
     uint32_t am[NS][MW];
     bool heavy = false;
 #pragma unroll
@@ -380,7 +405,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         const uint32_t ex = block_scan<TQ_PIECE>(cnt, scan_ws, &total);
         pre[threadIdx.x] = ex + cnt;                      // inclusive
         __syncthreads();
-        constexpr int U = 4;
+        constexpr int U = 2;
         for (uint32_t f0 = threadIdx.x; f0 < total; f0 += U * TQ_PIECE) {
             uint32_t owner[U], bitn[U], ka[U], kb[U], fw[U], fbit[U];
             int sc[U], hw[U];
@@ -433,28 +458,18 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         __syncthreads();
     };
     if (!(COMMET_TQ_ABLATE & 1024)) {
-        // plane B of every candidate
+        // plane B of every candidate; the one in nine that passes goes through planes C and D at once (two independent
+        // loads).  A second balanced sweep for C / D (1.2 K survivors per piece) cost more in prefix sums and barriers
+        // than the divergence it avoided.
         sweep(masks,
               [&](int i, uint32_t, uint32_t kb, uint32_t &bit) -> const uint32_t * {
                   bit = kb & 31u;
                   return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words + (kb >> 5);
               },
-              [&](uint32_t owner, int i, int h, uint32_t b, uint32_t, uint32_t) { atomicOr(&word_at(pass, i, h, owner), 1u << b); });
-        // masks := full hits (A & B & C & D): plane C of the survivors in the sweep, plane D behind it (one in a hundred)
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int h = 0; h < MW; ++h) word_at(masks, i, h, threadIdx.x) = 0;
-        __syncthreads();
-        if (!(COMMET_TQ_ABLATE & 16384))
-        sweep(pass,
-              [&](int i, uint32_t ka, uint32_t kb, uint32_t &bit) -> const uint32_t * {
-                  bit = (ka ^ kb) & 31u;
-                  return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 2 * fg.plane_words + ((ka ^ kb) >> 5);
-              },
               [&](uint32_t owner, int i, int h, uint32_t b, uint32_t ka, uint32_t kb) {
-                  const uint32_t *pd = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 3 * fg.plane_words;
-                  if (test_bit<uint32_t>(pd, ka | kb)) atomicOr(&word_at(masks, i, h, owner), 1u << b);
+                  const uint32_t *pc = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 2 * fg.plane_words, *pd = pc + fg.plane_words;
+                  const uint32_t vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
+                  if ((vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u) atomicOr(&word_at(pass, i, h, owner), 1u << b);
               });
     }
     // (3) the reference's control flow (search_reads.h:45-83) on the full hits of this thread's read: per chunk, strand 0
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
             int seen = 0, next_ok = 0;
             bool dead = false;
             for (int h = 0; h < MW && !found && !dead; ++h) {
-                uint32_t m = masks[((i * MW) + h) * TQ_PIECE + threadIdx.x];   // light reads: full hits (steps above)
+                uint32_t m = pass[((i * MW) + h) * TQ_PIECE + threadIdx.x];    // light reads: full hits (step 2)
                 if (heavy) {                                                     // heavy reads: lane-a candidates, probed here
                     m = 0;
 #pragma unroll

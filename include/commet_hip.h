@@ -180,7 +180,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
  *                        for read sets with at most 96 first-hit windows per read, else 4)
  *   tiled_search (0/1/2) large search sets against 1 or 2 chunk filters (24 <= k <= 32): lane-a gathers served from L2 slice
- *                        by slice from the set's cached query list; 2 = whenever possible, 0 / 1 = not (the default: no gain yet)
+ *                        by slice from the set's cached query list; 0 = sets of 2^20 reads or more whose list fits 4 GiB,
+ *                        1 = never, 2 = whenever possible
  *   slice_mode (0/1/2)   many-small-chunks regime (12 <= k <= 24): the filters of 32..256 chunks bit-sliced in one table
  *                        set and searched in ONE pass; 0 = from 8 chunks on, 1 = never, 2 = always
  *   slice_words          chunk filters per pass / 32 in that regime (0 auto, 1, 2, 4, 8)
