@@ -227,14 +227,15 @@ struct commet_readset {
     // query list of the tiled search (tile_search.hpp): the set's lane-a addresses sorted by address slice, made on first use
     struct QueryList {
         unsigned long long *d_tile_off = nullptr;
-        uint32_t *d_qaddr = nullptr, *d_qwho = nullptr;
+        uint32_t *d_qaddr = nullptr, *d_tstart = nullptr;
+        uint16_t *d_qwho = nullptr, *d_tlen = nullptr;
         uint64_t n_records = 0;
         uint32_t n_slices = 0, n_pieces = 0;
         int sbits = 0;
         bool built = false, failed = false;
         void release()
         {
-            (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho);
+            (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho); (void) hipFree(d_tstart); (void) hipFree(d_tlen);
             *this = QueryList();
         }
     };
@@ -386,6 +387,16 @@ uint64_t commet_max_kmer(const commet_ctx *c)
 {
     if (c->max_kmer_test) return c->max_kmer_test;          // test hook, see commet_set_option
     return (uint64_t) (1000000000.0 / pow(2, 33 - c->k));   // index_and_search.cpp:73,146
+}
+
+int commet_device_memory(const commet_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    HIP_OK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_OK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
 }
 
 int commet_synchronize(commet_ctx *c)
@@ -1330,7 +1341,16 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         ql.n_records = total;
         if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
-        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 4);
+        if (e == hipSuccess && total >= (1ull << 32)) e = hipErrorOutOfMemory;   // tstart is 32 bits (never with the 4 GiB cap)
+        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 2);
+        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_tstart, std::max<uint64_t>(entries, 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_tlen, std::max<uint64_t>(entries, 1) * 2);
+        if (e == hipSuccess) {
+            KScope ks(c, "tq_bounds_kernel", c->stream);
+            hipLaunchKernelGGL(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, c->stream, ql.d_tile_off, ql.n_slices,
+                               ql.n_pieces, ql.d_tstart, ql.d_tlen);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) {
             // reads sorted per round in LDS: as many as keep rpr * (first-hit windows per read) within TQ_FILL_CAP records
             const int64_t fhw = std::max<int64_t>(1, (int64_t) rs->max_len - (int64_t) t * c->k + 1);
@@ -1357,21 +1377,33 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
     return 0;
 }
 
+// the scan's result bytes (one per record of the set's query list); no room = this set keeps the gather kernels
+int ensure_query_results(commet_ctx *c, const commet_readset *rs)
+{
+    const uint64_t need = rs->ql.n_records;
+    if (c->qres_cap >= need && c->d_qres) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+    (void) hipFree(c->d_qres);
+    c->d_qres = nullptr, c->qres_cap = 0;
+    if (hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1)) != hipSuccess) {
+        (void) hipGetLastError();
+        rs->ql.failed = true;
+        return 1;
+    }
+    c->qres_cap = need;
+    return 0;
+}
+
 // one pass of rs over the g <= 2 chunk filters in slots slot0 .. slot0 + g - 1 (g == 2: slots 0, 1 with interleaved A planes)
 int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot0, const uint64_t *d_sel, uint64_t *d_tags,
                         unsigned long long *d_counters, uint32_t cstride)
 {
     if (rs->n_reads == 0) return 0;
     const commet_readset::QueryList &q = rs->ql;
-    if (c->qres_cap < q.n_records) {
-        HIP_OK(hipStreamSynchronize(c->stream));
-        (void) hipFree(c->d_qres);
-        c->d_qres = nullptr, c->qres_cap = 0;
-        HIP_OK(hipMalloc((void **) &c->d_qres, std::max<uint64_t>(q.n_records, 1)));
-        c->qres_cap = q.n_records;
-    }
+    if (c->qres_cap < q.n_records) return fail("internal error: tiled search without its result buffer");
     QueryListView v;
-    v.tile_off = q.d_tile_off, v.qaddr = q.d_qaddr, v.qwho = q.d_qwho, v.n_slices = q.n_slices, v.n_pieces = q.n_pieces, v.sbits = q.sbits;
+    v.tile_off = q.d_tile_off, v.qaddr = q.d_qaddr, v.qwho = q.d_qwho, v.tstart = q.d_tstart, v.tlen = q.d_tlen;
+    v.n_slices = q.n_slices, v.n_pieces = q.n_pieces, v.sbits = q.sbits;
     FilterGroupView fg;
     fg.slot0 = c->slot_ptr(slot0);
     fg.il_a = g == 1 ? c->slot_ptr(slot0) : c->il_a;   // one filter: its own plane A (stride 1)
@@ -1804,7 +1836,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         for (int s = 0; s < n_search && !rc; ++s) {
             const commet_readset *rs = search_rs[s];
             unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
-            if (g == 2 && tiled_ok(c, rs, g) && build_query_list(c, rs) == 0) {
+            if (g == 2 && tiled_ok(c, rs, g) && build_query_list(c, rs) == 0 && ensure_query_results(c, rs) == 0) {
                 // large set, two chunk filters: lane-a gathers served from L2, slice by slice (tile_search.hpp)
                 if (launch_search_tiled(c, rs, 2, 0, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search))) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
@@ -1814,7 +1846,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
                     c->cur_slot = i;
-                    if (tiled_ok(c, rs, 1) && build_query_list(c, rs) == 0) {   // the same, one filter at a time
+                    if (tiled_ok(c, rs, 1) && build_query_list(c, rs) == 0 && ensure_query_results(c, rs) == 0) {   // the same, one filter at a time
                         if (launch_search_tiled(c, rs, 1, i, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt + 2 * (uint64_t) i * n_search, (uint32_t) (2 * n_search))) rc = 1;
                     } else
                     if (launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;

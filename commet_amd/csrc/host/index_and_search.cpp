@@ -64,9 +64,15 @@ struct ServerState {
     std::map<std::pair<commet_ctx *, std::string>, CachedSet> sets;              // (context, files key) -> resident set
     uint64_t tick = 0, hits = 0, loads = 0, evictions = 0, requests = 0;
     uint64_t cached_bytes = 0, budget_bytes = 0;                                 // budget: COMMET_SERVER_CACHE_GB (default 96)
-    void evict_until(uint64_t need)
+    // makes room for `need` more bytes of resident sets: by the budget on their estimated footprint, and by what the
+    // device really has left (a set's footprint grows after it was cached: per-read counts, the tiled search's query list)
+    void evict_until(uint64_t need, commet_ctx *ctx)
     {
-        while (cached_bytes + need > budget_bytes) {
+        for (;;) {
+            uint64_t free_b = ~0ull, total_b = 0;
+            if (ctx) (void) commet_device_memory(ctx, &free_b, &total_b);
+            const bool tight = ctx && free_b < std::max<uint64_t>(4 * need, total_b / 4);
+            if (cached_bytes + need <= budget_bytes && !tight) return;
             auto victim = sets.end();
             for (auto it = sets.begin(); it != sets.end(); ++it)
                 if (!it->second.in_use && (victim == sets.end() || it->second.last_use < victim->second.last_use)) victim = it;
@@ -261,7 +267,7 @@ static void load_set(commet_ctx *ctx, const std::string &nickname, const std::ve
         cs.rs = out.rs;
         cs.bytes = bases / 2 + out.n_reads * 40 + (1u << 20);
         for (size_t i = 0; i < out.files.size(); ++i) cs.file_reads.push_back(commet_readset_file_reads(out.rs, i));
-        g_server->evict_until(cs.bytes);
+        g_server->evict_until(cs.bytes, ctx);
         cs.in_use = true;
         cs.last_use = ++g_server->tick;
         g_server->cached_bytes += cs.bytes;

@@ -20,7 +20,7 @@
 //   piece  = 1024 consecutive reads                                    n_pieces = ceil(n / 1024)
 //   tile (slice, piece) = records [tile_off[slice * n_pieces + piece], tile_off[... + 1])  — slice-major, so a slice's
 //   records are contiguous (probe) and a piece finds its share of every slice (replay)
-//   qaddr[i] = address within the slice | self-paired flag << 31;   qwho[i] = read within piece | window << 10
+//   qaddr[i] = address within the slice | self-paired flag << 31;   qwho[i] = read within piece | window << 8 (16 bits)
 #pragma once
 
 #include "kernels.hpp"
@@ -39,7 +39,10 @@ constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three m
 
 struct QueryListView {
     const unsigned long long *tile_off;   // n_slices * n_pieces + 1
-    const uint32_t *qaddr, *qwho;
+    const uint32_t *qaddr;
+    const uint16_t *qwho;                 // read within piece (8 bits) | window << 8
+    const uint32_t *tstart;               // piece-major copy of the tile bounds for the replay: tstart[piece * n_slices + slice]
+    const uint16_t *tlen;                 //   = first record / number of records of tile (slice, piece)
     uint32_t n_slices, n_pieces;
     int sbits;
 };
@@ -163,6 +166,19 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
     if (blockIdx.x == 0 && threadIdx.x == 0) a[n] = *grand_total;   // closes the table
 }
 
+// piece-major copy of the tile bounds (the replay reads all slices of ONE piece: 256 strided 8-byte loads become two short
+// contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 96).
+__global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long *__restrict__ tile_off, uint32_t n_slices, uint32_t n_pieces,
+                                                        uint32_t *__restrict__ tstart, uint16_t *__restrict__ tlen)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;          // = piece * n_slices + slice
+    if (i >= (uint64_t) n_slices * n_pieces) return;
+    const uint64_t p = i / n_slices, s = i % n_slices;
+    const unsigned long long a = tile_off[s * n_pieces + p], e = tile_off[s * n_pieces + p + 1];
+    tstart[i] = (uint32_t) a;
+    tlen[i] = (uint16_t) (e - a);
+}
+
 // writes the records of piece blockIdx.x into its tiles (tile_off = the scanned counts).  The records of `rpr` reads at a
 // time are sorted by slice in LDS (counting sort) and every tile's share leaves as one run of consecutive lanes: written
 // record by record straight from the window loop, each 4-byte store reached HBM on its own (18.7 GB written for 3 GB of
@@ -170,8 +186,9 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
 constexpr uint32_t TQ_FILL_CAP = 6144;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
 __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
                                                       uint32_t rpr, const unsigned long long *__restrict__ tile_off,
-                                                      uint32_t *__restrict__ qaddr, uint32_t *__restrict__ qwho)
+                                                      uint32_t *__restrict__ qaddr, uint16_t *__restrict__ qwho)
 {
+    static_assert(TQ_PIECE <= 256 && TQ_MAX_WIN <= 128, "qwho packs the read in 8 bits and the window in 7");
     extern __shared__ uint32_t fl[];
     uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *done = fill + n_slices;   // n_slices each
     uint32_t *rec_a = done + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
                 const uint32_t s = addr >> sbits;
                 const uint32_t at = base[s] + atomicAdd(&fill[s], 1u);
                 rec_a[at] = (addr & smask) | (selfp ? 0x80000000u : 0u);
-                rec_w[at] = i | (win << 10);
+                rec_w[at] = i | (win << 8);
             });
         __syncthreads();
         for (uint32_t s = wave; s < n_slices; s += 4) {
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
             const unsigned long long dst = tile_off[(uint64_t) s * n_pieces + blockIdx.x] + done[s];
             for (uint32_t j = lane; j < n; j += 64) {
                 qaddr[dst + j] = rec_a[base[s] + j];
-                qwho[dst + j] = rec_w[base[s] + j];
+                qwho[dst + j] = (uint16_t) rec_w[base[s] + j];
             }
             if (lane == 0) done[s] += n;
         }
@@ -292,8 +309,8 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
             const uint32_t sl = s0 + lane * NWAVE;                       // this lane's tile of the batch
             unsigned long long ta = 0, te = 0;
             if (sl < ql.n_slices) {
-                const unsigned long long *to = ql.tile_off + (uint64_t) sl * ql.n_pieces + blockIdx.x;
-                ta = to[0], te = to[1];
+                ta = ql.tstart[(uint64_t) blockIdx.x * ql.n_slices + sl];           // piece-major: a piece's bounds are contiguous
+                te = ta + ql.tlen[(uint64_t) blockIdx.x * ql.n_slices + sl];
             }
             const uint32_t len = (uint32_t) (te - ta);
             uint32_t inc = len;                                           // inclusive prefix of the tile lengths over the lanes
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                 const unsigned long long i = tbase + (f - (src ? before_raw : 0u));
                 const uint32_t res = __builtin_nontemporal_load(qres + i);
                 if (!res) continue;
-                const uint32_t who = __builtin_nontemporal_load(ql.qwho + i), rd = who & 1023u, win = who >> 10;
+                const uint32_t who = __builtin_nontemporal_load(ql.qwho + i), rd = who & 255u, win = who >> 8;
 #pragma unroll
                 for (int c = 0; c < GS; ++c) {
                     if ((res >> c) & 1u) atomicOr(&mask_at(c, 0, (int) (win >> 5), rd), 1u << (win & 31u));

@@ -42,6 +42,7 @@ SIGNATURES = {
     "commet_min_hits": (C.c_int, [C.c_void_p]),
     "commet_max_kmer": (C.c_uint64, [C.c_void_p]),
     "commet_synchronize": (C.c_int, [C.c_void_p]),
+    "commet_device_memory": (C.c_int, [C.c_void_p, u64p, u64p]),
     "commet_readset_create": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "commet_readset_destroy": (None, [C.c_void_p]),
     "commet_readset_begin_file": (C.c_int, [C.c_void_p]),

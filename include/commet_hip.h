@@ -53,6 +53,8 @@ int         commet_kmer_size(const commet_ctx *ctx);
 int         commet_min_hits(const commet_ctx *ctx);
 /* max_kmer = (unsigned long)(1e9 / 2^(33-k))  (src/index_and_search.cpp:73,146) */
 uint64_t    commet_max_kmer(const commet_ctx *ctx);
+/* free / total memory of the context's device (a resident server decides from it which sets to keep) */
+int         commet_device_memory(const commet_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* blocks until everything queued on the ctx's stream has finished */
 int         commet_synchronize(commet_ctx *ctx);
 
