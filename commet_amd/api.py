@@ -231,6 +231,32 @@ class ReadSet:
         self._check(self._lib.commet_readset_begin_file(self._h))
         self._check(self._lib.commet_readset_append(self._h, _ptr(b), _ptr(o), o.size - 1))
 
+    def add_file_staged(self, bases, offsets):
+        """The same through the pinned staging API (commet_readset_stage_acquire / _commit): the caller's parser writes
+        ASCII bases straight into pinned buffers, the device packs them (pack_reads_kernel)."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = o.size - 1
+        self._check(self._lib.commet_readset_begin_file(self._h))
+        done = 0
+        while done < n:
+            hb, ho = _l.u8p(), _l.u64p()
+            bcap, rcap = C.c_uint64(0), C.c_uint64(0)
+            self._check(self._lib.commet_readset_stage_acquire(self._h, C.byref(hb), C.byref(bcap), C.byref(ho), C.byref(rcap)))
+            b0 = int(o[done])
+            take = 0
+            while done + take < n and take < rcap.value and int(o[done + take + 1]) - b0 <= bcap.value:
+                take += 1
+            if take == 0:
+                self._check(self._lib.commet_readset_stage_commit(self._h, 0))
+                raise CommetError("a read does not fit the staging buffer")
+            nb = int(o[done + take]) - b0
+            C.memmove(hb, b[b0:b0 + nb].ctypes.data, nb)
+            offs = (o[done:done + take + 1] - np.uint64(b0)).astype(np.uint64)
+            C.memmove(ho, offs.ctypes.data, offs.size * 8)
+            self._check(self._lib.commet_readset_stage_commit(self._h, take))
+            done += take
+
     def finalize(self):
         self._check(self._lib.commet_readset_finalize(self._h))
 

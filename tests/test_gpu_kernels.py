@@ -309,3 +309,37 @@ def test_parallel_host_ingest_equals_batch_upload(commet, tmp_path, monkeypatch)
         t1, s1, i1 = ctx.index_and_search(a, [q])
         t2, s2, i2 = ctx.index_and_search(b, [q])
         assert np.array_equal(t1[0], t2[0]) and i1["n_chunks"] == i2["n_chunks"] and i1["kmers_indexed"] == i2["kmers_indexed"]
+
+
+def test_staging_api_device_pack_equals_host_pack():
+    """commet_readset_stage_acquire / _commit (ASCII in pinned buffers, pack_reads_kernel on the device) against
+    commet_readset_append (2-bit packed by the host threads): same k-mer counts, same filter, same search result — also
+    for a set that mixes the two ways file by file"""
+    import commet_amd
+    rng = np.random.default_rng(77)
+    reads = util.random_reads(rng, 3000, 1, 400, n_rate=0.02, lower_rate=0.2, other_rate=0.01) + [b""] * 0
+    half = len(reads) // 2
+    fa, fb = util.to_batch(reads[:half]), util.to_batch(reads[half:])
+    q = util.related_reads(rng, reads, 2500, 30, 300, share=0.6)
+    qb, qo = util.to_batch(q)
+    for k in (12, 25, 33):
+        with commet_amd.Context(k=k, t=2) as ctx:
+            host = commet_amd.ReadSet.from_files(ctx, [fa, fb])
+            dev = commet_amd.ReadSet(ctx, len(reads), int(fa[1][-1] + fb[1][-1]))
+            dev.add_file_staged(*fa)
+            dev.add_file_staged(*fb)
+            dev.finalize()
+            mixed = commet_amd.ReadSet(ctx, len(reads), int(fa[1][-1] + fb[1][-1]))
+            mixed.add_file(*fa)
+            mixed.add_file_staged(*fb)
+            mixed.finalize()
+            kc = host.kmer_counts()
+            assert np.array_equal(dev.kmer_counts(), kc) and np.array_equal(mixed.kmer_counts(), kc)
+            assert dev.file_reads() == host.file_reads() == mixed.file_reads() == [half, len(reads) - half]
+            qs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+            ref = ctx.index_and_search(host, [qs])
+            for other in (dev, mixed):
+                got = ctx.index_and_search(other, [qs])
+                assert np.array_equal(got[0][0], ref[0][0]) and got[1][0]["shared"] == ref[1][0]["shared"] > 200
+            back = ctx.index_and_search(qs, [dev])            # the device-packed set as the search set
+            assert np.array_equal(back[0][0], ctx.index_and_search(qs, [host])[0][0])
