@@ -220,3 +220,41 @@ def test_bucketed_multi_chunk_variants_match_oracle(tmp_path, k, L, uniform, n_i
                 (res[0]["indexed"], res[0]["searched"], res[0]["shared"]), (lanes, packed, no_uni, group)
             assert np.array_equal(util.bools_from_bits(tags[0], n), want), (lanes, packed, no_uni, group)
         assert stats[0]["shared"] > 1000
+
+
+def test_record_longer_than_a_staging_buffer(tmp_path):
+    """a 9 Mbase record (a contig used as a set: the reference accepts any length) is longer than one pinned staging buffer
+    of the ingest (3 MiB of planes = 8.4 M bases): the packer uploads it in pieces; results must equal the CPU checker's"""
+    import commet_amd as commet
+    rng = np.random.default_rng(123)
+    d = tmp_path / "long"
+    os.makedirs(d)
+    contig = util.random_reads(rng, 1, 9_000_000, 9_000_000, n_rate=0.0005, lower_rate=0, other_rate=0)[0]
+    shorts = util.random_reads(rng, 50, 60, 200)
+    q = [contig[a:a + 150] for a in rng.integers(0, len(contig) - 200, size=300)] + util.random_reads(rng, 300, 100, 150)
+    q = [util.revcomp(r) if i % 3 == 0 else r for i, r in enumerate(q)]
+    with open(d / "i.fa", "wb") as fh:
+        fh.write(b">s0\n" + shorts[0] + b"\n>contig\n")
+        for j in range(0, len(contig), 70):
+            fh.write(contig[j:j + 70] + b"\n")
+        for i, r in enumerate(shorts[1:]):
+            fh.write(b">s%d\n" % (i + 1) + r + b"\n")
+    util.write_fasta(str(d / "q.fa"), q)
+    (d / "index.txt").write_text("I:i.fa\n")
+    (d / "search.txt").write_text("Q:q.fa\n")
+
+    class S:
+        dir, index_cfg, search_cfg = str(d), "index.txt", "search.txt"
+    S.k, S.t = 20, 2
+    rc, res, chunks, kmers = run_oracle(S, str(tmp_path / "o"), str(tmp_path / "l"))
+    assert rc == 0
+    _, n, bits = util.read_bv(str(tmp_path / "o" / "q.fa_in_I.bv"))
+    with commet.Context(k=20, t=2) as ctx:
+        irs = commet.ReadSet.from_fasta(ctx, [str(d / "i.fa")])
+        qrs = commet.ReadSet.from_fasta(ctx, [str(d / "q.fa")])
+        assert irs.num_reads == 51 and int(irs.kmer_counts().max()) > 8_900_000
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == (res[0]["indexed"], res[0]["searched"], res[0]["shared"])
+        assert np.array_equal(util.bools_from_bits(tags[0], n), util.bools_from_bits(bits, n))
+        assert stats[0]["shared"] >= 250
