@@ -1,5 +1,6 @@
 """Extended randomised parity run (not part of the test-suite): job-level GPU results against the CPU checker
-on many scenarios of tests/scenarios.py, cycling through index modes, chunk-group sizes and input formats.
+on many scenarios of tests/scenarios.py, cycling through index modes, chunk-group sizes, input formats and (forced on)
+the bit-sliced regime and the tiled search.
   python tools/fuzz_gpu.py [first_seed] [count]"""
 import os
 import sys
@@ -31,6 +32,8 @@ def main():
         try:
             mode = seed % 3
             k = None if mode != 2 else [20, 21, 24, 25, 28][seed % 5]
+            if seed % 11 >= 7:                  # the round-2 paths need k >= 12 (bit-sliced) / k >= 24 (tiled search)
+                k = [12, 16, 21, 24, 26, 30][seed % 6]
             fmts = ("fa", "fq", "fa.gz", "fq.gz") if seed % 4 == 0 else ("fa",)
             scn = Scenario(os.path.join(d, "s"), seed, k=k, n_scale=1.0 + (seed % 7), formats=fmts,
                            crlf=False if len(fmts) > 1 else None)
@@ -41,6 +44,13 @@ def main():
                 ctx.set_option("count_probes", int(counting))
                 ctx.set_option("index_mode", mode)
                 ctx.set_option("chunk_group", 1 + seed % 8)
+                if seed % 11 >= 7:              # forced: bit-sliced regime (any number of chunks) or tiled search; small chunks
+                    counting = False
+                    ctx.set_option("count_probes", 0)
+                    ctx.set_option("slice_mode", 2 if seed % 2 else 1)
+                    ctx.set_option("slice_words", [0, 1, 2, 4, 8][seed % 5])
+                    ctx.set_option("tiled_search", 2 if seed % 2 == 0 else 1)
+                    ctx.set_option("chunk_group", 1 + seed % 3)
                 irs, isel = load_set(ctx, scn.sets[scn.index_name], scn.dir)
                 names = sorted(scn.search_names)
                 loaded = [load_set(ctx, scn.sets[nme], scn.dir) for nme in names]
