@@ -53,10 +53,12 @@ struct ReadStats {
         (void) init;
         return lut;
     }
-    void add(const char *s, size_t n)
+    // count = false: no criterion looks at the bases (no -n, -e 0: what Commet.py passes by default) — only the length
+    void add(const char *s, size_t n, bool count = true)
     {
-        const uint8_t *lut = classes();
         len += n;
+        if (!count) return;
+        const uint8_t *lut = classes();
         for (size_t i = 0; i < n; ++i) ++cnt[lut[(uint8_t) s[i]]];
     }
     uint64_t non_acgt() const { return cnt[4]; }
@@ -157,6 +159,7 @@ int main(int argc, char **argv)
     const bool fastq = mf.format() == ReadFormat::Fastq;
     if (fastq) bv.init_true(count_records(mf.format(), d, n));   // FASTA: the classification below counts the records
     long rm_length = 0, rm_N = 0, rm_shannon = 0;
+    const bool need_bases = max_N != INT_MAX || min_shannon > 0;   // else the verdict depends on the length alone
     auto classify = [&](const ReadStats &st, Shannon &sh) -> uint8_t {
         if (st.len == 0) return EMPTY;
         if ((int) st.len < min_size) return RM_LENGTH;
@@ -175,7 +178,7 @@ int main(int argc, char **argv)
         Shannon sh;
         for_each_fastq_record(d, n, bv.size, [&](const char *s, size_t len) {
             ReadStats st;
-            st.add(s, len);
+            st.add(s, len, need_bases);
             verdicts[0].push_back(classify(st, sh));
         });
     } else {
@@ -209,7 +212,7 @@ int main(int argc, char **argv)
                 while (j < end && d[j] != '>') {
                     nl = (const char *) memchr(d + j, '\n', end - j);
                     const size_t e = nl ? (size_t) (nl - d) : end;
-                    st.add(d + j, e - j);
+                    st.add(d + j, e - j, need_bases);
                     j = nl ? e + 1 : end;
                 }
                 i = j;
