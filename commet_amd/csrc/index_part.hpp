@@ -714,15 +714,29 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
         for (uint32_t i = threadIdx.x; i < nsub; i += NT) cnt[i] = 0, fill[i] = 0;
         __syncthreads();
         uint32_t key[S2_PER_THREAD];
+        const bool whole = n == S2_KEYS;   // (uniform) a whole slab inside one coarse bucket, the usual case: no per-key bounds tests
+        if (whole) {
+            // (pos = slab * S2_KEYS here: 16-byte aligned; which thread sorts which key does not matter)
+            const uint4 *in4 = (const uint4 *) (in + pos);
 #pragma unroll
-        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
-            const uint32_t i = threadIdx.x + NT * q;
-            key[q] = i < n ? in[pos + i] : 0xFFFFFFFFu;
-        }
+            for (uint32_t q = 0; q < S2_PER_THREAD / 4; ++q) {
+                const uint4 v = in4[threadIdx.x + NT * q];
+                key[4 * q] = v.x, key[4 * q + 1] = v.y, key[4 * q + 2] = v.z, key[4 * q + 3] = v.w;
+            }
 #pragma unroll
-        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
-            const uint32_t i = threadIdx.x + NT * q;
-            if (i < n && !(COMMET_ABLATE & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q)
+                if (!(COMMET_ABLATE & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+                const uint32_t i = threadIdx.x + NT * q;
+                key[q] = i < n ? in[pos + i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+                const uint32_t i = threadIdx.x + NT * q;
+                if (i < n && !(COMMET_ABLATE & 256)) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+            }
         }
         __syncthreads();
         lds_scan<NT>(cnt, base, nsub, wsum);
@@ -731,12 +745,21 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
             const unsigned long long want = g.packed ? (c + 2) / 3 : c;   // packed: whole groups of three keys
             gbase[i] = (c && !(COMMET_ABLATE & 128)) ? atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + i], want) : 0ull;
         }
+        if (whole) {
 #pragma unroll
-        for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
-            const uint32_t i = threadIdx.x + NT * q;
-            if (i < n && !(COMMET_ABLATE & 32)) {
-                const uint32_t sb = key[q] >> TILE_BITS;
-                sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q)
+                if (!(COMMET_ABLATE & 32)) {
+                    const uint32_t sb = key[q] >> TILE_BITS;
+                    sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
+                }
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+                const uint32_t i = threadIdx.x + NT * q;
+                if (i < n && !(COMMET_ABLATE & 32)) {
+                    const uint32_t sb = key[q] >> TILE_BITS;
+                    sorted[base[sb] + atomicAdd(&fill[sb], 1u)] = key[q] & TILE_MASK;
+                }
             }
         }
         __syncthreads();
