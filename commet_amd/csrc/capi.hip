@@ -1071,8 +1071,12 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
         {
             KScope ks(c, "part_scatter2_kernel", stream);
-            hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
-                               ws.off, g, ws.cur2, total);
+            if (g.packed && (1u << g.b2) <= S2P_MAX_SUB)
+                hipLaunchKernelGGL(part_scatter2_packed_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, (uint2 *) ws.bufB,
+                                   ws.off, g, ws.cur2, total);
+            else
+                hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
+                                   ws.off, g, ws.cur2, total);
         }
         HIP_OK(hipGetLastError());
     }
@@ -1089,7 +1093,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
         {
             KScope ks(c, "part_build_kernel", stream);
-            hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(256), TILE_WORDS * sizeof(uint32_t), stream,
+            hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(BUILD_NT), TILE_WORDS * sizeof(uint32_t), stream,
                                ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
         }
         HIP_OK(hipGetLastError());

@@ -46,7 +46,11 @@ constexpr uint32_t S1_ITEMS = S1_NT;                        // octet items per r
 constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
 constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
 constexpr uint32_t S2_PER_THREAD = S2_KEYS / S2_NT;
+constexpr uint32_t S2P_MAX_SUB = 128;                       // packed scatter-2: final buckets per coarse bucket (k <= 32; keeps the LDS at 38.7 KiB: four workgroups per CU)
 constexpr int      HIST_NT = 1024;                          // histogram workgroup size
+#ifndef BUILD_NT
+#define BUILD_NT 1024   // build workgroup: its loads in flight are what the kernel runs on (256 / 512 / 1024 threads: 2.75 / 2.52 / 2.36 ms per configs[1] step)
+#endif
 constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build workgroup
 constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
 constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
@@ -777,6 +781,136 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------
+// scatter2, packed geometry (final buckets = groups of three 19-bit keys in 8 bytes), 2^b2 <= S2P_MAX_SUB.
+//
+// Count, scan the runs' GROUP counts, place — a run's keys start at slot 3 * (its first group), so the slab is one flat
+// sequence of groups; gid[] = the run of a group, noted by the thread that places the group's first key — pad every
+// run's last group with its last key (setting a bit twice is harmless), then thread f packs and stores groups f,
+// f + NT, ... whatever run they belong to.  (Walking the runs one by one, 32 lanes per run of which ~22 have a group,
+// spent more instructions on the runs' bookkeeping than on their keys.)
+// A slab costs its workgroup a chain of dependent steps (keys in, count, scan, cursors, place, out: ~10 us with three
+// workgroups per CU), and the kernel's time is that chain, not a throughput — measured on configs[1], per step:
+// 4.84 ms as runs, 4.15 ms like this; fixed bins per final bucket (one atomic and one store per key, no counting pass)
+// halve the LDS work but expose the cursors' round trip: 4.7 ms; persistent workgroups that fetch the next slab's keys
+// while this one is written out: 6.1-6.7 ms (static shares lose more than the prefetch hides).  So: as few barriers
+// as possible, the bucket cursors reserved (one atomic per run, whole groups, as part_scan_kernel's bound on the groups
+// of a bucket assumes) while the keys are placed, and the dispatcher balancing one slab per workgroup.
+// ---------------------------------------------------------------------------
+#ifndef S2P_WAVES
+#define S2P_WAVES 6   // 80 VGPRs, three workgroups per CU; 8 (64 VGPRs, four per CU with S2P_MAX_SUB = 128) spills and measured 4.6 instead of 4.1 ms
+#endif
+__global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(const uint32_t *__restrict__ in, uint2 *__restrict__ out,
+                                                                     const uint64_t *__restrict__ off, PartGeom g,
+                                                                     unsigned long long *__restrict__ cursor2, uint64_t total)
+{
+    constexpr int NT = S2_NT;
+    __shared__ uint32_t sorted[S2_KEYS + 2 * S2P_MAX_SUB];
+    __shared__ uint32_t cnt[S2P_MAX_SUB], fill[S2P_MAX_SUB];
+    __shared__ unsigned long long gbase[S2P_MAX_SUB];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint8_t gid[S2_KEYS / 3 + S2P_MAX_SUB + 4];
+    const uint32_t nsub = 1u << g.b2;   // <= S2P_MAX_SUB < NT
+    // Slab order (option "s2_swizzle" = G, 0 = dispatch order): see part_scatter2_kernel
+    const uint32_t G = (uint32_t) g.xcd_swizzle;
+    uint64_t slab = blockIdx.x;
+    if (G > 1) {
+        const uint32_t q = gridDim.x / G, rem = gridDim.x % G, x = blockIdx.x % G;
+        slab = (uint64_t) x * q + min(x, rem) + blockIdx.x / G;
+    }
+    const uint64_t s0 = slab * S2_KEYS;
+    if (s0 >= total) return;
+    const uint64_t s1 = min(total, s0 + S2_KEYS);
+    uint32_t lo = 0, hi = g.nb1;   // coarse bucket containing s0: largest c with off[c << b2] <= s0
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[(uint64_t) mid << g.b2] <= s0) lo = mid;
+        else hi = mid;
+    }
+    uint32_t c1 = lo;
+    uint64_t pos = s0;
+    while (pos < s1) {
+        const uint64_t c_end = off[(uint64_t) (c1 + 1) << g.b2];
+        const uint64_t seg_end = min(s1, c_end);
+        if (seg_end <= pos) {   // empty coarse bucket
+            ++c1;
+            continue;
+        }
+        const uint32_t n = (uint32_t) (seg_end - pos);
+        const bool whole = n == S2_KEYS;   // (uniform) a whole slab inside one coarse bucket, the usual case: no per-key bounds tests
+        uint32_t key[S2_PER_THREAD];
+        if (whole) {   // (pos = slab * S2_KEYS here: 16-byte aligned; which thread sorts which key does not matter)
+            const uint4 *in4 = (const uint4 *) (in + pos);
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD / 4; ++q) {
+                const uint4 v = in4[threadIdx.x + NT * q];
+                key[4 * q] = v.x, key[4 * q + 1] = v.y, key[4 * q + 2] = v.z, key[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) {
+                const uint32_t i = threadIdx.x + NT * q;
+                key[q] = i < n ? in[pos + i] : 0xFFFFFFFFu;
+            }
+        }
+        if (threadIdx.x < nsub) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        if (whole) {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q)
+                if (threadIdx.x + NT * q < n) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
+        }
+        __syncthreads();
+        // ex = first GROUP of the run (exclusive scan of the runs' group counts); its keys start at slot 3 * ex, which is
+        // where the run's fill counter starts: the placement's atomic returns the key's slot
+        uint32_t n_groups = 0;
+        const uint32_t c = threadIdx.x < nsub ? cnt[threadIdx.x] : 0u;
+        const uint32_t ex = block_scan<NT>((c + 2) / 3, wsum, &n_groups);
+        // the run's place in its final bucket: reserved now, used after the placement (the atomic's round trip runs beside it)
+        unsigned long long at = 0;
+        if (threadIdx.x < nsub) {
+            fill[threadIdx.x] = 3u * ex;
+            if (c) at = atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + threadIdx.x], (unsigned long long) ((c + 2) / 3));
+        }
+        __syncthreads();
+        auto place = [&](uint32_t kq) {
+            const uint32_t sb = kq >> TILE_BITS;
+            const uint32_t slot = atomicAdd(&fill[sb], 1u), grp = slot / 3u;
+            sorted[slot] = kq & TILE_MASK;
+            if (slot == 3u * grp) gid[grp] = (uint8_t) sb;
+        };
+        if (whole) {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q) place(key[q]);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; ++q)
+                if (threadIdx.x + NT * q < n) place(key[q]);
+        }
+        __syncthreads();
+        if (threadIdx.x < nsub) {
+            gbase[threadIdx.x] = at - ex;   // where group 0 of the SLAB would go if the run's groups were numbered like the slab's
+            const uint32_t end = 3u * ex + c;
+            if (c % 3u) {
+                const uint32_t last = sorted[end - 1];
+                sorted[end] = last;
+                if (c % 3u == 1u) sorted[end + 1] = last;
+            }
+        }
+        __syncthreads();
+        for (uint32_t f = threadIdx.x; f < n_groups; f += NT) {
+            const uint32_t k0 = sorted[3u * f], k1 = sorted[3u * f + 1], k2 = sorted[3u * f + 2];
+            out[gbase[gid[f]] + f] = make_uint2(k0 | (k1 << 19), (k1 >> 13) | (k2 << 6));
+        }
+        __syncthreads();
+        pos = seg_end;
+        if (pos >= c_end) ++c1;
+    }
+}
+
 // zeroes the tiles of buckets that are split over several build workgroups (they merge with atomic ORs)
 __global__ __launch_bounds__(256) void part_zero_split_kernel(const uint32_t *__restrict__ wl_off, PartGeom g,
                                                               uint32_t *__restrict__ filter)
@@ -792,7 +926,7 @@ __global__ __launch_bounds__(256) void part_zero_split_kernel(const uint32_t *__
 // ---------------------------------------------------------------------------
 // packed geometry: off = goff (group offsets), gend = the final scatter2 cursors: bucket b's groups are
 // [off[b], gend[b]); its n_split workgroups take equal shares of them
-__global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(BUILD_NT) void part_build_kernel(const uint32_t *__restrict__ keys,
                                                          const uint64_t *__restrict__ off,
                                                          const uint32_t *__restrict__ wl_off, PartGeom g,
                                                          uint32_t *__restrict__ filter, int additive,
@@ -814,7 +948,7 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
     const uint64_t k0 = off[b] + (uint64_t) split * BUILD_CAP;
     const uint64_t k1 = min(off[b + 1], k0 + BUILD_CAP);
     uint4 *t4 = (uint4 *) tile;
-    for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) t4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += BUILD_NT) t4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (g.packed) {
         const uint64_t g0 = off[b], gn = gend[b] - g0;            // groups of the bucket
@@ -828,24 +962,24 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
             atomicOr(&tile[cq >> 5], 1u << (cq & 31u));
         };
         uint64_t v = v0 + threadIdx.x;
-        for (; v + 768 < v1; v += 1024) {
-            const uint2 x0 = gv[v], x1 = gv[v + 256], x2 = gv[v + 512], x3 = gv[v + 768];
+        for (; v + 3 * BUILD_NT < v1; v += 4 * BUILD_NT) {
+            const uint2 x0 = gv[v], x1 = gv[v + BUILD_NT], x2 = gv[v + 2 * BUILD_NT], x3 = gv[v + 3 * BUILD_NT];
             put(x0), put(x1), put(x2), put(x3);
         }
-        for (; v < v1; v += 256) put(gv[v]);
+        for (; v < v1; v += BUILD_NT) put(gv[v]);
     } else {
         // head up to 16-byte alignment, then 4 keys per lane per load, 4 loads in flight
         uint64_t a0 = (k0 + 3) & ~3ull;
         if (a0 > k1) a0 = k1;
-        for (uint64_t i = k0 + threadIdx.x; i < a0; i += 256) {
+        for (uint64_t i = k0 + threadIdx.x; i < a0; i += BUILD_NT) {
             const uint32_t key = keys[i];
             atomicOr(&tile[key >> 5], 1u << (key & 31u));
         }
         const uint64_t nvec = (k1 - a0) >> 2;
         const uint4 *kv = (const uint4 *) (keys + a0);
         uint64_t v = threadIdx.x;
-        for (; v + 768 < nvec; v += 1024) {
-            const uint4 x0 = kv[v], x1 = kv[v + 256], x2 = kv[v + 512], x3 = kv[v + 768];
+        for (; v + 3 * BUILD_NT < nvec; v += 4 * BUILD_NT) {
+            const uint4 x0 = kv[v], x1 = kv[v + BUILD_NT], x2 = kv[v + 2 * BUILD_NT], x3 = kv[v + 3 * BUILD_NT];
             const uint4 xs[4] = {x0, x1, x2, x3};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -855,14 +989,14 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
                 atomicOr(&tile[xs[u].w >> 5], 1u << (xs[u].w & 31u));
             }
         }
-        for (; v < nvec; v += 256) {
+        for (; v < nvec; v += BUILD_NT) {
             const uint4 x = kv[v];
             atomicOr(&tile[x.x >> 5], 1u << (x.x & 31u));
             atomicOr(&tile[x.y >> 5], 1u << (x.y & 31u));
             atomicOr(&tile[x.z >> 5], 1u << (x.z & 31u));
             atomicOr(&tile[x.w >> 5], 1u << (x.w & 31u));
         }
-        for (uint64_t i = a0 + 4 * nvec + threadIdx.x; i < k1; i += 256) {
+        for (uint64_t i = a0 + 4 * nvec + threadIdx.x; i < k1; i += BUILD_NT) {
             const uint32_t key = keys[i];
             atomicOr(&tile[key >> 5], 1u << (key & 31u));
         }
@@ -873,17 +1007,17 @@ __global__ __launch_bounds__(256) void part_build_kernel(const uint32_t *__restr
     if (n_split == 1) {
         uint4 *d4 = (uint4 *) dst;
         if (additive) {   // the filter already holds bits (commet_index_reads called again without a reset)
-            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) {
+            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += BUILD_NT) {
                 uint4 o = d4[i];
                 const uint4 n = t4[i];
                 o.x |= n.x, o.y |= n.y, o.z |= n.z, o.w |= n.w;
                 d4[i] = o;
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += 256) d4[i] = t4[i];
+            for (uint32_t i = threadIdx.x; i < TILE_WORDS / 4; i += BUILD_NT) d4[i] = t4[i];
         }
     } else {
-        for (uint32_t i = threadIdx.x; i < TILE_WORDS; i += 256) {
+        for (uint32_t i = threadIdx.x; i < TILE_WORDS; i += BUILD_NT) {
             const uint32_t v = tile[i];
             if (v) (void) __hip_atomic_fetch_or(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
