@@ -542,9 +542,15 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
 namespace {
 
 // ---- host ingest: records are 2-bit packed by the ingest threads (host/ingest_pack.hpp) and uploaded as planes ----
-constexpr uint64_t INGEST_STAGE_BYTES = 3ull << 20;       // one pinned staging buffer of planes (12 bytes per triple): 8 M bases;
+#ifndef INGEST_STAGE_KIB
+#define INGEST_STAGE_KIB 3072
+#endif
+#ifndef INGEST_STAGE_READS_LOG2
+#define INGEST_STAGE_READS_LOG2 17
+#endif
+constexpr uint64_t INGEST_STAGE_BYTES = (uint64_t) INGEST_STAGE_KIB << 10;       // one pinned staging buffer of planes (12 bytes per triple): 8 M bases;
                                                           // small, because pinning memory costs ~0.2 ms per MiB on first use
-constexpr uint64_t INGEST_STAGE_READS = 1ull << 17;       // base offsets per staging buffer
+constexpr uint64_t INGEST_STAGE_READS = 1ull << INGEST_STAGE_READS_LOG2;       // base offsets per staging buffer
 
 // the upload side of host/ingest_pack.hpp: two pinned staging buffers per worker out of the context's pool; a flush
 // queues hipMemcpyAsync of the planes (and the reads' base offsets) straight to their final place in the read set
@@ -558,20 +564,10 @@ struct HipPackSink {
         rs = set;
         commet_ctx *c = rs->ctx;
         if (hipSetDevice(c->device) != hipSuccess) return false;
-        while (c->ingest_pool.size() < (size_t) workers * 2) {   // hipHostMalloc is slow: buffers stay with the context
-            commet_ctx::IngestBuf b;
-            const bool ok = hipHostMalloc((void **) &b.h_planes, INGEST_STAGE_BYTES) == hipSuccess &&
-                            hipHostMalloc((void **) &b.h_goff, INGEST_STAGE_READS * sizeof(uint64_t)) == hipSuccess &&
-                            hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
-            if (!ok) {   // a half-made entry must not stay in the pool
-                if (b.h_planes) (void) hipHostFree(b.h_planes);
-                if (b.h_goff) (void) hipHostFree(b.h_goff);
-                if (b.done) (void) hipEventDestroy(b.done);
-                (void) hipGetLastError();
-                return false;
-            }
-            c->ingest_pool.push_back(b);
-        }
+        // the pool's entries exist up front (workers never resize it); their pinned memory is made by the worker that
+        // first needs it, in acquire(): pinning costs ~0.2 ms per MiB, and paid here, on one thread before any packing,
+        // it was 57 ms of the first set's 107 ms
+        if (c->ingest_pool.size() < (size_t) workers * 2) c->ingest_pool.resize((size_t) workers * 2);
         cur.assign(workers, 0);
         inflight.assign((size_t) workers * 2, 0);
         return true;
@@ -580,6 +576,20 @@ struct HipPackSink {
     {
         const size_t bi = (size_t) worker * 2 + cur[worker];
         commet_ctx::IngestBuf &b = rs->ctx->ingest_pool[bi];
+        if (!b.done) {   // hipHostMalloc is slow: buffers stay with the context
+            if (hipSetDevice(rs->ctx->device) != hipSuccess) return false;
+            const bool ok = hipHostMalloc((void **) &b.h_planes, INGEST_STAGE_BYTES) == hipSuccess &&
+                            hipHostMalloc((void **) &b.h_goff, INGEST_STAGE_READS * sizeof(uint64_t)) == hipSuccess &&
+                            hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {   // a half-made entry must not stay
+                if (b.h_planes) (void) hipHostFree(b.h_planes);
+                if (b.h_goff) (void) hipHostFree(b.h_goff);
+                if (b.done) (void) hipEventDestroy(b.done);
+                b = commet_ctx::IngestBuf();
+                (void) hipGetLastError();
+                return false;
+            }
+        }
         if (inflight[bi]) {
             if (hipEventSynchronize(b.done) != hipSuccess) return false;
             inflight[bi] = 0;
@@ -630,12 +640,19 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
                     (unsigned long long) rs->max_bases);
     HipPackSink sink;
     const int T = commet_host::ingest_threads();
+    static const bool verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    const auto tv0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count(); };
     if (!sink.prepare(rs, T)) return fail("cannot allocate the ingest staging buffers");
+    if (verbose) fprintf(stderr, "[ingest] staging ready      %8.1f ms\n", since());
     commet_host::PackSummary sm;
     std::string err;
     const bool ok = commet_host::ingest_arrays(bases, offsets, n_reads, rs->n_reads, rs->n_bases, T, sink, sm, err);
+    if (verbose) fprintf(stderr, "[ingest] packed + queued    %8.1f ms\n", since());
     // the staging buffers go back to the pool only once their copies are done
-    if (hipStreamSynchronize(rs->ctx->stream) != hipSuccess && ok) return fail("upload failed: %s", hipGetErrorString(hipGetLastError()));
+    const bool synced = hipStreamSynchronize(rs->ctx->stream) == hipSuccess;
+    if (verbose) fprintf(stderr, "[ingest] uploaded           %8.1f ms\n", since());
+    if (!synced && ok) return fail("upload failed: %s", hipGetErrorString(hipGetLastError()));
     if (!ok) return fail("%s", err.empty() ? "read set ingest failed" : err.c_str());
     absorb_summary(rs, sm);
     rs->n_reads += n_reads;
