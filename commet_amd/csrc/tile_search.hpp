@@ -384,19 +384,25 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         }
     __syncthreads();
     // A read that shares sequence with the index set has a lane-a bit on (nearly) every window of one strand; the
-    // reference leaves it after t hits, i.e. after ~4 t probes.  Such "heavy" reads (more than TQ_HEAVY candidates in one
-    // scan) keep their masks in registers and walk them themselves in step (3), stopping at t; probing all their windows in
-    // the balanced sweeps would multiply their probes by ten.
+    // reference leaves it after t hits, i.e. after ~4 t probes.  Such "heavy" scans (more than TQ_HEAVY candidates) keep
+    // their masks in registers and their thread walks them itself in step (3), stopping at t; probing all their windows
+    // in the balanced sweep would multiply their probes by ten.  The read's other scans (the other strand, the other
+    // chunk: a handful of chance candidates) stay in the sweep like anybody's.
     constexpr uint32_t TQ_HEAVY = 20;   // 4 / 12 / 18 / 24 / 32 / 40 -> 8.2 / 6.9 / 6.3 / 6.3 / 6.6 / 8.9 ms on configs[1]
     uint32_t am[NS][MW];
-    bool heavy = false;
+    uint32_t hv = 0;                    // bit i: scan i is heavy
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         uint32_t n = 0;
 #pragma unroll
         for (int h = 0; h < MW; ++h) am[i][h] = word_at(masks, i, h, threadIdx.x), n += __popc(am[i][h]);
-        heavy |= n > TQ_HEAVY;
+        if (n > TQ_HEAVY) {
+            hv |= 1u << i;
+#pragma unroll
+            for (int h = 0; h < MW; ++h) word_at(masks, i, h, threadIdx.x) = 0;   // (the sweep's first barrier comes before anyone else reads them)
+        }
     }
+    const bool heavy = hv != 0;
     // words of another read of the piece around window end q
     auto keys_of = [&](uint32_t owner, int strand, int q, uint32_t &ka, uint32_t &kb) {
         uint64_t t0;
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
         else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
     };
-    // one balanced sweep over the set bits of `src` (heavy reads excluded), four candidates per thread and round so that
+    // one balanced sweep over the set bits of `src` (heavy scans are not in it), four candidates per thread and round so that
     // four probes are in flight per lane: word_of(owner, scan, window end) -> {filter word address, bit} of the first plane
     // to test; on_set(owner, scan, mask word, bit, ka, kb) is called for the candidates whose bit is set
     auto sweep = [&](uint32_t *src, auto &&word_of, auto &&on_set) {
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
 #pragma unroll
         for (int i = 0; i < NS; ++i)
 #pragma unroll
-            for (int h = 0; h < MW; ++h) cnt += heavy ? 0u : __popc(word_at(src, i, h, threadIdx.x));
+            for (int h = 0; h < MW; ++h) cnt += __popc(word_at(src, i, h, threadIdx.x));
         uint32_t total;
         const uint32_t ex = block_scan<TQ_PIECE>(cnt, scan_ws, &total);
         pre[threadIdx.x] = ex + cnt;                      // inclusive
@@ -490,27 +496,35 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
               });
     }
     // (3) the reference's control flow (search_reads.h:45-83) on the full hits of this thread's read: per chunk, strand 0
-    // then strand 1; greedy non-overlapping hits; the windows behind the first-hit ones are probed one by one, and only
-    // for a scan that already has a hit (exact pruning, see search_kernel)
+    // then strand 1; greedy non-overlapping hits; the windows behind the first-hit ones are probed only for a scan that
+    // already has a hit (exact pruning, see search_kernel).  Those tails are fetched by the whole workgroup: the threads
+    // that need one post (read, first window end) in LDS, then thread p takes window p % 32 of request p / 32 — one
+    // round trip and ~50 instructions per window with every lane busy, where a thread fetching its own 32 windows
+    // (lane_a_bits32: a rolling window, four batches of eight loads) kept the other lanes of its wave waiting through
+    // ~1500 instructions and four round trips (1.8 ms of this kernel's 6.1 on configs[1]).
+    __shared__ uint32_t tail_req[TQ_PIECE], tail_bits[TQ_PIECE];
+    __shared__ uint32_t tail_n;
     int found_chunk = -1;
-    if (active && !(COMMET_TQ_ABLATE & (1024 | 8192))) {
-        uint64_t t0;
-        uint32_t len;
-        read_extent(rv, r, t0, len);
+    {
+        uint64_t t0 = 0;
+        uint32_t len = 0;
+        if (r < rv.n) read_extent(rv, r, t0, len);
         const uint32_t *p = rv.planes + 3 * t0;
         const int last = (int) len - 1;
         const int pe = last - (t - 1) * k;
         const int q0 = k - 1;
+        const bool scanning = active && !(COMMET_TQ_ABLATE & (1024 | 8192));
         bool found = false;
-        for (int i = 0; i < 2 * fg.g && !found; ++i) {
+        for (int i = 0; i < 2 * fg.g; ++i) {   // (uniform)
             const int strand = i & 1;
             const uint32_t *pb = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words;
             const uint32_t *pc = pb + fg.plane_words, *pd = pc + fg.plane_words;
             int seen = 0, next_ok = 0;
-            bool dead = false;
+            bool dead = !scanning || found;
             for (int h = 0; h < MW && !found && !dead; ++h) {
-                uint32_t m = pass[((i * MW) + h) * TQ_PIECE + threadIdx.x];    // light reads: full hits (step 2)
-                if (heavy) {                                                     // heavy reads: lane-a candidates, probed here
+                const bool hscan = (hv >> i) & 1u;
+                uint32_t m = pass[((i * MW) + h) * TQ_PIECE + threadIdx.x];    // light scans: full hits (step 2)
+                if (hscan) {                                                     // heavy scans: lane-a candidates, probed here
                     m = 0;
 #pragma unroll
                     for (int ii = 0; ii < NS; ++ii)
@@ -526,14 +540,14 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                         dead = true;
                         break;
                     }
-                    if (heavy) {
+                    if (hscan) {
                         ItemWords<uint32_t> it;
                         it.load(p, (uint32_t) q >> 5);
                         uint32_t wh, wl, ka, kb;
                         (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);
                         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
                         else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
-                        // three independent loads, one round trip: a heavy read's candidates are almost all true k-mers of the
+                        // three independent loads, one round trip: a heavy scan's candidates are almost all true k-mers of the
                         // index set, the short circuit b -> c -> d would only serialise them
                         const uint32_t vb = pb[kb >> 5], vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
                         if (!((vb >> (kb & 31u)) & (vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u)) continue;
@@ -546,10 +560,37 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                     }
                 }
             }
-            if (!found && !dead && seen >= 1 && !(COMMET_TQ_ABLATE & 32768) && !((COMMET_TQ_ABLATE & 65536) && heavy) && !((COMMET_TQ_ABLATE & 131072) && !heavy)) {   // windows behind the first-hit ones (lane_a_bits32)
-                for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TQ_TAIL_WIN) {
-                    if (qb + (t - seen - 1) * k > last) break;
-                    uint32_t m = lane_a_bits32<uint32_t>(p, len, qb, last, k, strand, fg.il_a, GS, i >> 1, TQ_TAIL_WIN);
+            // windows behind the first-hit ones, 32 at a time, for the scans that have a hit but not yet t of them
+            const bool tails_on = !(COMMET_TQ_ABLATE & 32768) && !((COMMET_TQ_ABLATE & 65536) && heavy) && !((COMMET_TQ_ABLATE & 131072) && !heavy);
+            for (int qb = max(pe + 1, next_ok);; qb += 32) {   // (uniform trip count: every thread takes part in the barriers)
+                const bool want = tails_on && !found && !dead && seen >= 1 && qb <= last && qb + (t - seen - 1) * k <= last;
+                if (threadIdx.x == 0) tail_n = 0;
+                if (!__syncthreads_or(want)) break;
+                if (want) {
+                    tail_req[atomicAdd(&tail_n, 1u)] = threadIdx.x | ((uint32_t) qb << 8);
+                    tail_bits[threadIdx.x] = 0;
+                }
+                __syncthreads();
+                const uint32_t n_pairs = tail_n * 32u;
+                for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += TQ_PIECE) {
+                    const uint32_t rq = tail_req[pr >> 5], owner = rq & 255u, w = pr & 31u;
+                    const int q = (int) (rq >> 8) + (int) w;
+                    uint64_t ot0;
+                    uint32_t olen;
+                    read_extent(rv, (uint64_t) blockIdx.x * TQ_PIECE + owner, ot0, olen);
+                    if (q >= (int) olen) continue;
+                    ItemWords<uint32_t> it;
+                    it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                    uint32_t wh, wl;
+                    if (!it.window((uint32_t) q & 31u, k, kmask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
+                    const uint32_t ka = strand ? (~wh & kmask) : (__brev(wh) >> sh);
+                    const uint32_t addr = psi_a<uint32_t>(ka, k);
+                    const uint32_t v = fg.il_a[(uint64_t) (addr >> 5) * GS + (uint32_t) (i >> 1)];
+                    if ((v >> (addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << w);
+                }
+                __syncthreads();
+                if (want) {
+                    uint32_t m = tail_bits[threadIdx.x];
                     while (m && !found) {
                         const int q = qb + (__ffs((int) m) - 1);
                         m &= m - 1u;
@@ -573,7 +614,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                     }
                 }
             }
-            if (found) found_chunk = i >> 1;
+            if (found && found_chunk < 0) found_chunk = i >> 1;
         }
     }
     const bool found = found_chunk >= 0;
