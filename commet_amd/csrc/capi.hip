@@ -1087,7 +1087,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
         if (grid >= (1ull << 24)) return fail("scatter launch too large");
         {
-            KScope ks(c, "part_scatter2_kernel", stream);
+            KScope ks(c, (g.packed && (1u << g.b2) <= S2P_MAX_SUB) ? "part_scatter2_packed_kernel" : "part_scatter2_kernel", stream);
             if (g.packed && (1u << g.b2) <= S2P_MAX_SUB)
                 hipLaunchKernelGGL(part_scatter2_packed_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, (uint2 *) ws.bufB,
                                    ws.off, g, ws.cur2, total);

@@ -74,6 +74,29 @@ __device__ __forceinline__ void set_bit(uint32_t *plane, W key)
                                  __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The (scanned, found) counters of a search launch: every wave adding its two popcounts to the same global words
+// serialises at L2 (milliseconds on a 10 M-read set), so the waves of a workgroup add into LDS first and the workgroup
+// adds once.  Every thread of the workgroup must call this (it holds barriers); wg_cnt: 2 * n_chunks words of LDS.
+__device__ __forceinline__ void add_chunk_counters(unsigned long long *__restrict__ counters, uint32_t cstride, int n_chunks,
+                                                   bool active, int found_chunk, unsigned int *wg_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 2u * (unsigned) n_chunks) wg_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // chunk i: scanned = active reads not found in an earlier chunk of the group, found = found in chunk i
+    for (int i = 0; i < n_chunks; ++i) {
+        const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
+        const uint64_t fd = __ballot(found_chunk == i);
+        if (lane == 0) {
+            if (sc) atomicAdd(&wg_cnt[2 * i], (unsigned int) __popcll(sc));
+            if (fd) atomicAdd(&wg_cnt[2 * i + 1], (unsigned int) __popcll(fd));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u * (unsigned) n_chunks && wg_cnt[threadIdx.x])
+        atomicAdd(&counters[(uint64_t) (threadIdx.x >> 1) * cstride + (threadIdx.x & 1u)], (unsigned long long) wg_cnt[threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------
 // Strand-paired layout of plane A.
 // The forward key of a window W is kf = bitreverse_k(W) and its reverse-complement
@@ -464,14 +487,13 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
         }
     }
     const uint64_t fb = __ballot(found);
-    const uint64_t ab = __ballot(active);
     if (lane == 0 && in_range) {
         if (tags) tags[word] = tagw | fb;
         if (found_out) found_out[word] = fb;
-        if (counters) {
-            if (ab) atomicAdd(&counters[0], (unsigned long long) __popcll(ab));
-            if (fb) atomicAdd(&counters[1], (unsigned long long) __popcll(fb));
-        }
+    }
+    if (counters) {
+        __shared__ unsigned int wg_cnt[2];
+        add_chunk_counters(counters, 0, 1, active, found ? 0 : -1, wg_cnt);
     }
     if (COUNT && probe_counter) {
         for (int o = 32; o > 0; o >>= 1) probes += __shfl_down(probes, o, 64);
@@ -784,15 +806,8 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
     const uint64_t fb = __ballot(found);
     if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
     if (counters) {
-        // chunk i: scanned = active reads not found in an earlier chunk of the group, found = found in chunk i
-        for (int i = 0; i < fg.g; ++i) {
-            const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
-            const uint64_t fd = __ballot(found_chunk == i);
-            if (lane == 0) {
-                if (sc) atomicAdd(&counters[(uint64_t) i * cstride + 0], (unsigned long long) __popcll(sc));
-                if (fd) atomicAdd(&counters[(uint64_t) i * cstride + 1], (unsigned long long) __popcll(fd));
-            }
-        }
+        __shared__ unsigned int wg_cnt[2 * GS];
+        add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);
     }
     if (COUNT && probe_counter) {
         for (int o = 32; o > 0; o >>= 1) probes += __shfl_down(probes, o, 64);
@@ -949,14 +964,8 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
     const uint64_t fb = __ballot(found);
     if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
     if (counters) {
-        for (int i = 0; i < fg.g; ++i) {
-            const uint64_t sc = __ballot(active && (found_chunk < 0 || found_chunk >= i));
-            const uint64_t fd = __ballot(found_chunk == i);
-            if (lane == 0) {
-                if (sc) atomicAdd(&counters[(uint64_t) i * cstride + 0], (unsigned long long) __popcll(sc));
-                if (fd) atomicAdd(&counters[(uint64_t) i * cstride + 1], (unsigned long long) __popcll(fd));
-            }
-        }
+        __shared__ unsigned int wg_cnt[2 * GS];
+        add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);
     }
 }
 
