@@ -502,56 +502,15 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 }
 
 // ---------------------------------------------------------------------------
-constexpr int TAIL_WIN = 8;   // windows behind the first-hit ones are fetched this many at a time: the scan usually ends at
-                              // the first of them that hits, and every extra probe is an L2 miss (what these kernels are bound by)
-
-// Lane-a bits of up to n_win <= 32 consecutive windows of one strand, fetched with INDEPENDENT loads (eight in flight at a time):
-// bit j of the result = the complete window ending at q_lo + j (q_lo + j <= q_hi) has its lane-a bit set in the A plane
-// `plane_a` (words interleaved with stride `stride`, this chunk at offset `ci`).  Used for the windows behind the first-
-// hit ones: a scan that already has a hit needs them, and probing them one after the other (load, test, next window)
-// puts up to (t - 1) * k dependent HBM round trips into the wave — measured 8.6 ms of a 10.2 ms kernel on configs[1].
-// ---------------------------------------------------------------------------
-template <typename W>
-__device__ __forceinline__ uint32_t lane_a_bits32(const uint32_t *__restrict__ p, uint32_t len, int q_lo, int q_hi, int k, int strand,
-                                                  const uint32_t *__restrict__ plane_a, int stride, int ci, int n_win = 32)
-{
-    using T = KeyTraits<W>;
-    const int sh = T::BITS - k;
-    const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
-    q_hi = min(q_hi, min(q_lo + n_win - 1, (int) len - 1));
-    if (q_hi < q_lo) return 0u;
-    // roll up to q_lo - 1 (the k - 1 bases before the first window are enough)
-    W wh = 0;
-    uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
-    auto roll = [&](int pos) {
-        const uint32_t w = (uint32_t) pos >> 5, j = (uint32_t) pos & 31u;
-        if (w != cw) hi = p[3 * w], va = p[3 * w + 2], cw = w;
-        wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
-        run = ((va >> j) & 1u) ? run + 1 : 0;
-    };
-    for (int pos = max(0, q_lo - (k - 1)); pos < q_lo; ++pos) roll(pos);
-    uint32_t bits = 0;
-    for (int q0 = q_lo; q0 <= q_hi; q0 += 8) {
-        uint32_t v[8], b[8];
-        bool on[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            on[u] = false, v[u] = 0, b[u] = 0;
-            if (q0 + u > q_hi) continue;
-            roll(q0 + u);
-            if (run < (uint32_t) k) continue;
-            const W ka = strand ? (W) (~wh & mask) : (W) (T::brev(wh) >> sh);
-            const W addr = psi_a<W>(ka, k);
-            on[u] = true, b[u] = (uint32_t) addr & 31u;
-            v[u] = plane_a[(uint64_t) (addr >> 5) * stride + ci];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (on[u]) bits |= ((v[u] >> b[u]) & 1u) << (q0 + u - q_lo);
-    }
-    return bits;
-}
-
+// windows per request of a cooperative tail fetch (powers of two <= 32).  More per request wastes L2 misses behind the hit
+// that ends the scan; fewer costs round trips.  search_group_kernel on configs[1]: 4 / 8 / 16 / 32 -> 9.29 / 9.25 / 9.25 / 9.37 ms
+// (9.39-9.65 with per-thread tails); search_group8_kernel on a 2 x 50 M-read pair: 8 / 16 / 32 -> 127 / 120.5 / 118.3 ms (136.6).
+#ifndef GROUP_TAIL_WIN
+#define GROUP_TAIL_WIN 16
+#endif
+#ifndef GROUP8_TAIL_WIN
+#define GROUP8_TAIL_WIN 32
+#endif
 // ---------------------------------------------------------------------------
 // search against a GROUP of chunk filters in one pass over the reads.
 // The reference re-scans the search set once per index chunk (index_and_search.cpp:
@@ -618,24 +577,25 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
     bool found = false;
     int found_chunk = -1;
     uint32_t probes = 0;
+    uint64_t t0 = 0;
+    uint32_t len = 0;
+    if (r < rv.n) read_extent(rv, r, t0, len);
+    const uint32_t *p = rv.planes + 3 * t0;
+    const int sh = T::BITS - k;
+    const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+    const bool staged = rw_nw && !COUNT;
+    auto getw = [&](uint32_t i) -> uint32_t { return staged ? rw[i * 256u + threadIdx.x] : p[i]; };
+    // Pruning (exact, see search_kernel): with `seen` hits a window ending at q matters only if
+    // q + (t-seen-1)*k <= len-1.  The gather therefore covers the windows that can be a FIRST hit,
+    // q <= pe = len-1-(t-1)*k (all of them in COUNT builds); later windows are needed only after a real
+    // 4-lane hit and are then fetched by the whole workgroup (below) or, in COUNT builds, one by one in the replay.
+    const int last = (int) len - 1;
+    const int pe = COUNT ? last : last - (t - 1) * k;
     if (active) {
-        uint64_t t0;
-        uint32_t len;
-        read_extent(rv, r, t0, len);
-        const uint32_t *p = rv.planes + 3 * t0;
-        const int sh = T::BITS - k;
-        const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
-        if (rw_nw && !COUNT) {
+        if (staged) {
             const uint32_t n3 = 3u * ((len + 31u) >> 5);
             for (uint32_t i = 0; i < n3; ++i) rw[i * 256u + threadIdx.x] = p[i];
         }
-        auto getw = [&](uint32_t i) -> uint32_t { return (rw_nw && !COUNT) ? rw[i * 256u + threadIdx.x] : p[i]; };
-        // Pruning (exact, see search_kernel): with `seen` hits a window ending at q matters only if
-        // q + (t-seen-1)*k <= len-1.  The gather therefore covers the windows that can be a FIRST hit,
-        // q <= pe = len-1-(t-1)*k (all of them in COUNT builds); later windows are needed only after a real
-        // 4-lane hit and are then probed one by one in the replay.
-        const int last = (int) len - 1;
-        const int pe = COUNT ? last : last - (t - 1) * k;
         // (1) gather: lane-a bits of the complete windows ending at or before pe, all chunks, both strands
         {
             W wh = 0;
@@ -673,78 +633,114 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                 }
             }
         }
-        // (2) replay the reference control flow per chunk (search_reads.h:45-83)
-        for (int i = 0; i < fg.g && !found; ++i) {
+    }
+    if constexpr (!COUNT) {
+        // (2) Sparse replay of the reference control flow per chunk (search_reads.h:45-83): the reference probes a window
+        // iff its k bases are ACGT (that is what a gathered mask bit stands on) and it ends at least k bases after the
+        // strand's last full hit.  A window whose lane-a bit is clear can never be a hit, so only the set mask bits are
+        // visited, in order, with that rule; their keys come straight from the read's words (no rolling over the bases
+        // in between).  Every thread walks the loops (the ones without work only for the barriers of the tails).
+        __shared__ uint32_t tail_req[256], tail_bits[256];
+        __shared__ uint32_t tail_n;
+        for (int i = 0; i < fg.g; ++i) {   // (uniform)
             const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
             const uint32_t *pc = pb + fg.plane_words;
             const uint32_t *pd = pc + fg.plane_words;
-            if constexpr (!COUNT) {
-                // Sparse replay: the reference probes a window iff its k bases are ACGT (that is what a gathered mask
-                // bit stands on) and it ends at least k bases after the strand's last full hit.  A window whose lane-a
-                // bit is clear can never be a hit, so only the set mask bits are visited, in order, with that rule;
-                // their keys come straight from the read's words (no rolling over the bases in between).
-                for (int strand = 0; strand < 2 && !found; ++strand) {
-                    int seen = 0, next_ok = 0;
-                    bool dead = false;
-                    auto probe_bcd = [&](W wh, W wl) -> bool {
-                        W ka, kb;
-                        if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
-                        else ka = ~wh & mask, kb = ~wl & mask;
-                        return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
-                    };
-                    for (uint32_t w = 0; (int) (w * 32u) <= pe && !found && !dead; ++w) {
-                        uint32_t m = mask_at(i, strand, w);
-                        if (!m) continue;
+            for (int strand = 0; strand < 2; ++strand) {
+                int seen = 0, next_ok = 0;
+                bool dead = !active || found;
+                auto probe_bcd = [&](W wh, W wl) -> bool {
+                    W ka, kb;
+                    if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                    else ka = ~wh & mask, kb = ~wl & mask;
+                    return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
+                };
+                for (uint32_t w = 0; (int) (w * 32u) <= pe && !found && !dead; ++w) {
+                    uint32_t m = mask_at(i, strand, w);
+                    if (!m) continue;
+                    ItemWords<W> it;
+                    it.load_with(getw, w);
+                    while (m && !found) {
+                        const uint32_t j = (uint32_t) __ffs((int) m) - 1u;
+                        m &= m - 1u;
+                        const int q = (int) (32u * w + j);
+                        if (q < next_ok) continue;
+                        if (q + (t - seen - 1) * k > last) {
+                            dead = true;
+                            break;
+                        }
+                        W wh, wl;
+                        (void) it.window(j, k, mask, wh, wl);   // valid: the gather saw a complete window here
+                        if (probe_bcd(wh, wl)) {
+                            ++seen;
+                            next_ok = q + k;
+                            if (seen >= t) found = true;
+                        }
+                    }
+                }
+                // Windows behind the gathered ones matter only after a first full hit (pruning, see above).  Their lane-a
+                // bits are fetched by the whole workgroup, GROUP_TAIL_WIN windows per request: the threads that need a tail
+                // post (read, first window end), thread p takes window p % GROUP_TAIL_WIN of request p / GROUP_TAIL_WIN —
+                // one round trip with every lane busy (see tq_replay_kernel); then only the set ones are probed.
+                for (int qb = max(pe + 1, next_ok);; qb += GROUP_TAIL_WIN) {   // (uniform trip count)
+                    const bool want = !found && !dead && seen >= 1 && qb <= last && qb + (t - seen - 1) * k <= last;
+                    if (threadIdx.x == 0) tail_n = 0;
+                    if (!__syncthreads_or(want)) break;
+                    if (want) {
+                        tail_req[atomicAdd(&tail_n, 1u)] = threadIdx.x | ((uint32_t) qb << 8);
+                        tail_bits[threadIdx.x] = 0;
+                    }
+                    __syncthreads();
+                    const uint32_t n_pairs = tail_n * (uint32_t) GROUP_TAIL_WIN;
+                    for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += 256) {
+                        const uint32_t rq = tail_req[pr / GROUP_TAIL_WIN], owner = rq & 255u, wi = pr % GROUP_TAIL_WIN;
+                        const int q = (int) (rq >> 8) + (int) wi;
+                        uint64_t ot0;
+                        uint32_t olen;
+                        read_extent(rv, blockIdx.x * 256ull + owner, ot0, olen);
+                        if (q >= (int) olen) continue;
+                        const uint32_t *op = rv.planes + 3 * ot0;
                         ItemWords<W> it;
-                        it.load_with(getw, w);
+                        it.load_with([&](uint32_t x) -> uint32_t { return staged ? rw[x * 256u + owner] : op[x]; }, (uint32_t) q >> 5);
+                        W wh, wl;
+                        if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
+                        const W ka = strand ? (W) (~wh & mask) : (W) (T::brev(wh) >> sh);
+                        const W addr = psi_a<W>(ka, k);
+                        const uint32_t v = fg.il_a[(uint64_t) (addr >> 5) * GS + i];
+                        if ((v >> ((uint32_t) addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << wi);
+                    }
+                    __syncthreads();
+                    if (want) {
+                        uint32_t m = tail_bits[threadIdx.x];
                         while (m && !found) {
-                            const uint32_t j = (uint32_t) __ffs((int) m) - 1u;
+                            const int q = qb + (__ffs((int) m) - 1);
                             m &= m - 1u;
-                            const int q = (int) (32u * w + j);
                             if (q < next_ok) continue;
                             if (q + (t - seen - 1) * k > last) {
                                 dead = true;
                                 break;
                             }
+                            ItemWords<W> it;
+                            it.load_with(getw, (uint32_t) q >> 5);
                             W wh, wl;
-                            (void) it.window(j, k, mask, wh, wl);   // valid: the gather saw a complete window here
+                            (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
                             if (probe_bcd(wh, wl)) {
                                 ++seen;
-                                next_ok = q + k;
+                                next_ok = q + k;   // the next complete window ends k bases later
                                 if (seen >= t) found = true;
                             }
                         }
                     }
-                    // windows behind the gathered ones matter only after a first full hit (pruning, see above); their lane-a
-                    // bits come 32 windows at a time with independent loads (lane_a_bits32), then only the set ones are probed
-                    if (!found && !dead && seen >= 1) {
-                        for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TAIL_WIN) {
-                            if (qb + (t - seen - 1) * k > last) break;
-                            uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i, TAIL_WIN);
-                            while (m && !found) {
-                                const int q = qb + (__ffs((int) m) - 1);
-                                m &= m - 1u;
-                                if (q < next_ok) continue;
-                                if (q + (t - seen - 1) * k > last) {
-                                    dead = true;
-                                    break;
-                                }
-                                ItemWords<W> it;
-                                it.load_with(getw, (uint32_t) q >> 5);
-                                W wh, wl;
-                                (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
-                                if (probe_bcd(wh, wl)) {
-                                    ++seen;
-                                    next_ok = q + k;   // the next complete window ends k bases later
-                                    if (seen >= t) found = true;
-                                }
-                            }
-                        }
-                    }
                 }
-                if (found) found_chunk = i;
-                continue;
             }
+            if (found && found_chunk < 0) found_chunk = i;
+        }
+    } else if (active) {
+        // (2, COUNT builds) the reference's walk base by base, every probe counted
+        for (int i = 0; i < fg.g && !found; ++i) {
+            const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
+            const uint32_t *pc = pb + fg.plane_words;
+            const uint32_t *pd = pc + fg.plane_words;
             for (int strand = 0; strand < 2 && !found; ++strand) {
                 W wh = 0, wl = 0;
                 uint32_t run = 0;
@@ -830,6 +826,10 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
 {
     using T = KeyTraits<W>;
     constexpr int GS = 8;
+    // tails (the windows behind the first-hit ones, for a scan that has a hit but not yet t of them) are fetched by the
+    // whole workgroup: see tq_replay_kernel (tile_search.hpp), where doing so took 1.8 ms of tails to 1.1
+    __shared__ uint32_t tail_req[256], tail_bits[256];
+    __shared__ uint32_t tail_n;
     const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
@@ -842,81 +842,129 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
     bool found = false;
     int found_chunk = -1;
+    uint64_t t0 = 0;
+    uint32_t len = 0;
+    if (r < rv.n) read_extent(rv, r, t0, len);
+    const uint32_t *p = rv.planes + 3 * t0;
+    const int sh = T::BITS - k;
+    const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
+    const int last = (int) len - 1;
+    const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW
+    const int q0 = k - 1;
+    uint32_t fm[MW][GS], rm[MW][GS];       // [word of the 32 * MW relative positions][filter]
+#pragma unroll
+    for (int h = 0; h < MW; ++h)
+#pragma unroll
+        for (int i = 0; i < GS; ++i) fm[h][i] = 0, rm[h][i] = 0;
+    // (1) gather
     if (active) {
-        uint64_t t0;
-        uint32_t len;
-        read_extent(rv, r, t0, len);
-        const uint32_t *p = rv.planes + 3 * t0;
-        const int sh = T::BITS - k;
-        const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
-        const int last = (int) len - 1;
-        const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW
-        const int q0 = k - 1;
-        uint32_t fm[MW][GS], rm[MW][GS];       // [word of the 32 * MW relative positions][filter]
+        W wh = 0;
+        uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
+        auto roll = [&](int pos) {
+            const uint32_t w = (uint32_t) pos >> 5, j = (uint32_t) pos & 31u;
+            if (w != cw) hi = p[3 * w], va = p[3 * w + 2], cw = w;
+            wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+            run = ((va >> j) & 1u) ? run + 1 : 0;
+        };
+        for (int pos = 0; pos < q0 && pos <= pe; ++pos) roll(pos);
 #pragma unroll
-        for (int h = 0; h < MW; ++h)
+        for (int h = 0; h < MW; ++h) {
+            for (int jj = 0; jj < 32; ++jj) {
+                const int q = q0 + 32 * h + jj;
+                if (q > pe) break;
+                roll(q);
+                if (run >= (uint32_t) k) {
+                    bool selfp;
+                    const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
+                    const uint32_t *src = fg.il_a + (uint64_t) (addr >> 5) * GS;
+                    const uint4 v = *(const uint4 *) src, u = *(const uint4 *) (src + 4);
+                    const uint32_t x[GS] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
+                    const uint32_t bit = (uint32_t) addr & 31u;
 #pragma unroll
-            for (int i = 0; i < GS; ++i) fm[h][i] = 0, rm[h][i] = 0;
-        // (1) gather
-        {
-            W wh = 0;
-            uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
-            auto roll = [&](int pos) {
-                const uint32_t w = (uint32_t) pos >> 5, j = (uint32_t) pos & 31u;
-                if (w != cw) hi = p[3 * w], va = p[3 * w + 2], cw = w;
-                wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
-                run = ((va >> j) & 1u) ? run + 1 : 0;
-            };
-            for (int pos = 0; pos < q0 && pos <= pe; ++pos) roll(pos);
-#pragma unroll
-            for (int h = 0; h < MW; ++h) {
-                for (int jj = 0; jj < 32; ++jj) {
-                    const int q = q0 + 32 * h + jj;
-                    if (q > pe) break;
-                    roll(q);
-                    if (run >= (uint32_t) k) {
-                        bool selfp;
-                        const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
-                        const uint32_t *src = fg.il_a + (uint64_t) (addr >> 5) * GS;
-                        const uint4 v = *(const uint4 *) src, u = *(const uint4 *) (src + 4);
-                        const uint32_t x[GS] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
-                        const uint32_t bit = (uint32_t) addr & 31u;
-#pragma unroll
-                        for (int i = 0; i < GS; ++i) {
-                            const uint32_t fb = (x[i] >> bit) & 1u;
-                            const uint32_t rb = selfp ? fb : ((x[i] >> (bit ^ 1u)) & 1u);
-                            fm[h][i] |= fb << jj;
-                            rm[h][i] |= rb << jj;
-                        }
+                    for (int i = 0; i < GS; ++i) {
+                        const uint32_t fb = (x[i] >> bit) & 1u;
+                        const uint32_t rb = selfp ? fb : ((x[i] >> (bit ^ 1u)) & 1u);
+                        fm[h][i] |= fb << jj;
+                        rm[h][i] |= rb << jj;
                     }
                 }
             }
         }
-        // (2) sparse replay, filter by filter (unrolled: the masks are registers)
+    }
+    // (2) sparse replay, filter by filter (unrolled: the masks are registers); every thread walks the loop, the ones without
+    // work only for its barriers
 #pragma unroll
-        for (int i = 0; i < GS; ++i) {
-            if (i >= fg.g || found) continue;
-            const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
-            const uint32_t *pc = pb + fg.plane_words;
-            const uint32_t *pd = pc + fg.plane_words;
+    for (int i = 0; i < GS; ++i) {
+        if (i >= fg.g) continue;   // (uniform)
+        const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
+        const uint32_t *pc = pb + fg.plane_words;
+        const uint32_t *pd = pc + fg.plane_words;
 #pragma unroll
-            for (int strand = 0; strand < 2; ++strand) {
-                if (found) continue;
-                int seen = 0, next_ok = 0;
-                bool dead = false;
-                auto probe_bcd = [&](W wh, W wl) -> bool {
-                    W ka, kb;
-                    if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
-                    else ka = ~wh & mask, kb = ~wl & mask;
-                    return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
-                };
+        for (int strand = 0; strand < 2; ++strand) {
+            int seen = 0, next_ok = 0;
+            bool dead = !active || found;
+            auto probe_bcd = [&](W wh, W wl) -> bool {
+                W ka, kb;
+                if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
+                else ka = ~wh & mask, kb = ~wl & mask;
+                return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
+            };
 #pragma unroll
-                for (int h = 0; h < MW; ++h) {
-                    uint32_t m = strand ? rm[h][i] : fm[h][i];
-                    while (m && !found && !dead) {
-                        const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;
+            for (int h = 0; h < MW; ++h) {
+                uint32_t m = strand ? rm[h][i] : fm[h][i];
+                while (m && !found && !dead) {
+                    const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;
+                    m &= m - 1u;
+                    const int q = q0 + 32 * h + (int) jj;
+                    if (q < next_ok) continue;
+                    if (q + (t - seen - 1) * k > last) {
+                        dead = true;
+                        break;
+                    }
+                    ItemWords<W> it;
+                    it.load(p, (uint32_t) q >> 5);
+                    W wh, wl;
+                    (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
+                    if (probe_bcd(wh, wl)) {
+                        ++seen;
+                        next_ok = q + k;
+                        if (seen >= t) found = true;
+                    }
+                }
+            }
+            // windows behind the gathered ones, after a first full hit only, GROUP8_TAIL_WIN at a time
+            for (int qb = max(pe + 1, next_ok);; qb += GROUP8_TAIL_WIN) {   // (uniform trip count: every thread takes part in the barriers)
+                const bool want = !found && !dead && seen >= 1 && qb <= last && qb + (t - seen - 1) * k <= last;
+                if (threadIdx.x == 0) tail_n = 0;
+                if (!__syncthreads_or(want)) break;
+                if (want) {
+                    tail_req[atomicAdd(&tail_n, 1u)] = threadIdx.x | ((uint32_t) qb << 8);
+                    tail_bits[threadIdx.x] = 0;
+                }
+                __syncthreads();
+                const uint32_t n_pairs = tail_n * (uint32_t) GROUP8_TAIL_WIN;
+                for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += 256) {
+                    const uint32_t rq = tail_req[pr / GROUP8_TAIL_WIN], owner = rq & 255u, w = pr % GROUP8_TAIL_WIN;
+                    const int q = (int) (rq >> 8) + (int) w;
+                    uint64_t ot0;
+                    uint32_t olen;
+                    read_extent(rv, blockIdx.x * 256ull + owner, ot0, olen);
+                    if (q >= (int) olen) continue;
+                    ItemWords<W> it;
+                    it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                    W wh, wl;
+                    if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
+                    const W ka = strand ? (W) (~wh & mask) : (W) (T::brev(wh) >> sh);
+                    const W addr = psi_a<W>(ka, k);
+                    const uint32_t v = fg.il_a[(uint64_t) (addr >> 5) * GS + i];
+                    if ((v >> ((uint32_t) addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << w);
+                }
+                __syncthreads();
+                if (want) {
+                    uint32_t m = tail_bits[threadIdx.x];
+                    while (m && !found) {
+                        const int q = qb + (__ffs((int) m) - 1);
                         m &= m - 1u;
-                        const int q = q0 + 32 * h + (int) jj;
                         if (q < next_ok) continue;
                         if (q + (t - seen - 1) * k > last) {
                             dead = true;
@@ -933,33 +981,9 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                         }
                     }
                 }
-                if (!found && !dead && seen >= 1) {   // windows behind the gathered ones, after a first full hit only (lane_a_bits32)
-                    for (int qb = max(pe + 1, next_ok); qb <= last && !found && !dead; qb += TAIL_WIN) {
-                        if (qb + (t - seen - 1) * k > last) break;
-                        uint32_t m = lane_a_bits32<W>(p, len, qb, last, k, strand, fg.il_a, GS, i, TAIL_WIN);
-                        while (m && !found) {
-                            const int q = qb + (__ffs((int) m) - 1);
-                            m &= m - 1u;
-                            if (q < next_ok) continue;
-                            if (q + (t - seen - 1) * k > last) {
-                                dead = true;
-                                break;
-                            }
-                            ItemWords<W> it;
-                            it.load(p, (uint32_t) q >> 5);
-                            W wh, wl;
-                            (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
-                            if (probe_bcd(wh, wl)) {
-                                ++seen;
-                                next_ok = q + k;
-                                if (seen >= t) found = true;
-                            }
-                        }
-                    }
-                }
             }
-            if (found && found_chunk < 0) found_chunk = i;
         }
+        if (found && found_chunk < 0) found_chunk = i;
     }
     const uint64_t fb = __ballot(found);
     if (lane == 0 && in_range && tags) tags[word] = tagw | fb;

@@ -33,8 +33,6 @@
 namespace commet {
 
 constexpr uint32_t TQ_PIECE = 256;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
-constexpr int      TQ_TAIL_WIN = 32;      // tail windows per batch of lane-a probes (the fused kernels take 8: fewer misses; here the
-                                          // replay has no gathers to hide the round trips behind, and 32 measured faster: 6.9 vs 7.3 ms)
 constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
 
 struct QueryListView {
@@ -500,7 +498,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
     // already has a hit (exact pruning, see search_kernel).  Those tails are fetched by the whole workgroup: the threads
     // that need one post (read, first window end) in LDS, then thread p takes window p % 32 of request p / 32 — one
     // round trip and ~50 instructions per window with every lane busy, where a thread fetching its own 32 windows
-    // (lane_a_bits32: a rolling window, four batches of eight loads) kept the other lanes of its wave waiting through
+    // (a rolling window, four batches of eight loads) kept the other lanes of its wave waiting through
     // ~1500 instructions and four round trips (1.8 ms of this kernel's 6.1 on configs[1]).
     __shared__ uint32_t tail_req[TQ_PIECE], tail_bits[TQ_PIECE];
     __shared__ uint32_t tail_n;

@@ -1,9 +1,9 @@
 # one rocprofv3 counter pass of a single bench step on the GPU box, summed per kernel:
-#   bash tools/pmc_pass.sh <name> COUNTER [COUNTER ...]      -> gpurun_out/<name>.csv (+ a table on stdout)
+#   [BENCH_ARGS="--reads 50000000"] bash tools/pmc_pass.sh <name> COUNTER [COUNTER ...]      -> gpurun_out/<name>.csv (+ a table on stdout)
 R=$GRAFT_REPO_ROOT
 N=$1; shift
 cd /tmp && export TMPDIR=/tmp
-COMMET_INDEX_LANES=1 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pp_$N -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix > /tmp/pp_$N.log 2>&1 || { tail -20 /tmp/pp_$N.log; exit 1; }
+COMMET_INDEX_LANES=1 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pp_$N -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix $BENCH_ARGS > /tmp/pp_$N.log 2>&1 || { tail -20 /tmp/pp_$N.log; exit 1; }
 cp $(find /tmp/pp_$N -name "*counter_collection.csv" | head -1) $R/gpurun_out/$N.csv
 python3 - $R/gpurun_out/$N.csv <<'P'
 import csv, sys, collections
