@@ -80,7 +80,19 @@ class Ranks:
                 import datetime
                 # a rank that dies must not leave the others waiting for long (default 30 min)
                 tmo = datetime.timedelta(seconds=float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600")))
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=tmo)
+                # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): keep them out of a
+                # caller's result stream (bench.py prints one JSON line there) by lending fd 1 to stderr meanwhile
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                try:
+                    os.dup2(2, 1)
+                    dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=tmo)
+                    dist.barrier()          # the connections are made (and announced) at the first collective
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
             self.dist = dist
 
     def barrier(self):
