@@ -508,6 +508,12 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 #ifndef GROUP_TAIL_WIN
 #define GROUP_TAIL_WIN 16
 #endif
+#ifndef GROUP8_ABLATE
+#define GROUP8_ABLATE 0   // timing ablations (wrong results): 1 no replay, 2 no tails
+#endif
+#ifndef G8_HEAVY
+#define G8_HEAVY 20   // (8 / 12 / 16 / 20 / 24 / 28: 140 / 130 / 105 / 104 / 101 / 104 ms on a 2 x 50 M-read pair) search_group8_kernel: a scan with more lane-a candidates than this walks them itself
+#endif
 #ifndef GROUP8_TAIL_WIN
 #define GROUP8_TAIL_WIN 32
 #endif
@@ -830,6 +836,10 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
     // whole workgroup: see tq_replay_kernel (tile_search.hpp), where doing so took 1.8 ms of tails to 1.1
     __shared__ uint32_t tail_req[256], tail_bits[256];
     __shared__ uint32_t tail_n;
+    // the first-hit candidates of a scan are probed by the whole workgroup as well (see (2) below)
+    __shared__ uint32_t cand[256 * G8_HEAVY];
+    __shared__ uint32_t full_hit[MW][256];
+    __shared__ uint32_t cand_n;
     const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
@@ -893,6 +903,14 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
     }
     // (2) sparse replay, filter by filter (unrolled: the masks are registers); every thread walks the loop, the ones without
     // work only for its barriers
+    if (GROUP8_ABLATE & 1) {   // keep the gather alive
+        uint32_t n = 0;
+#pragma unroll
+        for (int h = 0; h < MW; ++h)
+#pragma unroll
+            for (int i = 0; i < GS; ++i) n += __popc(fm[h][i]) + 3 * __popc(rm[h][i]);
+        if (n == (uint32_t) t) found = true;   // (never with the t the bench uses... wrong results anyway)
+    }
 #pragma unroll
     for (int i = 0; i < GS; ++i) {
         if (i >= fg.g) continue;   // (uniform)
@@ -902,16 +920,73 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
 #pragma unroll
         for (int strand = 0; strand < 2; ++strand) {
             int seen = 0, next_ok = 0;
-            bool dead = !active || found;
+            bool dead = !active || found || (GROUP8_ABLATE & 1);
             auto probe_bcd = [&](W wh, W wl) -> bool {
                 W ka, kb;
                 if (strand == 0) ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
                 else ka = ~wh & mask, kb = ~wl & mask;
                 return test_bit<W>(pb, kb) && test_bit<W>(pc, ka ^ kb) && test_bit<W>(pd, ka | kb);
             };
+            // The scan's lane-a candidates (~3 of a read that shares nothing with the chunk, a different number in every
+            // lane) are posted in LDS and dealt out evenly: thread p probes candidate p, p + 256, ... through planes B, C, D
+            // and marks the full hits in full_hit[]; walking them per thread kept a wave in as many dependent round trips as
+            // its busiest lane has candidates.  A scan with more than G8_HEAVY candidates is a read that shares sequence
+            // with the chunk: it walks its own candidates and stops at t hits, as the reference does.
+            uint32_t mm[MW], ncand = 0;
+#pragma unroll
+            for (int h = 0; h < MW; ++h) mm[h] = dead ? 0u : (strand ? rm[h][i] : fm[h][i]), ncand += __popc(mm[h]);
+            const bool self = ncand > G8_HEAVY;
+            if (threadIdx.x == 0) cand_n = 0;
+#pragma unroll
+            for (int h = 0; h < MW; ++h) full_hit[h][threadIdx.x] = 0;
+            __syncthreads();
+            if (!self && ncand) {
+                uint32_t at = atomicAdd(&cand_n, ncand);   // <= 256 * G8_HEAVY in all
+#pragma unroll
+                for (int h = 0; h < MW; ++h)
+                    for (uint32_t m = mm[h]; m; m &= m - 1u) cand[at++] = threadIdx.x | ((32u * h + (uint32_t) __ffs((int) m) - 1u) << 8);
+            }
+            __syncthreads();
+            {
+                const uint32_t n_cand = cand_n;
+                constexpr int U = 2;   // candidates per thread and round: their probes are in flight together (1 / 2 / 4: no difference)
+                for (uint32_t c0 = threadIdx.x; c0 < n_cand; c0 += U * 256) {
+                    uint32_t owner[U], wq[U], vb[U];
+                    W ka[U], kb[U];
+                    bool have[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t ci = c0 + (uint32_t) u * 256u;
+                        have[u] = ci < n_cand;
+                        owner[u] = 0, wq[u] = 0, vb[u] = 0, ka[u] = 0, kb[u] = 0;
+                        if (!have[u]) continue;
+                        const uint32_t e = cand[ci];
+                        owner[u] = e & 255u, wq[u] = e >> 8;
+                        const int q = q0 + (int) wq[u];
+                        uint64_t ot0;
+                        uint32_t olen;
+                        read_extent(rv, blockIdx.x * 256ull + owner[u], ot0, olen);
+                        ItemWords<W> it;
+                        it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                        W wh, wl;
+                        (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);   // complete: the gather saw it
+                        if (strand == 0) ka[u] = T::brev(wh) >> sh, kb[u] = T::brev(wl) >> sh;
+                        else ka[u] = ~wh & mask, kb[u] = ~wl & mask;
+                        vb[u] = pb[kb[u] >> 5];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!have[u] || !((vb[u] >> ((uint32_t) kb[u] & 31u)) & 1u)) continue;
+                        const W kc = ka[u] ^ kb[u], kd = ka[u] | kb[u];
+                        const uint32_t vc = pc[kc >> 5], vd = pd[kd >> 5];
+                        if ((vc >> ((uint32_t) kc & 31u)) & (vd >> ((uint32_t) kd & 31u)) & 1u) atomicOr(&full_hit[wq[u] >> 5][owner[u]], 1u << (wq[u] & 31u));
+                    }
+                }
+            }
+            __syncthreads();
 #pragma unroll
             for (int h = 0; h < MW; ++h) {
-                uint32_t m = strand ? rm[h][i] : fm[h][i];
+                uint32_t m = self ? mm[h] : full_hit[h][threadIdx.x];
                 while (m && !found && !dead) {
                     const uint32_t jj = (uint32_t) __ffs((int) m) - 1u;
                     m &= m - 1u;
@@ -921,20 +996,21 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                         dead = true;
                         break;
                     }
-                    ItemWords<W> it;
-                    it.load(p, (uint32_t) q >> 5);
-                    W wh, wl;
-                    (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
-                    if (probe_bcd(wh, wl)) {
-                        ++seen;
-                        next_ok = q + k;
-                        if (seen >= t) found = true;
+                    if (self) {
+                        ItemWords<W> it;
+                        it.load(p, (uint32_t) q >> 5);
+                        W wh, wl;
+                        (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);
+                        if (!probe_bcd(wh, wl)) continue;
                     }
+                    ++seen;
+                    next_ok = q + k;
+                    if (seen >= t) found = true;
                 }
             }
             // windows behind the gathered ones, after a first full hit only, GROUP8_TAIL_WIN at a time
             for (int qb = max(pe + 1, next_ok);; qb += GROUP8_TAIL_WIN) {   // (uniform trip count: every thread takes part in the barriers)
-                const bool want = !found && !dead && seen >= 1 && qb <= last && qb + (t - seen - 1) * k <= last;
+                const bool want = !(GROUP8_ABLATE & 2) && !found && !dead && seen >= 1 && qb <= last && qb + (t - seen - 1) * k <= last;
                 if (threadIdx.x == 0) tail_n = 0;
                 if (!__syncthreads_or(want)) break;
                 if (want) {
