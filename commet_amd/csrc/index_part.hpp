@@ -55,7 +55,10 @@ constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build wo
 constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
 constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
 constexpr uint32_t MAX_L1 = 256;                            // 2^b1 upper bound
-constexpr uint32_t S1_GRID_MAX = 512;                       // scatter-1 workgroups (two per CU: 70 KiB of LDS each)
+#ifndef S1_ALIGNED
+#define S1_ALIGNED 1
+#endif
+constexpr uint32_t S1_GRID_MAX = 1024;                       // pieces of the read range = scatter-1 workgroups (two run per CU at a time; 512 / 1024 / 2048 pieces: 4.46 / 4.37 / 4.33 ms per configs[1] step)
 
 struct PartGeom {
     int      k;
@@ -214,6 +217,21 @@ __device__ __forceinline__ void write_run(uint32_t *__restrict__ out, unsigned l
         const uint32_t *q = sorted + s0 + 4 * v;
         o4[v] = make_uint4(q[0], q[1], q[2], q[3]);
     }
+    const uint32_t done = head + 4 * nvec;
+    if (g < n - done) out[dst + done + g] = sorted[src + done + g];
+}
+
+// write_run for a run whose LDS copy starts at the same offset from a 16-byte boundary as its destination (src = dst mod 4
+// words): the whole vectors are then single 16-byte LDS reads, too.
+__device__ __forceinline__ void write_run_aligned(uint32_t *__restrict__ out, unsigned long long dst, const uint32_t *sorted,
+                                                  uint32_t src, uint32_t n, uint32_t g, uint32_t G)
+{
+    const uint32_t head = min(n, (uint32_t) ((4u - (uint32_t) (dst & 3ull)) & 3u));
+    if (g < head) out[dst + g] = sorted[src + g];
+    const uint32_t nvec = (n - head) >> 2;
+    const uint4 *s4 = (const uint4 *) (sorted + src + head);
+    uint4 *o4 = (uint4 *) (out + dst + head);
+    for (uint32_t v = g; v < nvec; v += G) o4[v] = s4[v];
     const uint32_t done = head + 4 * nvec;
     if (g < n - done) out[dst + done + g] = sorted[src + done + g];
 }
@@ -465,14 +483,23 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
 }
 
 // blockoff[j * nb1 + c] = where scatter1 workgroup j starts writing in coarse bucket c
-//                        = off[c << b2] + keys of c counted for workgroups 0 .. j-1.   One workgroup per c.
+//                        = off[c << b2] + keys of c counted for workgroups 0 .. j-1.   One workgroup per c;
+// thread x takes the BLOCKOFF_PER consecutive workgroups j = x * BLOCKOFF_PER ... (n_blk1 <= S1_GRID_MAX).
+constexpr uint32_t BLOCKOFF_PER = (S1_GRID_MAX + 511) / 512;
 __global__ __launch_bounds__(512) void part_blockoff_kernel(const uint32_t *__restrict__ blockcnt,
                                                             const uint64_t *__restrict__ off, PartGeom g, uint32_t n_blk1,
                                                             unsigned long long *__restrict__ blockoff)
 {
     __shared__ uint64_t s_sum[512];
     const uint32_t c = blockIdx.x;
-    const uint64_t v = threadIdx.x < n_blk1 ? blockcnt[(uint64_t) threadIdx.x * g.nb1 + c] : 0;   // n_blk1 <= 512
+    uint32_t cntv[BLOCKOFF_PER];
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BLOCKOFF_PER; ++i) {
+        const uint32_t j = threadIdx.x * BLOCKOFF_PER + i;
+        cntv[i] = j < n_blk1 ? blockcnt[(uint64_t) j * g.nb1 + c] : 0u;
+        v += cntv[i];
+    }
     s_sum[threadIdx.x] = v;
     __syncthreads();
     for (uint32_t o = 1; o < 512; o <<= 1) {
@@ -481,7 +508,13 @@ __global__ __launch_bounds__(512) void part_blockoff_kernel(const uint32_t *__re
         s_sum[threadIdx.x] += a;
         __syncthreads();
     }
-    if (threadIdx.x < n_blk1) blockoff[(uint64_t) threadIdx.x * g.nb1 + c] = off[(uint64_t) c << g.b2] + (s_sum[threadIdx.x] - v);
+    uint64_t at = off[(uint64_t) c << g.b2] + (s_sum[threadIdx.x] - v);
+#pragma unroll
+    for (uint32_t i = 0; i < BLOCKOFF_PER; ++i) {
+        const uint32_t j = threadIdx.x * BLOCKOFF_PER + i;
+        if (j < n_blk1) blockoff[(uint64_t) j * g.nb1 + c] = at;
+        at += cntv[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -504,7 +537,11 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     constexpr bool WIDE = sizeof(W) == 8;          // 33 <= k <= 34: keys of 33 / 34 bits
     constexpr uint32_t NTR = WIDE ? 3u : 2u;       // word triples a k-mer window can span
     using T = KeyTraits<W>;
-    __shared__ uint32_t sorted[S1_KEYS];
+    // ALIGNED: a run's LDS copy starts at the same offset from a 16-byte boundary as its place in bufA (up to 3 + 3 idle
+    // slots per run), so that the write-out reads whole vectors from LDS.  Only where the LDS allows it beside two
+    // workgroups per CU: the round planner's tables of the other variant take that room.
+    constexpr bool ALIGNED = UNI && S1_ALIGNED;
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[S1_KEYS + (ALIGNED ? 6 * MAX_L1 : 0)];
     __shared__ uint32_t cnt[MAX_L1], base[MAX_L1];
     __shared__ unsigned long long gbase[MAX_L1], gcur[MAX_L1];   // this round's / the next round's output position per coarse bucket
     __shared__ uint32_t istart[UNI ? 4 : NT + 4], rd_len[UNI ? 1 : NT], wsum[16], sh_n[4];
@@ -628,11 +665,26 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
             pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
         }
         __syncthreads();
-        lds_scan<NT>(cnt, base, g.nb1, wsum);
-        if (threadIdx.x < g.nb1) {   // exact positions: the hist pass counted this workgroup's keys per coarse bucket
-            const unsigned long long at = gcur[threadIdx.x];
-            gbase[threadIdx.x] = at;
-            gcur[threadIdx.x] = at + cnt[threadIdx.x];
+        if (!ALIGNED) {
+            lds_scan<NT>(cnt, base, g.nb1, wsum);
+            if (threadIdx.x < g.nb1) {   // exact positions: the hist pass counted this workgroup's keys per coarse bucket
+                const unsigned long long at = gcur[threadIdx.x];
+                gbase[threadIdx.x] = at;
+                gcur[threadIdx.x] = at + cnt[threadIdx.x];
+            }
+        } else {   // the same, the run of bucket c starting at (a multiple of 4) + (its place in bufA mod 4)
+            const bool mine = threadIdx.x < g.nb1;   // nb1 <= MAX_L1 < NT
+            const uint32_t c = mine ? cnt[threadIdx.x] : 0u;
+            const unsigned long long at = mine ? gcur[threadIdx.x] : 0ull;
+            const uint32_t ph = (uint32_t) (at & 3ull);
+            uint32_t tot;
+            const uint32_t ex = block_scan<NT>(mine ? ((ph + c + 3u) & ~3u) : 0u, wsum, &tot);
+            if (mine) {
+                base[threadIdx.x] = ex + ph;
+                gbase[threadIdx.x] = at;
+                gcur[threadIdx.x] = at + c;
+            }
+            __syncthreads();
         }
         // pass B: place every key at its bucket's base + its rank
         if (ion && !(COMMET_ABLATE & 2)) {
@@ -663,7 +715,10 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         // write-out: one wave per run, consecutive lanes -> consecutive addresses
         if (!(COMMET_ABLATE & 1))
         for (uint32_t c1 = wave * 4 + (lane >> 4); c1 < g.nb1; c1 += (NT / 64) * 4)
-            write_run(out, gbase[c1], sorted, base[c1], cnt[c1], lane & 15u, 16u);
+        {
+            if (ALIGNED) write_run_aligned(out, gbase[c1], sorted, base[c1], cnt[c1], lane & 15u, 16u);
+            else write_run(out, gbase[c1], sorted, base[c1], cnt[c1], lane & 15u, 16u);
+        }
         __syncthreads();
         r += rp.n_reads;
     }
