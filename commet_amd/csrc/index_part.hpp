@@ -55,6 +55,9 @@ constexpr uint32_t BUILD_CAP = 1u << 17;                    // keys per build wo
 constexpr uint32_t HIST_MAX_BUCKETS = 32768;                // LDS histogram capacity (128 KiB)
 constexpr uint32_t MAX_SUB = 512;                           // 2^b2 upper bound
 constexpr uint32_t MAX_L1 = 256;                            // 2^b1 upper bound
+#ifndef HIST_ROLLING
+#define HIST_ROLLING 1
+#endif
 #ifndef S1_ALIGNED
 #define S1_ALIGNED 1
 #endif
@@ -120,6 +123,48 @@ __device__ __forceinline__ void for_each_key(const uint32_t *p, uint32_t len, ui
         if (planes & 2u) f(1u, kb);
         if (planes & 4u) f(2u, ka ^ kb);
         if (planes & 8u) f(3u, ka | kb);
+    }
+}
+
+// The same for a bucket count (k <= 32): calls f(plane, bucket) with bucket = key >> TILE_BITS, the top nbits = k - TILE_BITS
+// bits of the plane's key, for the complete k-mers ending in octet q.  Those bits roll from one position to the next:
+//   top(keya) = the hi bits of the nbits OLDEST bases, oldest first   -> shift left, the next base enters at the bottom
+//   top(keyb) = the same of the lo bits
+//   top(psi_a) = top(keya) ^ ~(hi bits of the nbits NEWEST bases, newest first)    (psi_a_top: s = u ^ g(L))
+//                                                                     -> shift right, the new base enters at the top
+// so a position costs ~27 instructions instead of the ~52 of three 64-bit window extractions, two bit reversals and
+// psi_a_top (the histogram kernel spends 82 % of the VALU's cycles).  The entering bases sit at fixed offsets from the
+// octet's first position (k - nbits = TILE_BITS), one 64-bit shift per plane and octet.
+template <typename F>
+__device__ __forceinline__ void for_each_bucket32(const uint32_t *p, uint32_t len, uint32_t q, int k, F &&f)
+{
+    const uint32_t w = q >> 2, j0 = (q & 3u) * 8u;
+    ItemWords<uint32_t> it;
+    it.load(p, w);
+    const int nbits = k - TILE_BITS;
+    const uint32_t mask = (k == 32) ? ~0u : ((1u << k) - 1u), nmask = (1u << nbits) - 1u;
+    const uint64_t hi64 = ((uint64_t) it.hi[1] << 32) | it.hi[0], lo64 = ((uint64_t) it.lo[1] << 32) | it.lo[0];
+    const uint64_t va64 = ((uint64_t) it.va[1] << 32) | it.va[0];
+    const uint32_t s = 33u + j0 - (uint32_t) k;   // the window ending at j0 (ItemWords::window)
+    const uint32_t wh = (uint32_t) (hi64 >> s) & mask, wl = (uint32_t) (lo64 >> s) & mask, vw = (uint32_t) (va64 >> s) & mask;
+    uint32_t a_top = __brev(wh) >> (32 - nbits), b_top = __brev(wl) >> (32 - nbits), w_top = wh >> (k - nbits);
+    uint32_t run = (uint32_t) __clz((int) ~(vw << (32 - k)));   // valid bases in a row up to j0, counted up to k
+    // bit jj of these = the base that enters at position j0 + jj: the oldest groups take base (position - TILE_BITS)
+    const uint32_t cA = (uint32_t) (hi64 >> (32u - TILE_BITS + j0)), cB = (uint32_t) (lo64 >> (32u - TILE_BITS + j0));
+    const uint32_t cW = it.hi[1] >> j0, cV = it.va[1] >> j0;
+#pragma unroll
+    for (uint32_t jj = 0; jj < 8; ++jj) {
+        if (jj) {
+            a_top = ((a_top << 1) | ((cA >> jj) & 1u)) & nmask;
+            b_top = ((b_top << 1) | ((cB >> jj) & 1u)) & nmask;
+            w_top = (w_top >> 1) | (((cW >> jj) & 1u) << (nbits - 1));
+            run = ((cV >> jj) & 1u) ? run + 1u : 0u;
+        }
+        if (run < (uint32_t) k || 32u * w + j0 + jj >= len) continue;
+        f(0u, a_top ^ w_top ^ nmask);
+        f(1u, b_top);
+        f(2u, a_top ^ b_top);
+        f(3u, a_top | b_top);
     }
 }
 
@@ -349,6 +394,9 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     for (uint32_t pl = 0; pl < 4; ++pl)
         if (((pl + 1) << g.plane_shift) > b_lo && (pl << g.plane_shift) < b_lo + n_b) planes |= 1u << pl;
     if (FULL) planes = 15u;
+    // k <= 32 (always FULL): the buckets come from rolled top bits (for_each_bucket32)
+    constexpr bool ROLL = FULL && sizeof(W) == 4 && HIST_ROLLING;
+    auto add_bucket = [&](uint32_t plane, uint32_t bucket) { atomicAdd(h + (plane << g.plane_shift) + bucket, 1u); };
     auto add = [&](uint32_t plane, W key) {
         if (FULL) {
             atomicAdd(h + (plane << g.plane_shift) + (uint32_t) (key >> TILE_BITS), 1u);
@@ -371,7 +419,8 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
             uint32_t q = threadIdx.x % opr;
             const uint32_t dpos = NT / opr, dq = NT % opr;
             for (uint64_t id = threadIdx.x; id < total; id += NT) {
-                for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add, planes);
+                if constexpr (ROLL) for_each_bucket32(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add_bucket);
+                else for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add, planes);
                 rd += dpos, q += dq;
                 if (q >= opr) q -= opr, ++rd;
             }
@@ -382,7 +431,8 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
                 for (uint32_t id = threadIdx.x; id < rp.n_items; id += NT) {
                     uint32_t slot, q;
                     item_lookup(istart, rp.n_reads, id, g.k, slot, q);
-                    for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add, planes);
+                    if constexpr (ROLL) for_each_bucket32(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add_bucket);
+                    else for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add, planes);
                 }
                 __syncthreads();
                 r += rp.n_reads;
