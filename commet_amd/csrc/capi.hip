@@ -1057,7 +1057,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     }
     {
         const bool lds_hist = (size_t) g.nb * 4 <= (128u << 10);   // stage the histogram in LDS (coalesced loads) when it fits
-        const size_t lds = lds_hist ? (size_t) g.nb * 4 : 0;
+        const size_t lds = lds_hist ? ((size_t) g.nb + g.nb / 32 + 1) * 4 : 0;   // (padded: see the kernel)
         if (lds) HIP_OK(hipFuncSetAttribute((const void *) part_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         KScope ks(c, "part_scan_kernel", stream);
         hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,

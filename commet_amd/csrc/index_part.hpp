@@ -469,12 +469,14 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restr
     __shared__ uint32_t s_w32[16];
     __shared__ uint64_t c_off[MAX_L1 + 1];               // key offsets of the coarse buckets
     extern __shared__ uint32_t h_lds[];                   // the histogram, staged with coalesced loads when it fits (lds_hist)
+    // (one idle word per 32: thread x walks the counters x * per ... of its own, and with per = 32 every lane of a wave
+    // would otherwise sit in the same LDS bank — 64 cycles per access instead of 2, 40 % of this kernel's 110 us)
     const bool staged = lds_hist != 0;
     if (staged) {
-        for (uint32_t i = threadIdx.x; i < g.nb; i += 1024) h_lds[i] = hist[i];
+        for (uint32_t i = threadIdx.x; i < g.nb; i += 1024) h_lds[i + (i >> 5)] = hist[i];
         __syncthreads();
     }
-    auto count_of = [&](uint32_t b) { return staged ? h_lds[b] : hist[b]; };
+    auto count_of = [&](uint32_t b) { return staged ? h_lds[b + (b >> 5)] : hist[b]; };
     const uint32_t per = (g.nb + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
     const uint32_t sub_mask = (1u << g.b2) - 1u;
