@@ -215,12 +215,26 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             cmd += ["-o", bvs[s][j]]
             say("Filtering command: " + " ".join(cmd))
             cmds.append(cmd)
-        # independent processes (each one multi-threaded over its file): a few at a time
+        # independent processes (each one multi-threaded over its file), a few at a time — and beside the parsing of
+        # the sets below: nothing reads a filter's .bv before the sets are resident
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3"))) as pool:
-            list(pool.map(lambda c: subprocess.run(c, check=True, stdout=subprocess.DEVNULL), cmds))
-        ranks.barrier()
-    filter_s = time.perf_counter() - t_filter
+        filter_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3")))
+        filter_jobs = [filter_pool.submit(subprocess.run, c, check=True, stdout=subprocess.DEVNULL) for c in cmds]
+    else:
+        filter_pool, filter_jobs = None, []
+    filter_s = 0.0
+
+    def filters_done():
+        """every rank's filter files are written (raises what a filter_reads process raised)"""
+        nonlocal filter_s
+        if filter_pool is not None:
+            try:
+                for j in filter_jobs:
+                    j.result()
+            finally:
+                filter_pool.shutdown(wait=True)
+            filter_s = time.perf_counter() - t_filter
+            ranks.barrier()
 
     # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
     pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
@@ -265,6 +279,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
                 prof["load_s"] += time.perf_counter() - w0
                 prof["sets_loaded"] += 1
+        filters_done()
         counts, sel, considered_mine = {}, {}, {}
         for s in needed:
             counts[s] = eng.file_reads(sets[s])
@@ -342,7 +357,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         total_searched = ranks.sum_int(reads_searched)
         total_s = ranks.max_seconds(time.perf_counter() - t_start)
         if result is not None:
-            result.update(filter_s=slowest_filter, load_s=slowest_load, jobs_s=slowest, total_s=total_s,
+            # (the filter processes run beside the parsing: filter_s and load_s overlap, total_s is the wall time of it all)
+            result.update(filter_s=slowest_filter, load_s=slowest_load, filter_overlaps_load=filter_pool is not None, jobs_s=slowest, total_s=total_s,
                           reads_searched=total_searched, world=world, rank0_profile=prof,
                           per_rank=[p for _, p in everyone],
                           reads_per_s=total_searched / slowest if slowest > 0 else 0.0,
@@ -353,6 +369,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             eng.release(rs)
         return result
     finally:
+        if filter_pool is not None:
+            filter_pool.shutdown(wait=True, cancel_futures=True)
         eng.close()
         if scratch is not None:
             # rank 0 removes the scratch directory once everybody is through; a failing rank removes its own images
