@@ -214,7 +214,8 @@ def matrix_leg(args, ranks):
             shutil.rmtree(work, ignore_errors=True)
     if res is None:
         return None
-    keep = ("filter_s", "load_s", "jobs_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world")
+    keep = ("filter_s", "load_s", "jobs_s", "set_wait_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world",
+            "filter_overlaps_load", "load_overlaps_jobs")
     out = {f: (round(res[f], 4) if isinstance(res[f], float) else res[f]) for f in keep}
     out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix (BASELINE configs[2]) over {ranks.world} GPU(s): "
                         f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",

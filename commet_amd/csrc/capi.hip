@@ -116,6 +116,8 @@ struct commet_ctx {
     uint64_t plansum_cap = 0;
     uint64_t jobcnt_cap = 0;
     hipStream_t aux_stream = nullptr;         // second lane of a chunk group's index phase
+    hipStream_t load_stream = nullptr;        // everything that makes a read set (uploads, k-mer counts): a set may be loaded by one
+                                              // host thread while another runs jobs on sets that are complete
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
 
@@ -335,6 +337,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_s0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_s1);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->load_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream);
@@ -368,6 +371,7 @@ void commet_destroy(commet_ctx *c)
     c->part[0].release();
     c->part[1].release();
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
+    if (c->load_stream) (void) hipStreamSynchronize(c->load_stream), (void) hipStreamDestroy(c->load_stream);
     if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void) hipEventDestroy(c->ev_join);
     if (c->d_counters) (void) hipFree(c->d_counters);
@@ -432,8 +436,8 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     if (e == hipSuccess) e = hipMalloc((void **) &rs->d_found, bw * 8);
     if (e == hipSuccess) {
         const uint32_t mm[3] = {0xFFFFFFFFu, 0u, 0u};
-        e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->load_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->load_stream);
     }
     if (e != hipSuccess) {
         fail("read set allocation failed (%llu reads, %llu bases): %s", (unsigned long long) max_reads,
@@ -448,7 +452,8 @@ void commet_readset_destroy(commet_readset *rs)
 {
     if (!rs) return;
     (void) hipSetDevice(rs->ctx->device);
-    (void) hipStreamSynchronize(rs->ctx->stream);
+    (void) hipStreamSynchronize(rs->ctx->load_stream);
+    (void) hipStreamSynchronize(rs->ctx->stream);   // (a job that still reads the set)
     (void) hipFree(rs->d_planes);
     (void) hipFree(rs->d_goff);
     (void) hipFree(rs->d_kcnt);
@@ -522,13 +527,13 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
     }
     commet_ctx *c = rs->ctx;
     HIP_OK(hipSetDevice(c->device));
-    if (nbases) HIP_OK(hipMemcpyAsync(s.d_bases, s.h_bases, nbases, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(s.d_offs, s.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (nbases) HIP_OK(hipMemcpyAsync(s.d_bases, s.h_bases, nbases, hipMemcpyHostToDevice, c->load_stream));
+    HIP_OK(hipMemcpyAsync(s.d_offs, s.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->load_stream));
     const unsigned grid = (unsigned) ((n + 1 + 255) / 256);
-    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->stream, s.d_bases, s.d_offs, n, rs->n_reads,
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->load_stream, s.d_bases, s.d_offs, n, rs->n_reads,
                        rs->n_bases, rs->d_planes, rs->d_goff, rs->d_kcnt, rs->d_lenmm, c->k);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipEventRecord(s.done, c->stream));
+    HIP_OK(hipEventRecord(s.done, c->load_stream));
     s.inflight = true;
     rs->n_reads += n;
     rs->n_bases += nbases;
@@ -606,9 +611,9 @@ struct HipPackSink {
         const size_t bi = (size_t) worker * 2 + cur[worker];
         if (triple0 + n_triples > (rs->max_bases >> 5) + rs->max_reads + 1 || read0 + n_reads > rs->max_reads) return false;
         if (hipSetDevice(c->device) != hipSuccess) return false;
-        if (n_triples && hipMemcpyAsync(rs->d_planes + 3 * triple0, st.planes, n_triples * 12, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
-        if (n_reads && hipMemcpyAsync(rs->d_goff + read0, st.goff, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
-        if (hipEventRecord(c->ingest_pool[bi].done, c->stream) != hipSuccess) return false;
+        if (n_triples && hipMemcpyAsync(rs->d_planes + 3 * triple0, st.planes, n_triples * 12, hipMemcpyHostToDevice, c->load_stream) != hipSuccess) return false;
+        if (n_reads && hipMemcpyAsync(rs->d_goff + read0, st.goff, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, c->load_stream) != hipSuccess) return false;
+        if (hipEventRecord(c->ingest_pool[bi].done, c->load_stream) != hipSuccess) return false;
         inflight[bi] = 1;
         cur[worker] ^= 1;
         return true;
@@ -650,7 +655,7 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
     const bool ok = commet_host::ingest_arrays(bases, offsets, n_reads, rs->n_reads, rs->n_bases, T, sink, sm, err);
     if (verbose) fprintf(stderr, "[ingest] packed + queued    %8.1f ms\n", since());
     // the staging buffers go back to the pool only once their copies are done
-    const bool synced = hipStreamSynchronize(rs->ctx->stream) == hipSuccess;
+    const bool synced = hipStreamSynchronize(rs->ctx->load_stream) == hipSuccess;
     if (verbose) fprintf(stderr, "[ingest] uploaded           %8.1f ms\n", since());
     if (!synced && ok) return fail("upload failed: %s", hipGetErrorString(hipGetLastError()));
     if (!ok) return fail("%s", err.empty() ? "read set ingest failed" : err.c_str());
@@ -724,7 +729,7 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
             return &sink;
         },
         file_reads, total_reads, total_bases, sm, err);
-    if (rs) (void) hipStreamSynchronize(c->stream);
+    if (rs) (void) hipStreamSynchronize(c->load_stream);
     if (verbose)
         fprintf(stderr, "[ingest] packed + uploaded  %8.1f ms\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
@@ -768,7 +773,7 @@ int commet_readset_finalize(commet_readset *rs)
     if (rs->acquired) return fail("finalize with an uncommitted staging buffer");
     commet_ctx *c = rs->ctx;
     HIP_OK(hipSetDevice(c->device));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->load_stream));
     rs->st[0].inflight = rs->st[1].inflight = false;
     // shortest / longest read: from the packing kernel (reads that came through the staging API) and from the host
     // packer (append / from_fasta); the host copy of the per-read counts and their prefix sums (chunk planning) are made
@@ -783,11 +788,11 @@ int commet_readset_finalize(commet_readset *rs)
     if (rs->host_packed && rs->n_reads) {
         // host-packed reads have no counts yet: complete k-mers of every read from its validity plane, on the device
         const uint64_t nb = rs->n_bases;
-        HIP_OK(hipMemcpyAsync(rs->d_goff + rs->n_reads, &nb, sizeof nb, hipMemcpyHostToDevice, c->stream));   // closes the offsets
-        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((rs->n_reads + 255) / 256)), dim3(256), 0, c->stream, rs->view(), c->k,
+        HIP_OK(hipMemcpyAsync(rs->d_goff + rs->n_reads, &nb, sizeof nb, hipMemcpyHostToDevice, c->load_stream));   // closes the offsets
+        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((rs->n_reads + 255) / 256)), dim3(256), 0, c->load_stream, rs->view(), c->k,
                            rs->d_kcnt, rs->d_lenmm);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipStreamSynchronize(c->load_stream));
         HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     }
     rs->max_kcnt = rs->n_reads ? mm[2] : 0;
@@ -853,7 +858,7 @@ int commet_readset_save(const commet_readset *rs, const char *path)
     memcpy(m, &h, sizeof h);
     if (h.n_files) memcpy(m + lay.files_at, rs->files.data(), h.n_files * sizeof(FileSpan));
     if (h.n_empty) memcpy(m + lay.empty_at, rs->empty_reads.data(), h.n_empty * 8);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipStreamSynchronize(c->load_stream);
     if (e == hipSuccess) e = hipMemcpy(m + lay.planes_at, rs->d_planes, h.triples * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && !h.uniform_len) e = hipMemcpy(m + lay.goff_at, rs->d_goff, (h.n_reads + 1) * 8, hipMemcpyDeviceToHost);
     munmap(m, lay.total);
@@ -904,19 +909,19 @@ commet_readset *commet_readset_load(commet_ctx *c, const char *path)
     rs->n_reads = h.n_reads;
     rs->n_bases = h.n_bases;
     const uint32_t mm[3] = {h.n_reads ? h.min_len : 0xFFFFFFFFu, h.max_len, 0u};
-    hipError_t e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->load_stream);
     // the image is pageable memory: the copies below are staged by the runtime and return when the source has been read
-    if (e == hipSuccess) e = hipMemcpyAsync(rs->d_planes, m + lay.planes_at, h.triples * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rs->d_planes, m + lay.planes_at, h.triples * 12, hipMemcpyHostToDevice, c->load_stream);
     if (e == hipSuccess && !h.uniform_len)
-        e = hipMemcpyAsync(rs->d_goff, m + lay.goff_at, (h.n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(rs->d_goff, m + lay.goff_at, (h.n_reads + 1) * 8, hipMemcpyHostToDevice, c->load_stream);
     if (e == hipSuccess && h.n_reads) {
         ReadsView v = rs->view();
         v.uniform_len = h.uniform_len;
-        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->stream, v, c->k, rs->d_kcnt,
+        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->load_stream, v, c->k, rs->d_kcnt,
                            rs->d_lenmm);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->load_stream);
     munmap((void *) m, lay.total);
     if (e != hipSuccess) {
         fail("read set upload failed: %s", hipGetErrorString(e));

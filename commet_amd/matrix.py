@@ -203,7 +203,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     if bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
-        cmds = []
+        cmds, cmd_set = [], []
         for q, (s, j) in enumerate(todo):
             if q % world != rank:
                 continue
@@ -215,14 +215,26 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             cmd += ["-o", bvs[s][j]]
             say("Filtering command: " + " ".join(cmd))
             cmds.append(cmd)
+            cmd_set.append(s)
         # independent processes (each one multi-threaded over its file), a few at a time — and beside the parsing of
         # the sets below: nothing reads a filter's .bv before the sets are resident
         from concurrent.futures import ThreadPoolExecutor
         filter_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3")))
-        filter_jobs = [filter_pool.submit(subprocess.run, c, check=True, stdout=subprocess.DEVNULL) for c in cmds]
+        # (the sets are loaded last set first, see below: so are their filters)
+        filter_jobs = [filter_pool.submit(subprocess.run, c, check=True, stdout=subprocess.DEVNULL) for c in reversed(cmds)]
+        filter_end = [t_filter]
+        for j in filter_jobs:                                      # when the last of them was done
+            j.add_done_callback(lambda _f: filter_end.__setitem__(0, max(filter_end[0], time.perf_counter())))
+        filter_set = list(reversed(cmd_set))
     else:
-        filter_pool, filter_jobs = None, []
+        filter_pool, filter_jobs, filter_set = None, [], []
     filter_s = 0.0
+
+    def filter_done_for(s):
+        """set s's filter files are written (single rank: this process started them all)"""
+        for j, fs in zip(filter_jobs, filter_set):
+            if fs == s:
+                j.result()
 
     def filters_done():
         """every rank's filter files are written (raises what a filter_reads process raised)"""
@@ -233,7 +245,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     j.result()
             finally:
                 filter_pool.shutdown(wait=True)
-            filter_s = time.perf_counter() - t_filter
+            filter_s = (filter_end[0] if filter_jobs else time.perf_counter()) - t_filter
             ranks.barrier()
 
     # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
@@ -250,14 +262,17 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         token = ranks.broadcast_object(f"commet_pk_{os.getuid()}_{os.getpid()}_{int(time.time())}" if rank == 0 else None)
         scratch = os.path.join(_scratch_root(), token)
         os.makedirs(scratch, exist_ok=True)
+    # one rank: sets are loaded by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: load everything first)
+    pipelined = world == 1 and N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
     eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
+    loader = None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
                 jobs=0, call_ms=0.0, device_ms=0.0)
     try:
         # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
         t0 = time.perf_counter()
         sets = {}
-        for s in owned:
+        for s in ([] if pipelined else owned):
             if s not in needed and s not in needed_by_others:
                 continue
             w0 = time.perf_counter()
@@ -273,30 +288,77 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             else:
                 eng.release(rs)
         ranks.barrier()                                          # every image is in place
-        for s in needed:
+        for s in ([] if pipelined else needed):
             if s not in sets:
                 w0 = time.perf_counter()
                 sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
                 prof["load_s"] += time.perf_counter() - w0
                 prof["sets_loaded"] += 1
-        filters_done()
         counts, sel, considered_mine = {}, {}, {}
-        for s in needed:
+
+        def prepare(s):
+            """set s is resident and filtered: its per-file read counts and its input selection"""
             counts[s] = eng.file_reads(sets[s])
             parts = [read_bv(b) for b in bvs[s]]
             for (nb, _), c, f in zip(parts, counts[s], files[s]):
                 if nb != c:
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
-        for s in range(N):                                       # the diagonal: every set once, by its parser
-            if s % world == rank:
-                considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
-        load_s = time.perf_counter() - t0
-        considered = {}
-        for d in ranks.gather_objects(considered_mine):
-            considered.update(d)
-        considered = [considered[s] for s in range(N)]
-        say(f"loaded {N} sets in {load_s:.2f} s (rank 0: {prof['sets_parsed']} parsed, {prof['sets_loaded']} from packed images)")
+
+        if not pipelined:
+            filters_done()
+            for s in needed:
+                prepare(s)
+            for s in range(N):                                   # the diagonal: every set once, by its parser
+                if s % world == rank:
+                    considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+            load_s = time.perf_counter() - t0
+            considered = {}
+            for d in ranks.gather_objects(considered_mine):
+                considered.update(d)
+            considered = [considered[s] for s in range(N)]
+            say(f"loaded {N} sets in {load_s:.2f} s (rank 0: {prof['sets_parsed']} parsed, {prof['sets_loaded']} from packed images)")
+        else:
+            # One rank: a second host thread parses, packs and uploads the sets, LAST SET FIRST (read sets are made on a
+            # stream of their own, include/commet_hip.h), and the jobs of ref = N-2, N-3, ... start as soon as the sets
+            # ref .. N-1 are there: the host-bound loading hides behind the device-bound jobs.
+            import threading
+            ready = [threading.Event() for _ in range(N)]
+            load_err = []
+            load_end = [t0]
+            considered = [0] * N
+
+            def load_all():
+                try:
+                    for s in range(N - 1, -1, -1):
+                        w0 = time.perf_counter()
+                        rs = eng.parse(files[s])
+                        prof["parse_s"] += time.perf_counter() - w0
+                        prof["sets_parsed"] += 1
+                        sets[s] = rs
+                        filter_done_for(s)
+                        prepare(s)
+                        considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+                        ready[s].set()
+                except BaseException as ex:          # handed to the job thread, which is waiting for a set
+                    load_err.append(ex)
+                    for ev in ready:
+                        ev.set()
+                finally:
+                    load_end[0] = time.perf_counter()
+
+            loader = threading.Thread(target=load_all, name="commet-set-loader", daemon=True)
+            loader.start()
+
+        set_wait = [0.0]
+
+        def wait_for(s):
+            if loader is not None:
+                w0 = time.perf_counter()
+                ready[s].wait()
+                set_wait[0] += time.perf_counter() - w0
+                if load_err:
+                    raise load_err[0]
 
         # ---- my pairs, grouped by ref ------------------------------------------------------------------------
         shared = {}                    # (from set, in set) -> reads of `from` found in `in`
@@ -308,8 +370,9 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
 
         t_jobs = time.perf_counter()
-        for ref in sorted({p[0] for p in mine}):
+        for ref in sorted({p[0] for p in mine}, reverse=pipelined):
             targets = [i for (r, i) in mine if r == ref]
+            wait_for(ref)                                        # (pipelined: the sets ref .. N-1 are resident then)
             w0 = time.perf_counter()
             tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
             prof["j1_builds"] += 1
@@ -333,8 +396,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 shared[(i, ref)] = st3[0]["shared"]
                 reads_searched += considered[ref] + considered[i]
         eng.synchronize()
-        jobs_s = time.perf_counter() - t_jobs
+        jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
         prof["jobs_s"] = jobs_s
+        prof["set_wait_s"] = set_wait[0]
+        if loader is not None:
+            for s in range(N):                                   # (a set no pair needs is still loaded and counted)
+                wait_for(s)
+            loader.join()
+            filters_done()
+            load_s = load_end[0] - t0
         # ---- matrices on rank 0 -----------------------------------------------------------------------------
         everyone = ranks.gather_objects((shared, prof))
         result = None
@@ -358,7 +428,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         total_s = ranks.max_seconds(time.perf_counter() - t_start)
         if result is not None:
             # (the filter processes run beside the parsing: filter_s and load_s overlap, total_s is the wall time of it all)
-            result.update(filter_s=slowest_filter, load_s=slowest_load, filter_overlaps_load=filter_pool is not None, jobs_s=slowest, total_s=total_s,
+            result.update(filter_s=slowest_filter, load_s=slowest_load, filter_overlaps_load=filter_pool is not None,
+                          load_overlaps_jobs=pipelined, set_wait_s=prof.get("set_wait_s", 0.0), jobs_s=slowest, total_s=total_s,
                           reads_searched=total_searched, world=world, rank0_profile=prof,
                           per_rank=[p for _, p in everyone],
                           reads_per_s=total_searched / slowest if slowest > 0 else 0.0,
@@ -369,6 +440,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             eng.release(rs)
         return result
     finally:
+        if loader is not None and loader.is_alive():             # (an error in the job thread: the sets are released below)
+            loader.join()
         if filter_pool is not None:
             filter_pool.shutdown(wait=True, cancel_futures=True)
         eng.close()

@@ -19,7 +19,11 @@
  *     (include/boolean_vector.h:73-80, 222-233): read i = byte i/8, mask 1<<(i%8).
  *     A bit array over n reads has n/8+1 bytes (boolean_vector.h:130).
  *   - one ctx per (device, stream); calls on one ctx are serialised by the
- *     caller; several ctxs may be used from several host threads.
+ *     caller; several ctxs may be used from several host threads.  One exception:
+ *     read sets are made on a stream of their own, so ONE host thread may build read
+ *     sets of a ctx (commet_readset_create ... commet_readset_finalize,
+ *     commet_readset_from_*, commet_readset_load) while another runs
+ *     commet_index_and_search on sets that are complete (commet_amd/matrix.py does).
  *   - there is NO CPU fallback: without a usable HIP device commet_create fails.
  */
 #ifndef COMMET_HIP_H_
