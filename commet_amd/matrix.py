@@ -265,7 +265,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # one rank: sets are loaded by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: load everything first)
     pipelined = world == 1 and N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
     eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
-    loader = None
+    loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
                 jobs=0, call_ms=0.0, device_ms=0.0)
     try:
@@ -324,6 +324,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             # ref .. N-1 are there: the host-bound loading hides behind the device-bound jobs.
             import threading
             ready = [threading.Event() for _ in range(N)]
+            loader_stop = threading.Event()
             load_err = []
             load_end = [t0]
             considered = [0] * N
@@ -331,6 +332,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             def load_all():
                 try:
                     for s in range(N - 1, -1, -1):
+                        if loader_stop.is_set():                 # the job thread has failed
+                            break
                         w0 = time.perf_counter()
                         rs = eng.parse(files[s])
                         prof["parse_s"] += time.perf_counter() - w0
@@ -440,7 +443,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             eng.release(rs)
         return result
     finally:
-        if loader is not None and loader.is_alive():             # (an error in the job thread: the sets are released below)
+        if loader is not None and loader.is_alive():             # (an error in the job thread)
+            loader_stop.set()
             loader.join()
         if filter_pool is not None:
             filter_pool.shutdown(wait=True, cancel_futures=True)

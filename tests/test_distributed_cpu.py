@@ -172,3 +172,52 @@ def test_bench_json_contract_fields():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "workload"):
         assert re.search(r'"%s"' % key, src), key
+
+
+def _bv_bodies(d):
+    return {f: open(os.path.join(d, f), "rb").read().split(b"\n", 1)[1] for f in sorted(os.listdir(d)) if f.endswith(".bv")}
+
+
+def test_matrix_driver_single_rank_loads_sets_beside_the_jobs(tmp_path, monkeypatch):
+    """One rank: the sets are loaded (last set first) by a second thread while the jobs run.  Same .bv files and matrices as
+    with everything loaded up front (COMMET_MATRIX_PIPELINE=0), which the multi-rank test pins to Commet.py's job sequence."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from commet_amd import matrix
+    from oracle_engine import OracleEngine
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    OracleEngine.fail_on_rank = None
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("COMMET_MATRIX_PIPELINE", mode)
+        res[mode] = matrix.run("sets.txt", f"out{mode}/", k=k, t=t, verbose=False, engine_factory=OracleEngine)
+    assert res["1"]["load_overlaps_jobs"] is True and res["0"]["load_overlaps_jobs"] is False
+    assert res["1"]["per_rank"][0]["sets_parsed"] == len(names) == res["0"]["per_rank"][0]["sets_parsed"]
+    a, b = _bv_bodies(tmp_path / "out1"), _bv_bodies(tmp_path / "out0")
+    assert a == b and len(a) == 6 * 4
+    for f in ("matrix_plain.csv", "matrix_percentage.csv", "matrix_normalized.csv"):
+        assert open(tmp_path / "out1" / f).read() == open(tmp_path / "out0" / f).read()
+    assert res["1"]["reads_searched"] == res["0"]["reads_searched"]
+
+
+def test_matrix_driver_single_rank_loader_failure_reaches_the_caller(tmp_path, monkeypatch):
+    """the loading thread raises while parsing: the job thread, which waits for that set, must raise it (no hang)"""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from commet_amd import matrix
+    from oracle_engine import OracleEngine
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setenv("COMMET_MATRIX_PIPELINE", "1")
+    OracleEngine.fail_on_rank = 0
+    t0 = time.time()
+    try:
+        with pytest.raises(Exception, match="injected failure while parsing"):
+            matrix.run("sets.txt", "out/", k=k, t=t, verbose=False, engine_factory=OracleEngine)
+    finally:
+        OracleEngine.fail_on_rank = None
+    assert time.time() - t0 < 60
