@@ -290,7 +290,12 @@ def main():
 
     matrix_detail = None
     if not args.no_matrix and args.matrix_sets >= 2:
-        matrix_detail = matrix_leg(args, ranks)
+        try:
+            matrix_detail = matrix_leg(args, ranks)
+        except Exception as ex:   # the headline measured above must not be lost with this extra leg
+            import traceback
+            traceback.print_exc()
+            matrix_detail = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         steps = args.steps
