@@ -262,8 +262,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         token = ranks.broadcast_object(f"commet_pk_{os.getuid()}_{os.getpid()}_{int(time.time())}" if rank == 0 else None)
         scratch = os.path.join(_scratch_root(), token)
         os.makedirs(scratch, exist_ok=True)
-    # one rank: sets are loaded by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: load everything first)
-    pipelined = world == 1 and N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
+    # sets are made resident by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: everything first)
+    pipelined = N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
     eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
     loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
@@ -272,7 +272,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
         t0 = time.perf_counter()
         sets = {}
-        for s in ([] if pipelined else owned):
+        solo = pipelined and world == 1                           # (then the loading thread parses, too)
+        for s in ([] if solo else owned):
             if s not in needed and s not in needed_by_others:
                 continue
             w0 = time.perf_counter()
@@ -288,12 +289,6 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             else:
                 eng.release(rs)
         ranks.barrier()                                          # every image is in place
-        for s in ([] if pipelined else needed):
-            if s not in sets:
-                w0 = time.perf_counter()
-                sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
-                prof["load_s"] += time.perf_counter() - w0
-                prof["sets_loaded"] += 1
         counts, sel, considered_mine = {}, {}, {}
 
         def prepare(s):
@@ -305,43 +300,72 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
 
+        def fetch(s):
+            """another rank's set from its packed image"""
+            w0 = time.perf_counter()
+            sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
+            prof["load_s"] += time.perf_counter() - w0
+            prof["sets_loaded"] += 1
+
+        def diagonal():
+            """reads every set was asked about (its filters' popcount): each set once, by its parser; known to all ranks"""
+            for s in range(N):
+                if s % world == rank:
+                    considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+            got = {}
+            for d in ranks.gather_objects(considered_mine):
+                got.update(d)
+            return [got[s] for s in range(N)]
+
+        refs = sorted({p[0] for p in mine}, reverse=pipelined)    # pipelined: last reference set first
         if not pipelined:
+            for s in needed:
+                if s not in sets:
+                    fetch(s)
             filters_done()
             for s in needed:
                 prepare(s)
-            for s in range(N):                                   # the diagonal: every set once, by its parser
-                if s % world == rank:
-                    considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+            considered = diagonal()
             load_s = time.perf_counter() - t0
-            considered = {}
-            for d in ranks.gather_objects(considered_mine):
-                considered.update(d)
-            considered = [considered[s] for s in range(N)]
             say(f"loaded {N} sets in {load_s:.2f} s (rank 0: {prof['sets_parsed']} parsed, {prof['sets_loaded']} from packed images)")
         else:
-            # One rank: a second host thread parses, packs and uploads the sets, LAST SET FIRST (read sets are made on a
-            # stream of their own, include/commet_hip.h), and the jobs of ref = N-2, N-3, ... start as soon as the sets
-            # ref .. N-1 are there: the host-bound loading hides behind the device-bound jobs.
+            # A second host thread makes the sets resident in the order the jobs want them (read sets are made on a stream
+            # of their own, include/commet_hip.h) while this one runs the jobs of a reference set as soon as it and its
+            # targets are there: the host-bound loading hides behind the device-bound jobs.  One rank: the thread parses
+            # the files, last set first, and ref = N-2, N-3, ... need the sets ref .. N-1.  Several ranks: every rank has
+            # parsed its own sets above and all images are in place behind the barrier; the thread takes the others'.
             import threading
             ready = [threading.Event() for _ in range(N)]
             loader_stop = threading.Event()
             load_err = []
             load_end = [t0]
-            considered = [0] * N
+            if solo:
+                order = list(range(N - 1, -1, -1))
+                considered = [0] * N
+            else:
+                order = []
+                for ref in refs:
+                    for s in [ref] + [i for (r, i) in mine if r == ref]:
+                        if s not in order:
+                            order.append(s)
+                filters_done()                                   # (they ran beside the parsing; a barrier: other ranks' filters too)
+                considered = diagonal()
 
             def load_all():
                 try:
-                    for s in range(N - 1, -1, -1):
+                    for s in order:
                         if loader_stop.is_set():                 # the job thread has failed
                             break
-                        w0 = time.perf_counter()
-                        rs = eng.parse(files[s])
-                        prof["parse_s"] += time.perf_counter() - w0
-                        prof["sets_parsed"] += 1
-                        sets[s] = rs
-                        filter_done_for(s)
+                        if solo:
+                            w0 = time.perf_counter()
+                            sets[s] = eng.parse(files[s])
+                            prof["parse_s"] += time.perf_counter() - w0
+                            prof["sets_parsed"] += 1
+                            filter_done_for(s)
+                            considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
+                        elif s not in sets:
+                            fetch(s)
                         prepare(s)
-                        considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
                         ready[s].set()
                 except BaseException as ex:          # handed to the job thread, which is waiting for a set
                     load_err.append(ex)
@@ -373,9 +397,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
 
         t_jobs = time.perf_counter()
-        for ref in sorted({p[0] for p in mine}, reverse=pipelined):
+        for ref in refs:
             targets = [i for (r, i) in mine if r == ref]
-            wait_for(ref)                                        # (pipelined: the sets ref .. N-1 are resident then)
+            for s_need in [ref] + targets:                       # (pipelined: resident by now, or nearly)
+                wait_for(s_need)
             w0 = time.perf_counter()
             tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
             prof["j1_builds"] += 1
@@ -403,10 +428,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         prof["jobs_s"] = jobs_s
         prof["set_wait_s"] = set_wait[0]
         if loader is not None:
-            for s in range(N):                                   # (a set no pair needs is still loaded and counted)
+            for s in order:                                      # (one rank: a set no pair needs is still loaded and counted)
                 wait_for(s)
             loader.join()
-            filters_done()
+            if solo:
+                filters_done()
             load_s = load_end[0] - t0
         # ---- matrices on rank 0 -----------------------------------------------------------------------------
         everyone = ranks.gather_objects((shared, prof))
