@@ -66,8 +66,27 @@ def parse_args():
     ap.add_argument("--traffic", default=None, help="traffic.json to price the roofline with (default: the newest matching one under profiles/)")
     ap.add_argument("--no-matrix", action="store_true", help="skip the configs[2] matrix leg (detail.matrix)")
     ap.add_argument("--matrix-sets", type=int, default=10)
-    ap.add_argument("--matrix-reads", type=int, default=10_000_000)
+    ap.add_argument("--matrix-reads", type=int, default=None,
+                    help="reads per set of the matrix leg (default: 10 M = configs[2] on one GPU, 50 M = configs[3] on several)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, meet at the barriers, print the line's launch fields and leave (no GPU work: the CPU test of the launch path)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process, which has made no HIP
+    call and never will, starts the N ranks through torch.distributed.run as a CHILD process (one rank per GPU,
+    rendezvous on 127.0.0.1), passes the child's output through and leaves with its exit code."""
+    import socket
+    with socket.socket() as sk:                      # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores():
@@ -226,9 +245,22 @@ def matrix_leg(args, ranks):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from commet_amd import sharding
     ranks = sharding.Ranks(backend="gloo")   # host-side barrier / MAX only; N=1 needs no torch at all
     world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports {world}", file=sys.stderr)
+    if args.rendezvous_only:
+        elapsed = sharding.timed_region(ranks, lambda: None, lambda: time.sleep(0.01 * (rank + 1)), args.steps)
+        devices = ranks.gather_objects(int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous only (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed * 1000.0 / args.steps, 3), "devices": devices,
+                              "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None}), flush=True)
+        ranks.close()
+        return
 
     import numpy as np  # noqa: F401
     import commet_amd

@@ -221,3 +221,29 @@ def test_matrix_driver_single_rank_loader_failure_reaches_the_caller(tmp_path, m
     finally:
         OracleEngine.fail_on_rank = None
     assert time.time() - t0 < 60
+
+
+def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start the two ranks itself — as a
+    child process, the parent never touching the GPU — and print ONE line with n_gpus = 2 (the launch path only: the
+    ranks meet at the barriers of the timed region and leave; the GPU work behind it is covered by the -m gpu tests)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--rendezvous-only"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["self_launched"] is True
+    assert out["devices"] == [0, 1]                       # one rank per GPU: rank r works on device LOCAL_RANK = r
+    assert out["ms_per_step"] >= 20.0                     # MAX over the ranks (rank 1 sleeps 20 ms per step)
+
+
+def test_bench_under_a_launcher_does_not_launch_again(tmp_path):
+    """the driver's own form: torch.distributed.run ... bench.py --gpus 2 (WORLD_SIZE set): the ranks run as they are"""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--rendezvous-only"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
