@@ -175,6 +175,10 @@ struct commet_ctx {
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
     int slice_mode = 0;               // option: 0 auto, 1 never, 2 whenever k allows it
     int slice_gw = 0;                 // option: words per bit-sliced entry (32 chunks each); 0 = by the number of chunks
+    int slice_wide = 0;               // option: wide rows (all chunk filters side by side, slice_search.hpp): 0 auto (more than 256 chunks), 1 never, 2 whenever the regime applies
+    uint32_t wide_cap_words = 0;      // option "slice_wide_words": at most this many words per row (tests: several passes); 0 = the budget decides
+    uint32_t *wide_tables = nullptr;
+    uint64_t wide_table_words = 0;
     uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
     int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
     // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
@@ -313,6 +317,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (const char *e = getenv("COMMET_INDEX_LANES")) c->index_lanes = atoi(e) == 1 ? 1 : 2;   // 1: one kernel at a time (per-kernel profiles)
     if (const char *e = getenv("COMMET_TILED")) c->tiled_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("COMMET_SLICE_MODE")) c->slice_mode = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
+    if (const char *e = getenv("COMMET_SLICE_WIDE")) c->slice_wide = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
     if (const char *e = getenv("COMMET_SLICE_WORDS")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) c->slice_gw = v;
@@ -364,6 +369,7 @@ void commet_destroy(commet_ctx *c)
     (void) hipFree(c->d_qres);
     (void) hipFree(c->slice_stage);
     (void) hipFree(c->slice_tables);
+    (void) hipFree(c->wide_tables);
     (void) hipFree(c->d_slice_chunks);
     (void) hipFree(c->il_a);
     (void) hipFree(c->d_jobcnt);
@@ -1503,8 +1509,10 @@ int ensure_slice_buffers(commet_ctx *c, int gw, uint64_t n_chunks)
 }
 
 // filters of chunks [ci, ci + g) of the plan -> bit-sliced tables (slice_search.hpp)
-int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t ci, int g, int gw)
+int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t ci, int g, int gw,
+                       uint32_t *tables = nullptr, uint32_t row_words = 0, uint32_t col0 = 0)
 {
+    if (!tables) tables = c->slice_tables, row_words = (uint32_t) gw, col0 = 0;   // the table of one group (search_sliced_kernel)
     const int tile_bits = std::min(c->k, SLICE_TILE_BITS);
     const uint32_t tiles = 1u << (c->k - tile_bits);
     const size_t lds = (size_t) 4 << (tile_bits - 5);
@@ -1519,10 +1527,10 @@ int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *
     {
         KScope ks(c, "slice_transpose_kernel", c->stream);
         switch (gw) {
-        case 1: hipLaunchKernelGGL(slice_transpose_kernel<1>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
-        case 2: hipLaunchKernelGGL(slice_transpose_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
-        case 4: hipLaunchKernelGGL(slice_transpose_kernel<4>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
-        default: hipLaunchKernelGGL(slice_transpose_kernel<8>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, c->slice_tables); break;
+        case 1: hipLaunchKernelGGL(slice_transpose_kernel<1>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        case 2: hipLaunchKernelGGL(slice_transpose_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        case 4: hipLaunchKernelGGL(slice_transpose_kernel<4>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        default: hipLaunchKernelGGL(slice_transpose_kernel<8>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
         }
     }
     HIP_OK(hipGetLastError());
@@ -1542,6 +1550,76 @@ int launch_search_sliced(commet_ctx *c, const commet_readset *rs, int g, int gw,
     case 4: hipLaunchKernelGGL(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
     default: hipLaunchKernelGGL(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
     }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- wide rows (slice_search.hpp): every chunk filter of the job — or as many as the table budget allows — in one table ----
+struct WidePlan {
+    uint32_t nw = 0;              // words per row that hold chunks (a multiple of WIDE_GROUP_WORDS); 0 = no wide pass
+    uint32_t rw = 0;              // row stride in words (a multiple of 16: rows start on 64-byte boundaries)
+    uint64_t chunks_per_pass = 0;
+    int lpr = 0, np = 0;          // lanes per read, 16-byte pieces per lane
+};
+
+WidePlan wide_plan(const commet_ctx *c, uint64_t n_chunks, int slice_gw)
+{
+    WidePlan w;
+    if (!slice_gw || c->slice_wide == 1) return w;
+    if (c->slice_wide == 0 && n_chunks <= 256) return w;             // one table of the narrow kind holds them all
+    const uint64_t groups = (n_chunks + 255) / 256;
+    // four tables of 2^k rows: 16 bytes per row word and key; at most a third of what is free now, and 48 GiB
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return w;
+    const uint64_t have = (uint64_t) c->wide_table_words * 4;        // (what the context already holds counts as free)
+    const uint64_t budget = std::min<uint64_t>(((uint64_t) free_b + have) / 3, 48ull << 30);
+    uint64_t cap = std::min<uint64_t>(WIDE_MAX_ROW_WORDS, budget / (16ull << c->k));
+    if (c->wide_cap_words) cap = std::min<uint64_t>(cap, c->wide_cap_words);
+    cap = cap / WIDE_GROUP_WORDS * WIDE_GROUP_WORDS;
+    if (cap < WIDE_GROUP_WORDS) return w;
+    const uint64_t passes = (groups * WIDE_GROUP_WORDS + cap - 1) / cap;
+    const uint64_t groups_per_pass = (groups + passes - 1) / passes;
+    w.nw = (uint32_t) (groups_per_pass * WIDE_GROUP_WORDS);
+    w.rw = (w.nw + 15u) & ~15u;
+    w.chunks_per_pass = groups_per_pass * 256;
+    const uint32_t pieces = w.nw / 4;
+    w.lpr = pieces <= 8 ? 8 : pieces <= 16 ? 16 : pieces <= 32 ? 32 : 64;
+    w.np = pieces <= 64 ? 1 : 2;
+    return w;
+}
+
+int ensure_wide_tables(commet_ctx *c, const WidePlan &w)
+{
+    const uint64_t words = ((uint64_t) 4 * w.rw) << c->k;
+    if (c->wide_table_words >= words) return 0;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    (void) hipFree(c->wide_tables);
+    c->wide_tables = nullptr, c->wide_table_words = 0;
+    if (hipMalloc((void **) &c->wide_tables, words * 4) != hipSuccess) {
+        (void) hipGetLastError();
+        return 1;                                                    // the caller falls back to the narrow tables
+    }
+    c->wide_table_words = words;
+    return 0;
+}
+
+int launch_search_wide(commet_ctx *c, const commet_readset *rs, const WidePlan &w, int g, const uint64_t *d_sel, uint64_t *d_tags,
+                       unsigned long long *d_counters, uint32_t cstride)
+{
+    if (rs->n_reads == 0) return 0;
+    const uint64_t reads_per_block = 4ull * (64 / w.lpr);
+    const uint64_t blocks = (rs->n_reads + reads_per_block - 1) / reads_per_block;
+    if (blocks >= (1ull << 31)) return fail("search launch too large");
+    const dim3 grid((unsigned) blocks), block(256);
+    const int t = t_eff(c, rs);
+    KScope ks(c, "search_wide_kernel", c->stream);
+#define COMMET_WIDE(LPR, NP) hipLaunchKernelGGL((search_wide_kernel<LPR, NP>), grid, block, 0, c->stream, rs->view(), c->wide_tables, c->k, t, g, w.nw, w.rw, d_sel, d_tags, d_counters, cstride)
+    if (w.np == 2) COMMET_WIDE(64, 2);
+    else if (w.lpr == 64) COMMET_WIDE(64, 1);
+    else if (w.lpr == 32) COMMET_WIDE(32, 1);
+    else if (w.lpr == 16) COMMET_WIDE(16, 1);
+    else COMMET_WIDE(8, 1);
+#undef COMMET_WIDE
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1764,11 +1842,47 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             hc[i].first = ch.first;
             hc[i].count = ch.n_reads ? ch.last - ch.first + 1 : 0;
         }
-        if (ensure_slice_buffers(c, slice_gw, n_chunks)) rc = 1;
+        WidePlan wide = wide_plan(c, n_chunks, slice_gw);
+        if (wide.nw && ensure_wide_tables(c, wide)) wide = WidePlan();   // no room for the wide tables: groups of 256 chunks as before
+        if (ensure_slice_buffers(c, wide.nw ? 8 : slice_gw, n_chunks)) rc = 1;
         if (!rc && hipMemcpy(c->d_slice_chunks, hc.data(), n_chunks * sizeof(SliceChunk), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail("chunk descriptor upload failed");
+        // wide rows: the filters of a pass's chunks (all of them when the tables fit) are built 256 at a time into their
+        // columns of the rows, then every search set is scanned ONCE per pass
+        for (uint64_t c0 = 0; wide.nw && c0 < n_chunks && !rc; c0 += wide.chunks_per_pass) {
+            const uint64_t c1 = std::min<uint64_t>(n_chunks, c0 + wide.chunks_per_pass);
+            hipEvent_t a = nullptr, b = nullptr;
+            if (timed) {
+                if (new_event(&a) || new_event(&b)) { rc = 1; break; }
+                (void) hipEventRecord(a, c->stream);
+            }
+            for (uint64_t ci = c0; ci < c1 && !rc; ci += 256) {
+                const int g = (int) std::min<uint64_t>(256, c1 - ci);
+                if (launch_slice_build(c, index_rs, plan.dense ? nullptr : index_rs->d_sel, ci, g, 8, c->wide_tables, wide.rw,
+                                       (uint32_t) ((ci - c0) / 256 * WIDE_GROUP_WORDS))) rc = 1;
+                n_index_launches += 2;
+            }
+            if (rc) break;
+            if (timed) {
+                (void) hipEventRecord(b, c->stream);
+                e_idx0.push_back(a);
+                e_idx1.push_back(b);
+            }
+            for (int s = 0; s < n_search && !rc; ++s) {
+                const commet_readset *rs = search_rs[s];
+                if (launch_search_wide(c, rs, wide, (int) (c1 - c0), all_visited[s] ? nullptr : rs->d_sel, rs->d_tags,
+                                       d_cnt + 2 * (c0 * n_search + s), (uint32_t) (2 * n_search))) { rc = 1; break; }
+                if (rs->n_reads) ++n_search_launches;
+                if (timed) {
+                    hipEvent_t d = nullptr;
+                    if (new_event(&d)) { rc = 1; break; }
+                    (void) hipEventRecord(d, c->stream);
+                    e_set[s].push_back(d);
+                }
+            }
+        }
         const uint64_t G = 32ull * slice_gw;
-        for (uint64_t ci = 0; ci < n_chunks && !rc; ci += G) {
+        for (uint64_t ci = 0; ci < n_chunks && !rc && !wide.nw; ci += G) {
             const int g = (int) std::min<uint64_t>(G, n_chunks - ci);
             hipEvent_t a = nullptr, b = nullptr;
             if (timed) {
@@ -2009,6 +2123,16 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "slice_words")) {       // chunk filters per pass / 32 in the sliced regime: 0 auto, 1, 2, 4 or 8
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail("slice_words must be 0, 1, 2, 4 or 8");
         c->slice_gw = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "slice_wide")) {        // wide rows in the many-small-chunks regime: 0 auto (more than 256 chunks), 1 never, 2 always
+        if (value < 0 || value > 2) return fail("slice_wide must be 0, 1 or 2");
+        c->slice_wide = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "slice_wide_words")) {  // cap on the words per wide row (32 chunk filters each; tests: several passes); 0 = the budget decides
+        if (value < 0 || value > 512 || value % 8) return fail("slice_wide_words must be a multiple of 8 in 0..512");
+        c->wide_cap_words = (uint32_t) value;
         return 0;
     }
     if (!strcmp(name, "max_kmer")) {          // chunk size in k-mers (0 = the reference's constant); changes the chunking

@@ -92,10 +92,12 @@ __device__ __forceinline__ void transpose32(uint32_t (&x)[32])
     }
 }
 
-// tables[(((plane << k) + key) * GW) + cw] bit j = stage plane of chunk 32 * cw + j, bit key (0 for chunks >= g)
+// tables[(((plane << k) + key) * row_words) + col0 + cw] bit j = stage plane of chunk 32 * cw + j, bit key (0 for chunks >= g).
+// row_words = GW, col0 = 0: the table of one group of 32 * GW chunks; wide rows (below): the group's GW words sit at
+// column col0 of rows of row_words words that hold many groups side by side.
 template <int GW>
 __global__ __launch_bounds__(256) void slice_transpose_kernel(const uint32_t *__restrict__ stage, int k, int g,
-                                                              uint32_t *__restrict__ tables)
+                                                              uint32_t *__restrict__ tables, uint32_t row_words, uint32_t col0)
 {
     const uint64_t pw = 1ull << (k - 5);
     const uint64_t idx = blockIdx.x * 256ull + threadIdx.x;
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(256) void slice_transpose_kernel(const uint32_t *__
             x[j] = c < g ? stage[(((uint64_t) c * 4 + plane) << (k - 5)) + i] : 0u;
         }
         transpose32(x);
-        uint32_t *dst = tables + (((plane << k) + 32 * i) * GW) + cw;
+        uint32_t *dst = tables + (((plane << k) + 32 * i) * row_words) + col0 + cw;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) dst[(uint64_t) b * GW] = x[b];
+        for (int b = 0; b < 32; ++b) dst[(uint64_t) b * row_words] = x[b];
     }
 }
 
@@ -292,6 +294,224 @@ __global__ __launch_bounds__(256) void search_sliced_kernel(ReadsView rv, const 
     const uint64_t fb = __ballot(found);
     if (lane == 0 && in_range && tags && fb) tags[word] = tagw | fb;
     if (counters && found) atomicAdd(&counters[(uint64_t) found_chunk * cstride + 1], 1ull);   // found reads only: rare
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide rows: ALL chunk filters of the job (or as many as the table budget allows) side by side in one table.
+//
+// search_sliced_kernel is bound by the rate of L2-missing requests (one 32-byte entry of a 64-byte sector per request:
+// 700 GB of HBM traffic per pass at configs[4], 41 passes of 20 M reads, profiles/r03_c5_before), and two things it counts
+// on do not hold at k = 21 with 10 421 chunk filters: the short circuit a -> b -> c -> d prunes nothing at entry granularity
+// (an entry of 256 chunks is non-zero after A, after A & B and mostly after A & B & C), and plane D hardly filters at all —
+// keyd = keya | keyb has three one bits in four, so index and query keys crowd into the same few heavy keys and a random
+// window passes plane D with probability 0.68, not 0.11.  A window is therefore a four-lane hit in a chunk that shares
+// nothing with the read with probability 9e-4, "two hit windows" is true for ~130 chunks per read, and the exact replay
+// of those candidates was most of the kernel's requests.
+//
+// Here a key's entry is a ROW of up to 16 384 chunk bits (row_words words; 10 421 chunks = 328 words = 1.3 KB; the four
+// tables of configs[4] are 11 GB of the 288 GB), and a group of LPR lanes works on ONE read: lane l owns the 16-byte pieces
+// l, l + LPR, ... of every row.
+//   (1) row pass — per window, both strands: the rows of planes A, B, C (plane D is left to the replay: it would add a
+//       third to the bytes and removes a third of the candidates) are ANDed, six coalesced row fetches of which every
+//       byte is used; no divergence, no short circuit, the set is scanned once.  Candidate rule, per chunk bit and
+//       strand: the windows are cut into blocks of k; t non-overlapping hits lie in t different blocks, and hit j of the
+//       reference's greedy scan ends at or before last - (t - j) k.  With J = min(t, 3): a chunk can find the read on a
+//       strand only if J different blocks hold a hit among the windows ending at or before last - (t - J) k (a 2-bit
+//       saturating block counter per chunk bit: three masks per strand).  ~2 candidates per read at configs[4].
+//   (2) exact replay of the candidate chunks, smallest first, by the group with lane = window: every lane tests one
+//       window's four bits in chunk c, the ballot is the strand's hit mask, and the reference's greedy rule
+//       (search_reads.h:45-83: a hit, then the next complete window k bases on, t hits tag the read) is walked on the
+//       mask, forward strand first.  The first chunk that finds the read tags it — the reference's chunk order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t WIDE_MAX_ROW_WORDS = 512;             // 16 384 chunks per pass: LPR = 64 lanes x NP = 2 pieces of 4 words
+constexpr uint32_t WIDE_GROUP_WORDS = 8;                 // rows are filled in groups of 256 chunks (slice_build + transpose<8>)
+
+__device__ __forceinline__ uint4 and3(const uint4 &a, const uint4 &b, const uint4 &c)
+{
+    return make_uint4(a.x & b.x & c.x, a.y & b.y & c.y, a.z & b.z & c.z, a.w & b.w & c.w);
+}
+__device__ __forceinline__ void or_into(uint4 &d, const uint4 &a) { d.x |= a.x, d.y |= a.y, d.z |= a.z, d.w |= a.w; }
+// one more block with a hit for the chunk bits set in cur: 2-bit saturating counter (c1 c0), cur cleared
+__device__ __forceinline__ void wide_fold(uint32_t &cur, uint32_t &c0, uint32_t &c1)
+{
+    const uint32_t add = cur & ~(c0 & c1);
+    c1 |= c0 & add;
+    c0 ^= add;
+    cur = 0;
+}
+__device__ __forceinline__ void wide_fold(uint4 &cur, uint4 &c0, uint4 &c1)
+{
+    wide_fold(cur.x, c0.x, c1.x), wide_fold(cur.y, c0.y, c1.y), wide_fold(cur.z, c0.z, c1.z), wide_fold(cur.w, c0.w, c1.w);
+}
+__device__ __forceinline__ uint4 wide_at_least(const uint4 &c0, const uint4 &c1, int J)
+{
+    if (J <= 1) return make_uint4(c0.x | c1.x, c0.y | c1.y, c0.z | c1.z, c0.w | c1.w);
+    if (J == 2) return c1;
+    return make_uint4(c0.x & c1.x, c0.y & c1.y, c0.z & c1.z, c0.w & c1.w);
+}
+__device__ __forceinline__ uint32_t wide_word(const uint4 &v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int LPR, int NP>
+__global__ __launch_bounds__(256) void search_wide_kernel(ReadsView rv, const uint32_t *__restrict__ tables, int k, int t, int g,
+                                                          uint32_t nw, uint32_t rw, const uint64_t *__restrict__ sel,
+                                                          uint64_t *__restrict__ tags, unsigned long long *__restrict__ counters,
+                                                          uint32_t cstride)
+{
+    constexpr int RPW = 64 / LPR;                         // reads per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, sl = lane % LPR;
+    const uint64_t r = ((uint64_t) blockIdx.x * 4 + wave) * RPW + grp;
+    bool active = r < rv.n;
+    if (active && sel) active = (sel[r >> 6] >> (r & 63)) & 1ull;
+    if (active && tags) active = !((tags[r >> 6] >> (r & 63)) & 1ull);
+    const uint64_t plane_stride = ((uint64_t) rw) << k;   // words per table
+    const uint32_t *TA = tables, *TB = TA + plane_stride, *TC = TB + plane_stride, *TD = TC + plane_stride;
+    uint64_t t0 = 0;
+    uint32_t len = 0;
+    if (active) read_extent(rv, r, t0, len);
+    const uint32_t *p = rv.planes + 3 * t0;
+    const int sh = 32 - k;
+    const uint32_t mask = (1u << k) - 1u;
+    const int last = (int) len - 1;
+    const int J = min(t, 3);
+    const int lim = active ? last - (t - J) * k : -1;     // hit J of a strand's scan ends at or before lim
+    uint4 cand_f[NP], cand_r[NP];
+    bool have[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) have[i] = 4u * (uint32_t) (sl + LPR * i) < nw;
+    // (1) row pass over the windows ending at or before lim; every lane of the group rolls the same window
+    {
+        uint4 cur_f[NP], cur_r[NP], f0[NP], f1[NP], r0[NP], r1[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) cur_f[i] = cur_r[i] = f0[i] = f1[i] = r0[i] = r1[i] = make_uint4(0, 0, 0, 0);
+        uint32_t wh = 0, wl = 0, run = 0;
+        int in_block = 0;                                  // window positions since the block began
+        for (uint32_t w = 0; (int) (w * 32u) <= lim; ++w) {
+            const uint32_t hi = p[3 * w], lo = p[3 * w + 1], va = p[3 * w + 2];
+            const uint32_t nb = (uint32_t) min(32, lim - (int) (w * 32u) + 1);
+            for (uint32_t j = 0; j < nb; ++j) {
+                wh = (wh >> 1) | (((hi >> j) & 1u) << (k - 1));
+                wl = (wl >> 1) | (((lo >> j) & 1u) << (k - 1));
+                run = ((va >> j) & 1u) ? run + 1 : 0;
+                if ((int) (32u * w + j) < k - 1) continue;              // not a window position yet
+                if (run >= (uint32_t) k) {
+                    const uint32_t ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                    const uint32_t ra = ~wh & mask, rb = ~wl & mask;
+                    bool selfp;
+                    const uint32_t addr = psi_a<uint32_t>(ka, k, selfp);
+                    const uint4 *af = (const uint4 *) (TA + (uint64_t) addr * rw), *ar = (const uint4 *) (TA + (uint64_t) (selfp ? addr : addr ^ 1u) * rw);
+                    const uint4 *bf = (const uint4 *) (TB + (uint64_t) kb * rw), *br = (const uint4 *) (TB + (uint64_t) rb * rw);
+                    const uint4 *cf = (const uint4 *) (TC + (uint64_t) (ka ^ kb) * rw), *cr = (const uint4 *) (TC + (uint64_t) (ra ^ rb) * rw);
+                    uint4 x[NP][6];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        if (!have[i]) continue;
+                        const int pc = sl + LPR * i;
+                        x[i][0] = af[pc], x[i][1] = bf[pc], x[i][2] = cf[pc];
+                        x[i][3] = ar[pc], x[i][4] = br[pc], x[i][5] = cr[pc];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        if (!have[i]) continue;
+                        or_into(cur_f[i], and3(x[i][0], x[i][1], x[i][2]));
+                        or_into(cur_r[i], and3(x[i][3], x[i][4], x[i][5]));
+                    }
+                }
+                if (++in_block == k) {                      // the block is complete
+                    in_block = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) wide_fold(cur_f[i], f0[i], f1[i]), wide_fold(cur_r[i], r0[i], r1[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            wide_fold(cur_f[i], f0[i], f1[i]), wide_fold(cur_r[i], r0[i], r1[i]);   // the last, partial block
+            cand_f[i] = wide_at_least(f0[i], f1[i], J), cand_r[i] = wide_at_least(r0[i], r1[i], J);
+            if (!have[i]) cand_f[i] = cand_r[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // (2) exact replay of the candidate chunks, smallest chunk first.  The loops are uniform over the wave (ballots and
+    // shuffles inside); a group without work runs them with its predicate off.
+    int found_chunk = -1;
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu;                       // this lane's smallest candidate chunk (its words ascend with i)
+        if (found_chunk < 0) {
+#pragma unroll
+            for (int i = NP - 1; i >= 0; --i) {
+                const uint32_t w0 = 4u * (uint32_t) (sl + LPR * i);
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const uint32_t m = wide_word(cand_f[i], (uint32_t) j) | wide_word(cand_r[i], (uint32_t) j);
+                    if (m) best = (w0 + (uint32_t) j) * 32u + (uint32_t) __ffs((int) m) - 1u;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) best = min(best, (uint32_t) __shfl_xor((int) best, o, LPR));   // the group's smallest
+        const bool go = best != 0xFFFFFFFFu && (int) best < g;
+        if (!__any(best != 0xFFFFFFFFu)) break;
+        const uint32_t cw = best >> 5, cb = best & 31u;
+        // the owner of word cw reads the chunk's strand flags and drops the bits (columns past the last chunk hold zeros,
+        // so best >= g cannot happen; such a bit would be dropped here as well)
+        bool mine_f = false, mine_r = false;
+        if (best != 0xFFFFFFFFu) {
+            const uint32_t pc = cw >> 2, wj = cw & 3u, keep = ~(1u << cb);
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (pc == (uint32_t) (sl + LPR * i)) {
+                    mine_f = (wide_word(cand_f[i], wj) >> cb) & 1u, mine_r = (wide_word(cand_r[i], wj) >> cb) & 1u;
+                    if (wj == 0) cand_f[i].x &= keep, cand_r[i].x &= keep;
+                    else if (wj == 1) cand_f[i].y &= keep, cand_r[i].y &= keep;
+                    else if (wj == 2) cand_f[i].z &= keep, cand_r[i].z &= keep;
+                    else cand_f[i].w &= keep, cand_r[i].w &= keep;
+                }
+        }
+        uint64_t bf = __ballot(mine_f), br = __ballot(mine_r);
+        if constexpr (LPR < 64) bf = (bf >> (grp * LPR)) & ((1ull << LPR) - 1ull), br = (br >> (grp * LPR)) & ((1ull << LPR) - 1ull);
+        bool found = false;
+        for (int strand = 0; strand < 2; ++strand) {
+            const bool flagged = go && (strand ? br != 0 : bf != 0);   // a strand without J hit blocks cannot find the read
+            int seen = 0, next_ok = 0;
+            bool dead = false;
+            for (int qb = k - 1; __any(flagged && !found && !dead && qb <= last && qb + (t - seen - 1) * k <= last); qb += LPR) {
+                const int q = qb + sl;
+                bool hit = false;
+                if (flagged && !found && !dead && q <= last) {
+                    ItemWords<uint32_t> it;
+                    it.load(p, (uint32_t) q >> 5);
+                    uint32_t wh, wl;
+                    if (it.window((uint32_t) q & 31u, k, mask, wh, wl)) {
+                        uint32_t ka, kb;
+                        if (strand == 0) ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                        else ka = ~wh & mask, kb = ~wl & mask;
+                        const uint32_t va = TA[(uint64_t) psi_a<uint32_t>(ka, k) * rw + cw], vb = TB[(uint64_t) kb * rw + cw];
+                        const uint32_t vc = TC[(uint64_t) (ka ^ kb) * rw + cw], vd = TD[(uint64_t) (ka | kb) * rw + cw];
+                        hit = ((va & vb & vc & vd) >> cb) & 1u;
+                    }
+                }
+                uint64_t m = __ballot(hit);
+                if constexpr (LPR < 64) m = (m >> (grp * LPR)) & ((1ull << LPR) - 1ull);
+                while (m && !found && !dead) {
+                    const int qq = qb + (__ffsll((long long) m) - 1);
+                    m &= m - 1ull;
+                    if (qq < next_ok) continue;
+                    if (qq + (t - seen - 1) * k > last) {   // the missing hits no longer fit behind this window (exact, see search_kernel)
+                        dead = true;
+                        break;
+                    }
+                    ++seen;
+                    next_ok = qq + k;                       // hash.clear(), search_reads.h:60: the next complete window ends k bases on
+                    if (seen >= t) found = true;
+                }
+            }
+        }
+        if (go && found) found_chunk = (int) best;
+    }
+    if (found_chunk >= 0 && sl == 0) {
+        if (tags) atomicOr((unsigned long long *) &tags[r >> 6], 1ull << (r & 63));
+        if (counters) atomicAdd(&counters[(uint64_t) found_chunk * cstride + 1], 1ull);   // found reads only: rare
+    }
 }
 
 }  // namespace commet

@@ -246,10 +246,14 @@ def test_c5_regime_200k_slice_matches_cpu_checker(tmp_path):
         for words in (1, 8):
             ctx.set_option("slice_words", words)
             res[words] = ctx.index_and_search(irs, [qrs])
+        ctx.set_option("slice_words", 0)
+        ctx.set_option("slice_wide", 2)                                    # wide rows (auto only above 256 chunks): one pass, LPR = 8
+        res["wide"] = ctx.index_and_search(irs, [qrs])
+        ctx.set_option("slice_wide", 0)
         ctx.set_option("slice_mode", 1)
         res["slots"] = ctx.index_and_search(irs, [qrs])
     chunks = oracle_pool.chunks_from_counts(kc, ob.max_kmer(k))
-    assert len(chunks) > 100
+    assert len(chunks) > 100 and res["wide"][2]["search_launches"] == 1
     found, fed, first = oracle_pool.search_sample_over_chunks(str(tmp_path), "c5", b0, L, chunks, k, t, b1, first_chunk=True)
     assert fed == [int(kc[a:e].sum()) for a, e in chunks]
     searched_last = n - int(((first >= 0) & (first < len(chunks) - 1)).sum())
@@ -260,3 +264,62 @@ def test_c5_regime_200k_slice_matches_cpu_checker(tmp_path):
         assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == \
             (sum(e - a for a, e in chunks), searched_last, int(found.sum())), name
     assert found[: int(0.4 * n)].mean() > 0.5 and found.sum() > 50_000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# search_wide_kernel: every (lanes per read, pieces per lane) instantiation, one and several passes
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,t,L,n_chunks,cap_words,inst", [
+    (12, 1, 40, 300, 0, "8x1"),          # 2 groups of 256 chunks -> 16 words per row -> 8 lanes per read
+    (14, 2, 60, 1500, 0, "16x1"),        # 48 words
+    (16, 2, 80, 3000, 0, "32x1"),        # 96 words
+    (15, 3, 90, 6000, 0, "64x1"),        # 192 words
+    (13, 2, 50, 9000, 0, "64x2"),        # 288 words: two 16-byte pieces per lane
+    (16, 2, 80, 2900, 48, "16x1"),       # 12 groups in 2 passes of 6 (rows capped at 48 words)
+    (21, 5, 150, 700, 8, "8x1"),         # configs[4]'s k, t, read length; 3 passes of one group
+])
+def test_wide_rows_instantiations_match_cpu_checker(k, t, L, n_chunks, cap_words, inst):
+    """max_kmer = 1 (the library's test hook) makes every chunk one read (plus the dropped look-ahead read), so
+    a few thousand reads give the thousands of chunk filters the wide instantiations are chosen by; the CPU checker runs
+    the reference's chunk loop with the same constant."""
+    import commet_amd
+    rng = np.random.default_rng(77 * k + n_chunks)
+    idx_reads = util.random_reads(rng, 2 * n_chunks, L, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 1200, L, L, share=0.5, n_rate=0.002)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("max_kmer", 1)
+        ctx.set_option("slice_mode", 2)
+        ctx.set_option("slice_wide_words", cap_words)
+        irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+        kc = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        times = ctx.kernel_times()
+        ctx.set_option("slice_wide", 1)                                    # the narrow tables, 256 chunks per pass
+        narrow = ctx.index_and_search(irs, [qrs])
+    chunks = oracle_pool.chunks_from_counts(kc, 1)
+    assert abs(len(chunks) - n_chunks) <= n_chunks // 50 and info["n_chunks"] == len(chunks)
+    groups = (len(chunks) + 255) // 256
+    passes = 1 if not cap_words else -(-groups * 8 // cap_words)
+    assert info["search_launches"] == passes and times["search_wide_kernel"][0] == passes
+    nw = -(-groups // passes) * 8
+    pieces = nw // 4
+    assert inst == f"{8 if pieces <= 8 else 16 if pieces <= 16 else 32 if pieces <= 32 else 64}x{1 if pieces <= 64 else 2}"
+    found = np.zeros(len(q_reads) // 8 + 1, dtype=np.uint8)
+    searched_last = 0
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
+        active = ~found
+        searched_last = int(util.bools_from_bits(active, len(q_reads)).sum())
+        fnd, _ = f.search(t, qb, qo, active)
+        found |= fnd
+        f.close()
+    for tg, sg in ((tags, stats), (narrow[0], narrow[1])):
+        assert np.array_equal(tg[0], found)
+        assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
+        assert sg[0]["searched"] == searched_last and sg[0]["indexed"] == sum(e - a for a, e in chunks)
+    assert stats[0]["shared"] > 60

@@ -91,6 +91,43 @@ def test_job_sliced_regime_matches_oracle(tmp_path, seed):
                 pos += n
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_job_wide_rows_match_oracle(tmp_path, seed):
+    """the wide rows of the many-small-chunks regime (slice_search.hpp, search_wide_kernel: every chunk filter of a pass
+    side by side in one table, a group of lanes per read) forced on the randomised scenarios: multi-file sets, filter
+    bvs incl. all-zero ones, ragged / short / N-rich reads, t = 1..4; with the row capped at 8 words the jobs of more
+    than 256 chunks take several passes"""
+    import commet_amd as commet
+    scn = Scenario(str(tmp_path / "scn"), 700 + seed, k=[12, 13, 16, 20, 21, 24][seed % 6], n_scale=[1.0, 4.0, 12.0][seed % 3])
+    out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
+    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o)
+    assert rc == 0
+    with commet.Context(k=scn.k, t=scn.t) as ctx:
+        irs, isel = _load_set(commet, ctx, scn.sets[scn.index_name], scn.dir)
+        srs, ssel = [], []
+        for nme in sorted(scn.search_names):
+            r, s = _load_set(commet, ctx, scn.sets[nme], scn.dir)
+            srs.append(r)
+            ssel.append(s)
+        ctx.set_option("slice_mode", 2)
+        ctx.set_option("slice_wide", 2)
+        ctx.set_option("slice_wide_words", [0, 8][(seed // 6) % 2])
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        if chunks and any(r.num_reads for r in srs):
+            assert "search_wide_kernel" in ctx.kernel_times() and "search_sliced_kernel" not in ctx.kernel_times()
+        by_name = {r["name"]: r for r in res}
+        for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
+            o = by_name[nme]
+            assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
+            pos = 0
+            for fa, _, reads, _ in scn.sets[nme]:
+                _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
+                pos += n
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_job_tiled_search_matches_oracle(tmp_path, seed):
     """the tiled search (tile_search.hpp: the set's lane-a addresses sorted by address slice once, probed slice by slice out
