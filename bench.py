@@ -209,23 +209,26 @@ def matrix_leg(args, ranks):
     (each rank generates its share), filter + load + jobs all timed by the driver."""
     from commet_amd import matrix, synth
     root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
-    token = ranks.broadcast_object(f"commet_bench_{os.getuid()}_{os.getpid()}" if ranks.rank == 0 else None)
-    work = os.path.join(root, token)
-    os.makedirs(work, exist_ok=True)
-    S, n, L = args.matrix_sets, args.matrix_reads, args.read_len
-    t0 = time.perf_counter()
-    mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
-    if mine:
-        import multiprocessing as mp
-        with mp.get_context("spawn").Pool(min(len(mine), max(1, host_cores() // 2))) as pool:
-            pool.map(synth.write_set_fasta, mine, chunksize=1)
-    if ranks.rank == 0:
-        with open(os.path.join(work, "sets.txt"), "w") as fh:
-            for s in range(S):
-                fh.write(f"S{s}: {work}/set{s}.fa\n")
-    ranks.barrier()
-    gen_s = time.perf_counter() - t0
+    # rank 0 makes the work directory (mkdtemp: a fresh name, mode 0700 — /dev/shm is shared with other users)
+    work = ranks.broadcast_object(tempfile.mkdtemp(prefix="commet_bench_", dir=root) if ranks.rank == 0 else None)
+    S, L = args.matrix_sets, args.read_len
+    # one GPU: BASELINE configs[2] (10 x 10 M reads); several: configs[3] (10 x 50 M reads, the matrix sharded over the GPUs)
+    n = args.matrix_reads or (10_000_000 if ranks.world == 1 else 50_000_000)
+    which = {(10, 10_000_000): "BASELINE configs[2]", (10, 50_000_000): "BASELINE configs[3]"}.get((S, n), "custom size")
     try:
+        t0 = time.perf_counter()
+        mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
+        if mine:
+            import multiprocessing as mp
+            # (a 50 M-read set is ~12 GB of generator state per worker process)
+            with mp.get_context("spawn").Pool(min(len(mine), max(1, host_cores() // (2 * ranks.world) if ranks.world > 1 else host_cores() // 2))) as pool:
+                pool.map(synth.write_set_fasta, mine, chunksize=1)
+        if ranks.rank == 0:
+            with open(os.path.join(work, "sets.txt"), "w") as fh:
+                for s in range(S):
+                    fh.write(f"S{s}: {work}/set{s}.fa\n")
+        ranks.barrier()
+        gen_s = time.perf_counter() - t0
         res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False)
     finally:
         ranks.barrier()
@@ -236,10 +239,17 @@ def matrix_leg(args, ranks):
     keep = ("filter_s", "load_s", "jobs_s", "set_wait_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world",
             "filter_overlaps_load", "load_overlaps_jobs")
     out = {f: (round(res[f], 4) if isinstance(res[f], float) else res[f]) for f in keep}
-    out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix (BASELINE configs[2]) over {ranks.world} GPU(s): "
+    per_rank = [{f: (round(v, 4) if isinstance(v, float) else v) for f, v in p.items()} for p in res["per_rank"]]
+    busy = [p["jobs_s"] + p.get("set_wait_s", 0.0) for p in per_rank]
+    out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix ({which}) over {ranks.world} GPU(s): "
                         f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",
                generate_s=round(gen_s, 2),
-               per_rank=[{f: (round(v, 4) if isinstance(v, float) else v) for f, v in p.items()} for p in res["per_rank"]])
+               # how evenly the static cut of the pairs loaded the ranks: slowest / mean of the ranks' job time (1.0 = even),
+               # and what the cut predicted for every rank (its share of the pairs' cost) beside what it took
+               imbalance=round(max(busy) / (sum(busy) / len(busy)), 4) if busy and sum(busy) > 0 else None,
+               predicted_vs_actual_share=[{"rank": p["rank"], "predicted": p.get("predicted_share"),
+                                           "actual": round(b / sum(busy), 4) if sum(busy) > 0 else None} for p, b in zip(per_rank, busy)],
+               per_rank=per_rank)
     return out
 
 
@@ -282,8 +292,14 @@ def main():
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up
 
-    for _ in range(args.warmup):
+    # the very first job of a context also allocates its workspaces: reported (cold_context_first_job_ms), never timed
+    cold_context_first_job_s = None
+    for w in range(args.warmup):
+        t_c = time.perf_counter()
         ctx.index_and_search(irs, [qrs])
+        if w == 0:
+            ctx.synchronize()
+            cold_context_first_job_s = time.perf_counter() - t_c
 
     acc = dict(index_kernel_ms=0.0, search_ms=0.0, zero_ms=0.0, index_launches=0, search_launches=0)
     last = {}
@@ -296,6 +312,16 @@ def main():
 
     elapsed = sharding.timed_region(ranks, ctx.synchronize, step, args.steps)
     stats, info = last["stats"], last["info"]
+
+    # the first job on a SET also builds what is cached with the set (the tiled search's query list): not part of the
+    # steady-state `value`, reported beside it — the list is dropped, then one more job is timed (warm context)
+    query_list_bytes = qrs.cache_bytes
+    qrs.drop_cache()
+    ctx.synchronize()
+    t_c = time.perf_counter()
+    ctx.index_and_search(irs, [qrs])
+    ctx.synchronize()
+    first_job_s = time.perf_counter() - t_c
 
     # ---- untimed extras (rank 0): P_ref, per-kernel times, the random-gather ceiling ---------------------------
     probes, ktimes, gather_ceiling = None, None, None
@@ -383,10 +409,16 @@ def main():
                                             "frac": round(rps / gather_ceiling, 4),
                                             "what": "64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against commet_membench's "
                                                     "random 4-byte gathers over a filter-sized table, measured in this run"}
+            # what a step cannot avoid moving: both packed sets read once (12 bytes per 32 bases + a triple per read), every
+            # chunk's filter written once and read once (2^(k-1) bytes each way), the tag bits
+            triple_bytes = 12 * (L // 32 + 1)
+            compulsory = (info["reads_indexed"] + n) * triple_bytes + info["n_chunks"] * 2 * (1 << (k - 1)) + n // 8
+            roofline["compulsory_bytes"] = compulsory
             if step_bytes and covered:
                 roofline["whole_step"] = {"traffic": round(step_bytes), "device_ms": round(step_dev_ms, 3),
                                           "GBps": round(step_bytes / (step_dev_ms * 1e-3) / 1e9, 1),
                                           "frac": round(step_bytes / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                roofline["traffic_over_compulsory"] = round(step_bytes / compulsory, 2)
         # the contract's figure in REFERENCE probes, kept as detail: one request of ours answers several of them
         idx_bytes_step = info["reads_indexed"] * (L / 4.0) + 4.0 * kmers * 2 * SECTOR
         srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR if probes is not None else None
@@ -406,11 +438,19 @@ def main():
                        "p_ref_probes": probes,
                        "reference_model_bytes_per_step": {"index": round(idx_bytes_step), "search": round(srch_bytes_step) if srch_bytes_step else None,
                                                           "note": "SURVEY 8d's sector model of the REFERENCE's accesses; not what this implementation moves"},
+                       # a job on a search set that was never scanned (warm context): builds the set's query list as well
+                       "first_job_ms": round(first_job_s * 1e3, 3), "first_job_reads_per_s": round(n / first_job_s, 1),
+                       "query_list_bytes": query_list_bytes,
+                       "cold_context_first_job_ms": round(cold_context_first_job_s * 1e3, 3) if cold_context_first_job_s else None,
                        "upload_and_pack_s": round(upload_s, 3), "upload_second_set_s": round(upload_s - upload_first_s, 3),
                        "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
                        "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
                        "matrix": matrix_detail},
         }
+        if matrix_detail and "error" not in matrix_detail:
+            # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
+            out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
+                                                           "jobs_s", "imbalance", "predicted_vs_actual_share")}
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(args, b0, b1)
         print(json.dumps(out), flush=True)

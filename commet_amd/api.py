@@ -147,6 +147,12 @@ class Context:
         self._check(self._lib.commet_kernel_times(self._h, arr, 64, C.byref(n)))
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 64))}
 
+    def cache_stats(self):
+        """HBM held by the cached query lists of this context's read sets: dict(bytes, budget_bytes, evictions)"""
+        b, g, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.commet_cache_stats(self._h, C.byref(b), C.byref(g), C.byref(e)))
+        return dict(bytes=int(b.value), budget_bytes=int(g.value), evictions=int(e.value))
+
     def membench(self, atomic, table_bytes, n_access):
         ms = C.c_double(0)
         self._check(self._lib.commet_membench(self._h, int(atomic), int(table_bytes), int(n_access), C.byref(ms)))
@@ -207,6 +213,14 @@ class ReadSet:
             rs.add_file(b, o)
         rs.finalize()
         return rs
+
+    @property
+    def cache_bytes(self):
+        """HBM held by data derived from the set and cached with it (the tiled search's query list)"""
+        return int(self._lib.commet_readset_cache_bytes(self._h))
+
+    def drop_cache(self):
+        self._lib.commet_readset_drop_cache(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -173,6 +173,13 @@ struct commet_ctx {
     uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
     uint64_t qres_cap = 0;
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
+    // environment knobs of A/B runs, read ONCE in commet_create (nothing on the launch path calls getenv)
+    int tq_sbits = 0;                 // COMMET_TQ_SBITS: log2 bits per address slice of the query list (0 = TQ_SBITS)
+    unsigned tq_wpx = 64;             // COMMET_TQ_WPX: probe workgroups per XCD (a multiple of the 32 CUs of an XCD keeps the sweep even;
+                                      // measured: 32 or 64 (1 or 2 per CU) 2.3-2.6 ms, 128: 3.7, 256: 4.8)
+    bool stage_reads = true;          // COMMET_NO_STAGE_READS: search_group_kernel without the LDS copy of the lanes' reads
+    bool job_verbose = false;         // COMMET_JOB_VERBOSE: host-side phase times of every commet_index_and_search call on stderr
+    bool ingest_verbose = false;      // COMMET_INGEST_VERBOSE
     int slice_mode = 0;               // option: 0 auto, 1 never, 2 whenever k allows it
     int slice_gw = 0;                 // option: words per bit-sliced entry (32 chunks each); 0 = by the number of chunks
     int slice_wide = 0;               // option: wide rows (all chunk filters side by side, slice_search.hpp): 0 auto (more than 256 chunks), 1 never, 2 whenever the regime applies
@@ -188,6 +195,13 @@ struct commet_ctx {
         hipEvent_t done = nullptr;
     };
     std::vector<IngestBuf> ingest_pool;
+
+    // Derived data cached with the read sets (the tiled search's query lists, ~6 bytes per first-hit window: several times
+    // the packed set itself) is accounted here and given back under pressure: least recently used lists first when the
+    // budget is exceeded, every list that is not part of the running job when a device allocation fails.
+    std::mutex ql_mu;                                 // guards the registry and every query list of the context
+    std::vector<commet_readset *> sets;               // read sets alive on this context
+    uint64_t ql_bytes = 0, ql_budget = 64ull << 30, ql_clock = 0, ql_evictions = 0;
 
     uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
     FilterView view() const
@@ -239,6 +253,7 @@ struct commet_readset {
         uint32_t n_slices = 0, n_pieces = 0;
         int sbits = 0;
         bool built = false, failed = false;
+        uint64_t bytes = 0, last_use = 0;           // HBM held; the context's ql_clock at the last scan that used the list
         void release()
         {
             (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho); (void) hipFree(d_tstart); (void) hipFree(d_tlen);
@@ -246,6 +261,7 @@ struct commet_readset {
         }
     };
     mutable QueryList ql;
+    mutable bool in_job = false;                    // part of the commet_index_and_search call that is running: its list stays
     bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
     uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;
     bool finalized = false;
@@ -282,6 +298,51 @@ struct KScope {
 };
 }  // namespace
 
+namespace {
+// drops one set's query list (caller holds ql_mu); hipFree waits for the kernels that read it
+void drop_query_list(commet_ctx *c, const commet_readset *rs)
+{
+    if (!rs->ql.built && !rs->ql.bytes) return;
+    c->ql_bytes -= std::min(c->ql_bytes, rs->ql.bytes);
+    rs->ql.release();
+    ++c->ql_evictions;
+}
+
+// gives cached query lists back until at most `target` bytes of them are left: least recently used first, never a list
+// of the running job unless `even_in_job` (the job thread itself is out of memory and holds no list between build and
+// launch).  Returns the bytes released.  Caller holds ql_mu.
+uint64_t shrink_query_lists(commet_ctx *c, uint64_t target, bool even_in_job)
+{
+    uint64_t freed = 0;
+    while (c->ql_bytes > target) {
+        const commet_readset *victim = nullptr;
+        for (const commet_readset *rs : c->sets)
+            if (rs->ql.built && (even_in_job || !rs->in_job) && (!victim || rs->ql.last_use < victim->ql.last_use)) victim = rs;
+        if (!victim) break;
+        freed += victim->ql.bytes;
+        drop_query_list(c, victim);
+    }
+    return freed;
+}
+
+// hipMalloc that gives the cached query lists back and tries once more when the device is out of memory
+hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void) hipGetLastError();
+    uint64_t freed;
+    {
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        freed = shrink_query_lists(c, 0, job_thread);
+    }
+    if (!freed) return e;
+    e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) (void) hipGetLastError();
+    return e;
+}
+}  // namespace
+
 extern "C" {
 
 const char *commet_version(void) { return "commet-amd 0.1 (gfx950)"; }
@@ -316,6 +377,12 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->t = min_hits < 1 ? 1 : min_hits;
     if (const char *e = getenv("COMMET_INDEX_LANES")) c->index_lanes = atoi(e) == 1 ? 1 : 2;   // 1: one kernel at a time (per-kernel profiles)
     if (const char *e = getenv("COMMET_TILED")) c->tiled_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("COMMET_TQ_SBITS")) c->tq_sbits = atoi(e);
+    if (const char *e = getenv("COMMET_TQ_WPX")) c->tq_wpx = (unsigned) std::max(1, atoi(e));
+    c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
+    c->job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
+    c->ingest_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    if (const char *e = getenv("COMMET_QUERY_LIST_GB")) c->ql_budget = (uint64_t) (std::max(0.0, atof(e)) * (double) (1ull << 30));
     if (const char *e = getenv("COMMET_SLICE_MODE")) c->slice_mode = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
     if (const char *e = getenv("COMMET_SLICE_WIDE")) c->slice_wide = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
     if (const char *e = getenv("COMMET_SLICE_WORDS")) {
@@ -433,13 +500,17 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     rs->stage_reads = max_reads < STAGE_READS ? (max_reads ? max_reads : 1) : STAGE_READS;
     const uint64_t triples = (max_bases >> 5) + max_reads + 1;
     const uint64_t bw = bitmap_words(max_reads);
-    hipError_t e = hipMalloc((void **) &rs->d_planes, triples * 3 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_goff, (max_reads + 1) * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_kcnt, (max_reads + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_lenmm, 3 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_sel, bw * 8);
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_tags, bw * 8);
-    if (e == hipSuccess) e = hipMalloc((void **) &rs->d_found, bw * 8);
+    // (a set may be made by a second host thread while a job runs: that thread never takes a list of the running job)
+    hipError_t e = dev_alloc(c, (void **) &rs->d_planes, triples * 3 * sizeof(uint32_t), false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_goff, (max_reads + 1) * sizeof(uint64_t), false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_kcnt, (max_reads + 1) * sizeof(uint32_t), false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_lenmm, 3 * sizeof(uint32_t), false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_sel, bw * 8, false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_tags, bw * 8, false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_found, bw * 8, false);
+    // the gap triples between reads and the closing triple are never written by the host packer when the neighbours
+    // come from different staging buffers; no kernel reads them, but a packed image (commet_readset_save) carries them
+    if (e == hipSuccess) e = hipMemsetAsync(rs->d_planes, 0, triples * 3 * sizeof(uint32_t), c->load_stream);
     if (e == hipSuccess) {
         const uint32_t mm[3] = {0xFFFFFFFFu, 0u, 0u};
         e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->load_stream);
@@ -451,6 +522,10 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
         commet_readset_destroy(rs);
         return nullptr;
     }
+    {
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        c->sets.push_back(rs);
+    }
     return rs;
 }
 
@@ -460,6 +535,12 @@ void commet_readset_destroy(commet_readset *rs)
     (void) hipSetDevice(rs->ctx->device);
     (void) hipStreamSynchronize(rs->ctx->load_stream);
     (void) hipStreamSynchronize(rs->ctx->stream);   // (a job that still reads the set)
+    {
+        commet_ctx *c = rs->ctx;
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        c->ql_bytes -= std::min(c->ql_bytes, rs->ql.bytes);
+        c->sets.erase(std::remove(c->sets.begin(), c->sets.end(), rs), c->sets.end());
+    }
     (void) hipFree(rs->d_planes);
     (void) hipFree(rs->d_goff);
     (void) hipFree(rs->d_kcnt);
@@ -651,7 +732,7 @@ int commet_readset_append(commet_readset *rs, const uint8_t *bases, const uint64
                     (unsigned long long) rs->max_bases);
     HipPackSink sink;
     const int T = commet_host::ingest_threads();
-    static const bool verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    const bool verbose = rs->ctx->ingest_verbose;
     const auto tv0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count(); };
     if (!sink.prepare(rs, T)) return fail("cannot allocate the ingest staging buffers");
@@ -716,7 +797,7 @@ commet_readset *commet_readset_from_buffers(commet_ctx *c, const char *const *da
             return nullptr;
         }
     }
-    const bool verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    const bool verbose = c->ingest_verbose;
     const auto tv0 = std::chrono::steady_clock::now();
     commet_readset *rs = nullptr;
     HipPackSink sink;
@@ -852,7 +933,8 @@ int commet_readset_save(const commet_readset *rs, const char *path)
     h.uniform_len = rs->uniform_len, h.min_len = rs->min_len, h.max_len = rs->max_len;
     const PackLayout lay(h);
     const std::string tmp = std::string(path) + ".tmp";
-    const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
+    (void) unlink(tmp.c_str());                                   // (what an interrupted save may have left)
+    const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);   // never through a link somebody else planted
     if (fd < 0) return fail("cannot create %s: %s", tmp.c_str(), strerror(errno));
     if (ftruncate(fd, (off_t) lay.total) != 0) {
         close(fd);
@@ -889,6 +971,13 @@ commet_readset *commet_readset_load(commet_ctx *c, const char *path)
         memcmp(h.magic, "CMTPK01", 8) != 0) {
         close(fd);
         fail("%s is not a packed read set", path);
+        return nullptr;
+    }
+    // the counts are bounded by the file's own size before any arithmetic is done with them
+    const uint64_t fsz = (uint64_t) st.st_size;
+    if (h.n_files > fsz / sizeof(FileSpan) || h.n_empty > fsz / 8 || h.triples > fsz / 12 || h.n_reads > h.triples || (h.n_bases >> 5) > h.triples) {
+        close(fd);
+        fail("%s: inconsistent packed read set", path);
         return nullptr;
     }
     const PackLayout lay(h);
@@ -1017,13 +1106,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off); (void) hipFree(ws.goff);
         (void) hipFree(ws.cur2);
         ws.hist = ws.wl = nullptr; ws.off = ws.goff = nullptr; ws.cur2 = nullptr;
-        HIP_OK(hipMalloc((void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &ws.off, (g.nb + 1) * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void **) &ws.goff, (g.nb + 1) * sizeof(uint64_t)));
-        if (!ws.blockcnt) HIP_OK(hipMalloc((void **) &ws.blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t)));
-        if (!ws.blockoff) HIP_OK(hipMalloc((void **) &ws.blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long)));
-        HIP_OK(hipMalloc((void **) &ws.cur2, g.nb * sizeof(unsigned long long)));
+        HIP_OK(dev_alloc(c, (void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.off, (g.nb + 1) * sizeof(uint64_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.goff, (g.nb + 1) * sizeof(uint64_t), true));
+        if (!ws.blockcnt) HIP_OK(dev_alloc(c, (void **) &ws.blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t), true));
+        if (!ws.blockoff) HIP_OK(dev_alloc(c, (void **) &ws.blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.cur2, g.nb * sizeof(unsigned long long), true));
         ws.nb = g.nb;
     }
     if (ws.cap_keys < total) {
@@ -1032,8 +1121,8 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         ws.bufA = ws.bufB = nullptr;
         ws.cap_keys = 0;
         const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
-        HIP_OK(hipMalloc((void **) &ws.bufA, cap * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **) &ws.bufB, cap * sizeof(uint32_t)));
+        HIP_OK(dev_alloc(c, (void **) &ws.bufA, cap * sizeof(uint32_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.bufB, cap * sizeof(uint32_t), true));
         // first touch here, not inside the first scatter2 launch (measured: 15.6 ms instead of 2.5 ms for that one launch)
         HIP_OK(hipMemsetAsync(ws.bufA, 0, cap * sizeof(uint32_t), stream));
         HIP_OK(hipMemsetAsync(ws.bufB, 0, cap * sizeof(uint32_t), stream));
@@ -1204,7 +1293,7 @@ int ensure_slots(commet_ctx *c, int g, int gs)
     if (c->n_slots < g) {
         HIP_OK(hipStreamSynchronize(c->stream));
         uint32_t *nf = nullptr;
-        hipError_t e = hipMalloc((void **) &nf, (size_t) g * c->filter_bytes);
+        hipError_t e = dev_alloc(c, (void **) &nf, (size_t) g * c->filter_bytes, true);
         if (e != hipSuccess) return fail("cannot allocate %d filter slots: %s", g, hipGetErrorString(e));
         (void) hipFree(c->filter);
         c->filter = nf;
@@ -1215,7 +1304,7 @@ int ensure_slots(commet_ctx *c, int g, int gs)
         (void) hipFree(c->il_a);
         c->il_a = nullptr;
         c->il_stride = 0;
-        HIP_OK(hipMalloc((void **) &c->il_a, (size_t) gs * c->plane_words * sizeof(uint32_t)));
+        HIP_OK(dev_alloc(c, (void **) &c->il_a, (size_t) gs * c->plane_words * sizeof(uint32_t), true));
         c->il_stride = gs;
     }
     return 0;
@@ -1246,7 +1335,7 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
     size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
     // the lanes' reads staged in LDS too (3 * nw_max words each) when that still fits 64 KiB
     uint32_t rw_nw = 0;
-    if (!d_probes && nw_max <= 8 && lds + (size_t) 3 * nw_max * 256 * sizeof(uint32_t) <= (64u << 10) && !getenv("COMMET_NO_STAGE_READS")) {
+    if (!d_probes && nw_max <= 8 && lds + (size_t) 3 * nw_max * 256 * sizeof(uint32_t) <= (64u << 10) && c->stage_reads) {
         rw_nw = nw_max;
         lds += (size_t) 3 * nw_max * 256 * sizeof(uint32_t);
     }
@@ -1343,16 +1432,29 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
 int build_query_list(commet_ctx *c, const commet_readset *rs)
 {
     commet_readset::QueryList &ql = rs->ql;
-    if (ql.built) return 0;
+    if (ql.built) {
+        ql.last_use = ++c->ql_clock;
+        return 0;
+    }
     ql.sbits = TQ_SBITS;
-    if (const char *e = getenv("COMMET_TQ_SBITS")) ql.sbits = std::max(c->k - 10, std::min(c->k - 1, atoi(e)));   // A/B runs
+    if (c->tq_sbits) ql.sbits = std::max(c->k - 10, std::min(c->k - 1, c->tq_sbits));   // A/B runs
     ql.n_slices = 1u << (c->k - ql.sbits);
     ql.n_pieces = (uint32_t) ((rs->n_reads + TQ_PIECE - 1) / TQ_PIECE);
     const uint64_t entries = (uint64_t) ql.n_slices * ql.n_pieces;
     const uint32_t nb = (uint32_t) ((entries + 4095) / 4096);
     unsigned long long *d_totals = nullptr;
-    hipError_t e = hipMalloc((void **) &ql.d_tile_off, (entries + 1) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **) &d_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
+    // (the caller holds ql_mu: on an allocation failure here the other sets' lists are given back directly)
+    auto alloc = [&](void **ptr, size_t bytes) -> hipError_t {
+        hipError_t ae = hipMalloc(ptr, bytes);
+        if (ae != hipErrorOutOfMemory) return ae;
+        (void) hipGetLastError();
+        if (!shrink_query_lists(c, 0, false)) return ae;
+        ae = hipMalloc(ptr, bytes);
+        if (ae == hipErrorOutOfMemory) (void) hipGetLastError();
+        return ae;
+    };
+    hipError_t e = alloc((void **) &ql.d_tile_off, (entries + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = alloc((void **) &d_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
     if (e == hipSuccess) {
         const int t = t_eff(c, rs);
         const size_t lds = (size_t) ql.n_slices * 4;
@@ -1372,11 +1474,11 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) e = hipMemcpyAsync(&total, d_totals + nb, sizeof total, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         ql.n_records = total;
-        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
+        if (e == hipSuccess) e = alloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
         if (e == hipSuccess && total >= (1ull << 32)) e = hipErrorOutOfMemory;   // tstart is 32 bits (never with the 4 GiB cap)
-        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 2);
-        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_tstart, std::max<uint64_t>(entries, 1) * 4);
-        if (e == hipSuccess) e = hipMalloc((void **) &ql.d_tlen, std::max<uint64_t>(entries, 1) * 2);
+        if (e == hipSuccess) e = alloc((void **) &ql.d_qwho, std::max<uint64_t>(total, 1) * 2);
+        if (e == hipSuccess) e = alloc((void **) &ql.d_tstart, std::max<uint64_t>(entries, 1) * 4);
+        if (e == hipSuccess) e = alloc((void **) &ql.d_tlen, std::max<uint64_t>(entries, 1) * 2);
         if (e == hipSuccess) {
             KScope ks(c, "tq_bounds_kernel", c->stream);
             hipLaunchKernelGGL(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, c->stream, ql.d_tile_off, ql.n_slices,
@@ -1406,6 +1508,10 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         return 1;
     }
     ql.built = true;
+    ql.bytes = (entries + 1) * 8 + ql.n_records * 6 + entries * 6;
+    ql.last_use = ++c->ql_clock;
+    c->ql_bytes += ql.bytes;
+    if (c->ql_bytes > c->ql_budget) (void) shrink_query_lists(c, c->ql_budget, false);   // least recently used first; never one of this job
     return 0;
 }
 
@@ -1417,7 +1523,12 @@ int ensure_query_results(commet_ctx *c, const commet_readset *rs)
     if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
     (void) hipFree(c->d_qres);
     c->d_qres = nullptr, c->qres_cap = 0;
-    if (hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1)) != hipSuccess) {
+    hipError_t e = hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
+    if (e == hipErrorOutOfMemory) {   // (the caller holds ql_mu) give back the lists of sets outside this job and try once more
+        (void) hipGetLastError();
+        if (shrink_query_lists(c, 0, false)) e = hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
+    }
+    if (e != hipSuccess) {
         (void) hipGetLastError();
         rs->ql.failed = true;
         return 1;
@@ -1444,10 +1555,7 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
     fg.g = g;
     {
         KScope ks(c, "tq_probe_kernel", c->stream);
-        static const unsigned wpx = [] {
-            const char *e = getenv("COMMET_TQ_WPX");   // workgroups per XCD (A/B runs); a multiple of the 32 CUs of an XCD keeps the sweep even
-            return e ? (unsigned) std::max(1, atoi(e)) : 64u;   // measured: 32 or 64 (1 or 2 per CU) 2.3-2.6 ms, 128: 3.7, 256: 4.8
-        }();
+        const unsigned wpx = c->tq_wpx;
         if (g == 1) hipLaunchKernelGGL(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
         else hipLaunchKernelGGL(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
     }
@@ -1489,19 +1597,19 @@ int ensure_slice_buffers(commet_ctx *c, int gw, uint64_t n_chunks)
         if (c->slice_stage_words < stage_words) {
             (void) hipFree(c->slice_stage);
             c->slice_stage = nullptr, c->slice_stage_words = 0;
-            HIP_OK(hipMalloc((void **) &c->slice_stage, stage_words * 4));
+            HIP_OK(dev_alloc(c, (void **) &c->slice_stage, stage_words * 4, true));
             c->slice_stage_words = stage_words;
         }
         if (c->slice_table_words < table_words) {
             (void) hipFree(c->slice_tables);
             c->slice_tables = nullptr, c->slice_table_words = 0;
-            HIP_OK(hipMalloc((void **) &c->slice_tables, table_words * 4));
+            HIP_OK(dev_alloc(c, (void **) &c->slice_tables, table_words * 4, true));
             c->slice_table_words = table_words;
         }
         if (c->slice_chunks_cap < n_chunks) {
             (void) hipFree(c->d_slice_chunks);
             c->d_slice_chunks = nullptr, c->slice_chunks_cap = 0;
-            HIP_OK(hipMalloc((void **) &c->d_slice_chunks, n_chunks * sizeof(SliceChunk)));
+            HIP_OK(dev_alloc(c, (void **) &c->d_slice_chunks, n_chunks * sizeof(SliceChunk), true));
             c->slice_chunks_cap = n_chunks;
         }
     }
@@ -1595,7 +1703,7 @@ int ensure_wide_tables(commet_ctx *c, const WidePlan &w)
     HIP_OK(hipStreamSynchronize(c->stream));
     (void) hipFree(c->wide_tables);
     c->wide_tables = nullptr, c->wide_table_words = 0;
-    if (hipMalloc((void **) &c->wide_tables, words * 4) != hipSuccess) {
+    if (dev_alloc(c, (void **) &c->wide_tables, words * 4, true) != hipSuccess) {
         (void) hipGetLastError();
         return 1;                                                    // the caller falls back to the narrow tables
     }
@@ -1696,7 +1804,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
 {
     const auto wall0 = std::chrono::steady_clock::now();
     // host-side phase times of the call (COMMET_JOB_VERBOSE: one line per call on stderr)
-    static const bool job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
+    const bool job_verbose = c->job_verbose;
     auto lap_t = wall0;
     double ph_plan = 0, ph_upload = 0, ph_launch = 0, ph_wait = 0;
     auto lap = [&](double &acc) {
@@ -1714,6 +1822,21 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             if (search_rs[q] == search_rs[s]) return fail("search read set listed twice");
     }
     HIP_OK(hipSetDevice(c->device));
+    // the sets of this call keep their cached query lists whatever memory pressure another thread meets meanwhile
+    struct InJob {
+        commet_ctx *c;
+        const commet_readset *index_rs;
+        const commet_readset *const *srs;
+        int n;
+        void mark(bool v) const
+        {
+            std::lock_guard<std::mutex> lk(c->ql_mu);
+            index_rs->in_job = v;
+            for (int i = 0; i < n; ++i) srs[i]->in_job = v;
+        }
+        InJob(commet_ctx *c_, const commet_readset *i_, const commet_readset *const *s_, int n_) : c(c_), index_rs(i_), srs(s_), n(n_) { mark(true); }
+        ~InJob() { mark(false); }
+    } in_job(c, index_rs, search_rs, n_search);
 
     // an input filter that selects every read is no filter (Commet.py passes all-ones bvs when nothing was filtered)
     if (index_select && all_ones(index_select, index_rs->n_reads)) index_select = nullptr;
@@ -1730,7 +1853,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             (void) hipFree(c->d_plansum);
             c->d_plansum = nullptr;
             c->plansum_cap = 0;
-            HIP_OK(hipMalloc((void **) &c->d_plansum, nblk * sizeof(unsigned long long)));
+            HIP_OK(dev_alloc(c, (void **) &c->d_plansum, nblk * sizeof(unsigned long long), true));
             c->plansum_cap = nblk;
         }
         if (index_select && upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
@@ -1801,7 +1924,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         (void) hipFree(c->d_jobcnt);
         c->d_jobcnt = nullptr;
         c->jobcnt_cap = 0;
-        HIP_OK(hipMalloc((void **) &c->d_jobcnt, std::max<uint64_t>(n_cnt, 64) * sizeof(unsigned long long)));
+        HIP_OK(dev_alloc(c, (void **) &c->d_jobcnt, std::max<uint64_t>(n_cnt, 64) * sizeof(unsigned long long), true));
         c->jobcnt_cap = std::max<uint64_t>(n_cnt, 64);
     }
     unsigned long long *const d_cnt = c->d_jobcnt;
@@ -1976,9 +2099,16 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         for (int s = 0; s < n_search && !rc; ++s) {
             const commet_readset *rs = search_rs[s];
             unsigned long long *cnt = d_cnt + 2 * (ci * n_search + s);
-            if (g == 2 && tiled_ok(c, rs, g) && build_query_list(c, rs) == 0 && ensure_query_results(c, rs) == 0) {
-                // large set, two chunk filters: lane-a gathers served from L2, slice by slice (tile_search.hpp)
-                if (launch_search_tiled(c, rs, 2, 0, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search))) { rc = 1; break; }
+            // the tiled search (tile_search.hpp) of one pass: 0 = launched, 1 = not for this set / group, 2 = error.  The set's
+            // query list is made or found, and its kernels queued, under ql_mu: no other thread gives the list back in between
+            auto try_tiled = [&](int tg, int slot0, unsigned long long *tcnt) -> int {
+                std::lock_guard<std::mutex> qlk(c->ql_mu);
+                if (!tiled_ok(c, rs, tg) || build_query_list(c, rs) != 0 || ensure_query_results(c, rs) != 0) return 1;
+                return launch_search_tiled(c, rs, tg, slot0, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, tcnt, (uint32_t) (2 * n_search)) ? 2 : 0;
+            };
+            const int tiled2 = g == 2 ? try_tiled(2, 0, cnt) : 1;   // large set, two chunk filters: lane-a gathers served from L2, slice by slice
+            if (tiled2 == 2) { rc = 1; break; }
+            if (tiled2 == 0) {
                 if (rs->n_reads) ++n_search_launches;
             } else if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
                 if (launch_search_group(c, rs, g, gs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
@@ -1986,10 +2116,10 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
                     c->cur_slot = i;
-                    if (tiled_ok(c, rs, 1) && build_query_list(c, rs) == 0 && ensure_query_results(c, rs) == 0) {   // the same, one filter at a time
-                        if (launch_search_tiled(c, rs, 1, i, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt + 2 * (uint64_t) i * n_search, (uint32_t) (2 * n_search))) rc = 1;
-                    } else
-                    if (launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
+                    const int tiled1 = try_tiled(1, i, cnt + 2 * (uint64_t) i * n_search);   // the same, one filter at a time
+                    if (tiled1 == 2) rc = 1;
+                    else if (tiled1 == 1 &&
+                             launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
                     if (rs->n_reads) ++n_search_launches;
                 }
             }
@@ -2086,8 +2216,40 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
 
 /* ---- hooks ---------------------------------------------------------------- */
 
+uint64_t commet_readset_cache_bytes(const commet_readset *rs)
+{
+    std::lock_guard<std::mutex> lk(rs->ctx->ql_mu);
+    return rs->ql.built ? rs->ql.bytes : 0;
+}
+
+void commet_readset_drop_cache(commet_readset *rs)
+{
+    commet_ctx *c = rs->ctx;
+    (void) hipSetDevice(c->device);
+    std::lock_guard<std::mutex> lk(c->ql_mu);
+    if (rs->in_job) return;                              // (never under a running job)
+    drop_query_list(c, rs);
+    rs->ql.failed = false;                               // a list that did not fit once may fit now
+}
+
+int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions)
+{
+    std::lock_guard<std::mutex> lk(c->ql_mu);
+    if (bytes) *bytes = c->ql_bytes;
+    if (budget_bytes) *budget_bytes = c->ql_budget;
+    if (evictions) *evictions = c->ql_evictions;
+    return 0;
+}
+
 int commet_set_option(commet_ctx *c, const char *name, int64_t value)
 {
+    if (!strcmp(name, "query_list_budget_mb")) {   // HBM the cached query lists of this context's read sets may hold (default 64 GiB)
+        if (value < 0) return fail("query_list_budget_mb must be >= 0");
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        c->ql_budget = (uint64_t) value << 20;
+        (void) shrink_query_lists(c, c->ql_budget, false);
+        return 0;
+    }
     if (!strcmp(name, "count_probes")) {
         c->count_probes = value != 0;
         return 0;

@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/un.h>
+#include <cerrno>
 #include <csignal>
 #include <unistd.h>
 
@@ -72,7 +73,11 @@ struct ServerState {
             uint64_t free_b = ~0ull, total_b = 0;
             if (ctx) (void) commet_device_memory(ctx, &free_b, &total_b);
             const bool tight = ctx && free_b < std::max<uint64_t>(4 * need, total_b / 4);
-            if (cached_bytes + need <= budget_bytes && !tight) return;
+            // what the sets hold now: their packed reads (estimated when they were cached) + the query lists the tiled
+            // search has made for them since (commet_readset_cache_bytes: several times the set itself)
+            uint64_t held = cached_bytes;
+            for (auto &kv : sets) held += commet_readset_cache_bytes(kv.second.rs);
+            if (held + need <= budget_bytes && !tight) return;
             auto victim = sets.end();
             for (auto it = sets.begin(); it != sets.end(); ++it)
                 if (!it->second.in_use && (victim == sets.end() || it->second.last_use < victim->second.last_use)) victim = it;
@@ -129,18 +134,37 @@ struct LoadedSet {
     bool any_bv = false;
     uint64_t n_reads = 0;
     CachedSet *cached = nullptr;   // resident mode: the set belongs to the server's cache
+
+    LoadedSet() = default;
+    LoadedSet(const LoadedSet &) = delete;
+    LoadedSet &operator=(const LoadedSet &) = delete;
+    LoadedSet(LoadedSet &&o) noexcept { *this = std::move(o); }
+    LoadedSet &operator=(LoadedSet &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            nickname = std::move(o.nickname), files = std::move(o.files), select = std::move(o.select);
+            rs = o.rs, any_bv = o.any_bv, n_reads = o.n_reads, cached = o.cached;
+            o.rs = nullptr, o.cached = nullptr;
+        }
+        return *this;
+    }
+    // a loaded set is given back: destroyed, or (resident mode) left in the cache for the next invocation.  Also on the
+    // way out of a request that fails (TOOL_EXIT unwinds through here): a set that was loaded but never reached the
+    // cache would otherwise keep its gigabytes of HBM for the life of the server.
+    void release()
+    {
+        if (cached) cached->in_use = false;
+        else if (rs) commet_readset_destroy(rs);
+        rs = nullptr;
+        cached = nullptr;
+    }
+    ~LoadedSet() { release(); }
 };
 
 static void build_select(LoadedSet &out);
 
-// a loaded set is given back: destroyed, or (resident mode) left in the cache for the next invocation
-static void release_set(LoadedSet &ls)
-{
-    if (ls.cached) ls.cached->in_use = false;
-    else if (ls.rs) commet_readset_destroy(ls.rs);
-    ls.rs = nullptr;
-    ls.cached = nullptr;
-}
+static void release_set(LoadedSet &ls) { ls.release(); }
 
 // FileManager::addFile for every entry of one set (file_manager.h:117-216),
 // FastaFile ctors (fasta_file.h:49-116), then streams the reads to HBM.
@@ -608,7 +632,10 @@ static int serve(const char *sock_path)
     std::cerr << "index_and_search: serving on " << sock_path << "\n";
     for (;;) {
         const int fd = accept(ls, nullptr, nullptr);
-        if (fd < 0) continue;
+        if (fd < 0) {
+            if (errno != EINTR) usleep(20000);   // (EMFILE and the like do not go away by asking again at once)
+            continue;
+        }
         uint32_t n = 0;
         std::vector<std::string> strs;
         bool ok = read_all(fd, &n, 4) && n >= 2 && n < 4096;

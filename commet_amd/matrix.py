@@ -251,7 +251,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
     pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
     size = [float(sum(os.path.getsize(f) for f in fl)) for fl in files]   # cost proxy known before any parsing
-    runs = sharding.assign_pairs_contiguous([size[a] + size[b] for a, b in pairs], world)
+    pair_cost = [size[a] + size[b] for a, b in pairs]
+    runs = sharding.assign_pairs_contiguous(pair_cost, world)
     mine = [pairs[c] for c in runs[rank]]
     needed = sorted({s for p in mine for s in p})
     owned = [s for s in range(N) if s % world == rank]
@@ -259,15 +260,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
     scratch = None
     if world > 1:
-        token = ranks.broadcast_object(f"commet_pk_{os.getuid()}_{os.getpid()}_{int(time.time())}" if rank == 0 else None)
-        scratch = os.path.join(_scratch_root(), token)
-        os.makedirs(scratch, exist_ok=True)
+        # rank 0 makes the directory (mkdtemp: a fresh name, mode 0700 — the scratch root is shared with other users)
+        scratch = ranks.broadcast_object(tempfile.mkdtemp(prefix="commet_pk_", dir=_scratch_root()) if rank == 0 else None)
     # sets are made resident by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: everything first)
     pipelined = N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
     eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
     loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
-                jobs=0, call_ms=0.0, device_ms=0.0)
+                jobs=0, call_ms=0.0, device_ms=0.0,
+                predicted_share=round(sum(pair_cost[c] for c in runs[rank]) / max(sum(pair_cost), 1e-9), 4))   # what the static cut expects of this rank
     try:
         # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
         t0 = time.perf_counter()

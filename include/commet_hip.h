@@ -111,6 +111,16 @@ uint64_t        commet_readset_num_reads(const commet_readset *rs);
 uint64_t        commet_readset_num_files(const commet_readset *rs);
 /* kmers_out[n_reads]: complete k-mers of each read (valid after finalize) */
 int             commet_readset_kmer_counts(const commet_readset *rs, uint32_t *kmers_out);
+/* Derived data cached WITH a resident set: the query list of the tiled search (the set's lane-a addresses sorted by
+ * address slice; depends on (k, t) and the set only, made on the set's first scan, ~6 bytes per first-hit window — 2.2 GB
+ * for 10 M x 100 bp reads at k = 32, t = 2, against 0.5 GB for the packed set).  The lists of a context are held to a
+ * budget (option "query_list_budget_mb", COMMET_QUERY_LIST_GB; default 64 GiB): the least recently used ones are given
+ * back first, and all of them (but the running job's) when a device allocation of the context fails, which is then
+ * tried again.  cache_bytes: HBM the set's list holds now; drop_cache: give it back (rebuilt on the next scan that
+ * wants it; no-op while a job uses the set); cache_stats: the context's totals.  No counterpart in the reference. */
+uint64_t        commet_readset_cache_bytes(const commet_readset *rs);
+void            commet_readset_drop_cache(commet_readset *rs);
+int             commet_cache_stats(commet_ctx *ctx, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions);
 
 /* ---- the two kernels ------------------------------------------------------ */
 /* Replaces `new BloomFilter` per chunk (index_and_search.cpp:256-262,
@@ -191,6 +201,10 @@ int commet_index_and_search(commet_ctx *ctx,
  *   slice_mode (0/1/2)   many-small-chunks regime (12 <= k <= 24): the filters of 32..256 chunks bit-sliced in one table
  *                        set and searched in ONE pass; 0 = from 8 chunks on, 1 = never, 2 = always
  *   slice_words          chunk filters per pass / 32 in that regime (0 auto, 1, 2, 4, 8)
+ *   slice_wide (0/1/2)   that regime with EVERY chunk filter (up to 16 384 per pass) side by side in rows of one table and a
+ *                        group of lanes per read (search_wide_kernel): 0 = jobs of more than 256 chunks, 1 = never, 2 = always
+ *   slice_wide_words     cap on the words per wide row (a multiple of 8, 32 chunk filters per word; 0 = by the memory free)
+ *   query_list_budget_mb HBM the cached query lists of the context's read sets may hold (see commet_readset_cache_bytes)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
  *   kernel_timing (0/1)  time every kernel launch of commet_index_and_search (commet_kernel_times)

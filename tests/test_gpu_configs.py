@@ -139,6 +139,8 @@ def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
 # one pair of configs[3]: 2 x 50 M reads, 7 index chunks -> search_group8_kernel<u32, 2>, one pass
 # ---------------------------------------------------------------------------------------------------------------
 def test_c4_sized_pair_seven_chunks(tmp_path):
+    """one pair of BASELINE configs[3] (10 x 50 M reads) at full size: J1 (7 chunks, every grouping of the chunk filters),
+    then J2 and J3 on the selection-restricted index sets, every job bit-exact on a 20 000-read sample"""
     import commet_amd
     from commet_amd import synth
     k, t, n, L = 32, 2, 50_000_000, 100
@@ -158,18 +160,35 @@ def test_c4_sized_pair_seven_chunks(tmp_path):
             assert np.array_equal(tg[0], tags[0]), group
             assert (sg[0]["indexed"], sg[0]["searched"], sg[0]["shared"]) == \
                 (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]), group
+        # the rest of the pair's chain as Commet.py runs it (Commet.py:186-240) at configs[3]'s size:
+        # J2 = S_0 in (S_1 restricted to J1's result), J3 = S_1 in (S_0 restricted to J2's result)
+        kc1 = qrs.kmer_counts()
+        ctx.set_option("chunk_group", 8)
+        tags2, stats2, info2 = ctx.index_and_search(qrs, [irs], index_select=tags[0])
+        tags3, stats3, info3 = ctx.index_and_search(irs, [qrs], index_select=tags2[0])
     found = util.bools_from_bits(tags[0], n)
     assert stats[0]["shared"] == int(found.sum())
     assert stats[0]["indexed"] == n - 6                                   # six look-ahead reads dropped
     assert found[: n // 4].mean() > 0.85 and found[n // 4:].mean() < 0.02
+    T2, T3 = util.bools_from_bits(tags2[0], n), util.bools_from_bits(tags3[0], n)
+    assert stats2[0]["shared"] == int(T2.sum()) and stats3[0]["shared"] == int(T3.sum())
+    # (T3 within T1 is NOT an invariant: J3's two chunks each span reads that J1 had in several of its seven chunks, so two
+    # hits that J1 saw in different filters can meet in one of J3's; the sample replays below are the check.  It is rare.)
+    assert int((T3 & ~found).sum()) < n // 1000
+    assert info2["n_chunks"] == 2 and info3["n_chunks"] == 2              # a quarter of 50 M reads: 8.6e8 k-mers
     rng = np.random.default_rng(5)
-    smp = _sample(rng, n, 6000, 14000)
+    smp, smp0 = _sample(rng, n, 6000, 14000), _sample(rng, n, 6000, 14000)
     sb = np.ascontiguousarray(b1.reshape(n, L)[smp]).reshape(-1)
-    del b1
+    sb0 = np.ascontiguousarray(b0.reshape(n, L)[smp0]).reshape(-1)
     want, nch = _replay(str(tmp_path), "c4", b0, L, None, kc, k, t, sb)
     assert nch == 7
     assert np.array_equal(found[smp], want)
     assert want.sum() > 4000
+    want2, nch2 = _replay(str(tmp_path), "c4j2", b1, L, found, kc1, k, t, sb0)      # index set restricted to J1's result
+    assert nch2 == 2 and np.array_equal(T2[smp0], want2)
+    want3, nch3 = _replay(str(tmp_path), "c4j3", b0, L, T2, kc, k, t, sb)
+    assert nch3 == 2 and np.array_equal(T3[smp], want3)
+    assert want2.sum() > 4000 and want3.sum() > 4000
 
 
 # ---------------------------------------------------------------------------------------------------------------
