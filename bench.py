@@ -403,6 +403,21 @@ def main():
                 "note": "durations: hipEvents around every launch in untimed extra steps (one index lane, so they add up); "
                         "bytes: rocprofv3 PMC passes of this workload (gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py)",
             }
+            if dom == "search_wide_kernel":
+                # ALGORITHMIC bytes of the row pass (SURVEY 8d's "bytes per unit x units", for this kernel's own algorithm):
+                # per read and window that can hold hit J = min(t, 3) of a strand's scan, six rows (planes A, B, C, both
+                # strands) of one bit per chunk filter; rows are filled in groups of 256 chunks
+                J = min(t, 3)
+                windows = max(0, (L - 1 - (t - J) * k) - (k - 1) + 1)
+                groups = -(-info["n_chunks"] // 256)
+                passes = -(-groups * 8 // 512)
+                row_bytes = -(-groups // passes) * 8 * 4
+                alg = n * windows * 6 * row_bytes * passes
+                roofline["algorithmic"] = {"bytes_per_launch": alg // max(1, int(e["launches_per_step"])),
+                                           "GBps": round(alg / (e["ms_per_step"] * 1e-3) / 1e9, 1),
+                                           "frac": round(alg / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "model": f"{n} reads x {windows} windows x 6 rows x {row_bytes} B (one bit per chunk filter, "
+                                                    f"{info['n_chunks']} chunks in groups of 256) x {passes} pass(es)"}
             if fetch and gather_ceiling and dom.startswith(("search", "tq_")):
                 rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
                 roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),

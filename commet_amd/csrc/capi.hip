@@ -30,6 +30,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <future>
 #include <thread>
 #include <string>
@@ -40,6 +41,22 @@ using namespace commet;
 namespace {
 
 thread_local std::string g_err;
+
+// Every kernel launch of the library notes its entry point here (the host-side handle hipLaunchKernel takes): the
+// test-suite resolves the addresses against the library's symbol table and checks that every instantiation compiled
+// into it was reached by a parity test (commet_launched_kernels, tests/test_gpu_zz_dispatch_coverage.py).
+std::mutex g_launch_mu;
+std::set<const void *> g_launched;
+inline void note_launch(const void *entry)
+{
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    g_launched.insert(entry);
+}
+#define COMMET_LAUNCH(kernel, ...)                    \
+    do {                                               \
+        note_launch((const void *) (kernel));          \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);       \
+    } while (0)
 
 int fail(const char *fmt, ...)
 {
@@ -617,7 +634,7 @@ int commet_readset_stage_commit(commet_readset *rs, uint64_t n)
     if (nbases) HIP_OK(hipMemcpyAsync(s.d_bases, s.h_bases, nbases, hipMemcpyHostToDevice, c->load_stream));
     HIP_OK(hipMemcpyAsync(s.d_offs, s.h_offs, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->load_stream));
     const unsigned grid = (unsigned) ((n + 1 + 255) / 256);
-    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid), dim3(256), 0, c->load_stream, s.d_bases, s.d_offs, n, rs->n_reads,
+    COMMET_LAUNCH(pack_reads_kernel, dim3(grid), dim3(256), 0, c->load_stream, s.d_bases, s.d_offs, n, rs->n_reads,
                        rs->n_bases, rs->d_planes, rs->d_goff, rs->d_kcnt, rs->d_lenmm, c->k);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(s.done, c->load_stream));
@@ -876,7 +893,7 @@ int commet_readset_finalize(commet_readset *rs)
         // host-packed reads have no counts yet: complete k-mers of every read from its validity plane, on the device
         const uint64_t nb = rs->n_bases;
         HIP_OK(hipMemcpyAsync(rs->d_goff + rs->n_reads, &nb, sizeof nb, hipMemcpyHostToDevice, c->load_stream));   // closes the offsets
-        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((rs->n_reads + 255) / 256)), dim3(256), 0, c->load_stream, rs->view(), c->k,
+        COMMET_LAUNCH(kmer_counts_kernel, dim3((unsigned) ((rs->n_reads + 255) / 256)), dim3(256), 0, c->load_stream, rs->view(), c->k,
                            rs->d_kcnt, rs->d_lenmm);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(c->load_stream));
@@ -1012,7 +1029,7 @@ commet_readset *commet_readset_load(commet_ctx *c, const char *path)
     if (e == hipSuccess && h.n_reads) {
         ReadsView v = rs->view();
         v.uniform_len = h.uniform_len;
-        hipLaunchKernelGGL(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->load_stream, v, c->k, rs->d_kcnt,
+        COMMET_LAUNCH(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->load_stream, v, c->k, rs->d_kcnt,
                            rs->d_lenmm);
         e = hipGetLastError();
     }
@@ -1067,10 +1084,10 @@ int launch_index_atomic(commet_ctx *c, const commet_readset *rs, uint64_t first,
     if (blocks >= (1ull << 24)) return fail("index launch too large (>= 2^32 reads in one chunk)");
     KScope ks(c, "index_kernel", c->stream);
     if (c->k <= 32)
-        hipLaunchKernelGGL(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+        COMMET_LAUNCH(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
                            c->k, first, count, d_sel, d_fed);
     else
-        hipLaunchKernelGGL(index_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+        COMMET_LAUNCH(index_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
                            c->k, first, count, d_sel, d_fed);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1152,6 +1169,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             uint32_t nblk = grid1;
             void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt};
             KScope ks(c, "part_hist_kernel", stream);
+            note_launch(fn);
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
         }
     }
@@ -1160,13 +1178,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const size_t lds = lds_hist ? ((size_t) g.nb + g.nb / 32 + 1) * 4 : 0;   // (padded: see the kernel)
         if (lds) HIP_OK(hipFuncSetAttribute((const void *) part_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         KScope ks(c, "part_scan_kernel", stream);
-        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
+        COMMET_LAUNCH(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
                            ws.cur2, ws.wl, ws.goff, lds_hist ? 1 : 0);
     }
     HIP_OK(hipGetLastError());
     {
         KScope ks(c, "part_blockoff_kernel", stream);
-        hipLaunchKernelGGL(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
+        COMMET_LAUNCH(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
                            ws.blockoff);
     }
     HIP_OK(hipGetLastError());
@@ -1180,6 +1198,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const unsigned long long *boff = ws.blockoff;
         void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
         KScope ks(c, "part_scatter1_kernel", stream);
+        note_launch(fn);
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
     }
     if (COMMET_ABLATE & 31) return 0;   // ablation builds only: scatter1 left garbage in bufA, nothing downstream may consume it
@@ -1189,10 +1208,10 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         {
             KScope ks(c, (g.packed && (1u << g.b2) <= S2P_MAX_SUB) ? "part_scatter2_packed_kernel" : "part_scatter2_kernel", stream);
             if (g.packed && (1u << g.b2) <= S2P_MAX_SUB)
-                hipLaunchKernelGGL(part_scatter2_packed_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, (uint2 *) ws.bufB,
+                COMMET_LAUNCH(part_scatter2_packed_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, (uint2 *) ws.bufB,
                                    ws.off, g, ws.cur2, total);
             else
-                hipLaunchKernelGGL(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
+                COMMET_LAUNCH(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
                                    ws.off, g, ws.cur2, total);
         }
         HIP_OK(hipGetLastError());
@@ -1203,14 +1222,14 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         if (grid >= (1ull << 24)) return fail("build launch too large");
         if (zero_fill) {   // no memset happened: clear the tiles that several workgroups OR into
             KScope ks(c, "part_zero_split_kernel", stream);
-            hipLaunchKernelGGL(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, stream, ws.wl, g, slot);
+            COMMET_LAUNCH(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, stream, ws.wl, g, slot);
             HIP_OK(hipGetLastError());
         }
         HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int) (TILE_WORDS * sizeof(uint32_t))));
         {
             KScope ks(c, "part_build_kernel", stream);
-            hipLaunchKernelGGL(part_build_kernel, dim3((unsigned) grid), dim3(BUILD_NT), TILE_WORDS * sizeof(uint32_t), stream,
+            COMMET_LAUNCH(part_build_kernel, dim3((unsigned) grid), dim3(BUILD_NT), TILE_WORDS * sizeof(uint32_t), stream,
                                ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
         }
         HIP_OK(hipGetLastError());
@@ -1270,17 +1289,17 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
     KScope ks(c, "search_kernel", c->stream);
     if (c->k <= 32) {
         if (cnt)
-            hipLaunchKernelGGL((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
+            COMMET_LAUNCH((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
         else
-            hipLaunchKernelGGL((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
+            COMMET_LAUNCH((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
     } else {
         if (cnt)
-            hipLaunchKernelGGL((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
+            COMMET_LAUNCH((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
         else
-            hipLaunchKernelGGL((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
+            COMMET_LAUNCH((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
                                d_tags, d_found, d_counters, d_probes);
     }
     HIP_OK(hipGetLastError());
@@ -1315,13 +1334,13 @@ int launch_interleave(commet_ctx *c, int g, int gs)
     const uint64_t blocks = std::min<uint64_t>((c->plane_words + 255) / 256, 1u << 16);
     KScope ks(c, "interleave_a_kernel", c->stream);
     if (gs == 2)
-        hipLaunchKernelGGL(interleave_a_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+        COMMET_LAUNCH(interleave_a_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
     else if (gs == 4)
-        hipLaunchKernelGGL(interleave_a_kernel<4>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+        COMMET_LAUNCH(interleave_a_kernel<4>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
     else
-        hipLaunchKernelGGL(interleave_a_kernel<8>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
+        COMMET_LAUNCH(interleave_a_kernel<8>, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->filter, 4 * c->plane_words,
                            c->plane_words, g, c->il_a);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1342,11 +1361,11 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
     KScope ks(c, "search_group_kernel", c->stream);
     if (d_probes) {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        hipLaunchKernelGGL((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
+        COMMET_LAUNCH((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
                            d_counters, cstride, d_probes, rw_nw);
     } else {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        hipLaunchKernelGGL((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
+        COMMET_LAUNCH((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
                            d_counters, cstride, d_probes, rw_nw);
     }
     HIP_OK(hipGetLastError());
@@ -1371,17 +1390,17 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
         KScope ks(c, "search_group8_kernel", c->stream);
         if (c->k <= 32) {
             if (three)
-                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
+                COMMET_LAUNCH((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
             else
-                hipLaunchKernelGGL((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
+                COMMET_LAUNCH((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
         } else {
             if (three)
-                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
+                COMMET_LAUNCH((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
             else
-                hipLaunchKernelGGL((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
+                COMMET_LAUNCH((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
                                    d_tags, d_counters, cstride);
         }
         HIP_OK(hipGetLastError());
@@ -1460,14 +1479,14 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         const size_t lds = (size_t) ql.n_slices * 4;
         {
             KScope ks(c, "tq_count_kernel", c->stream);
-            hipLaunchKernelGGL(tq_count_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+            COMMET_LAUNCH(tq_count_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
                                ql.n_pieces, ql.d_tile_off);
         }
         {
             KScope ks(c, "tq_scan_kernels", c->stream);
-            hipLaunchKernelGGL(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals);
-            hipLaunchKernelGGL(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, c->stream, d_totals, nb, d_totals + nb);
-            hipLaunchKernelGGL(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals, d_totals + nb);
+            COMMET_LAUNCH(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals);
+            COMMET_LAUNCH(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, c->stream, d_totals, nb, d_totals + nb);
+            COMMET_LAUNCH(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals, d_totals + nb);
         }
         e = hipGetLastError();
         unsigned long long total = 0;
@@ -1481,7 +1500,7 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) e = alloc((void **) &ql.d_tlen, std::max<uint64_t>(entries, 1) * 2);
         if (e == hipSuccess) {
             KScope ks(c, "tq_bounds_kernel", c->stream);
-            hipLaunchKernelGGL(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, c->stream, ql.d_tile_off, ql.n_slices,
+            COMMET_LAUNCH(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, c->stream, ql.d_tile_off, ql.n_slices,
                                ql.n_pieces, ql.d_tstart, ql.d_tlen);
             e = hipGetLastError();
         }
@@ -1494,7 +1513,7 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
             e = hipFuncSetAttribute((const void *) tq_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
             if (e == hipSuccess) {
                 KScope ks(c, "tq_fill_kernel", c->stream);
-                hipLaunchKernelGGL(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                COMMET_LAUNCH(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
                                    ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
                 e = hipGetLastError();
             }
@@ -1556,8 +1575,8 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
     {
         KScope ks(c, "tq_probe_kernel", c->stream);
         const unsigned wpx = c->tq_wpx;
-        if (g == 1) hipLaunchKernelGGL(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
-        else hipLaunchKernelGGL(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+        if (g == 1) COMMET_LAUNCH(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
+        else COMMET_LAUNCH(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
     }
     HIP_OK(hipGetLastError());
     const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;
@@ -1566,11 +1585,11 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
         KScope ks(c, "tq_replay_kernel", c->stream);
         const dim3 grid(q.n_pieces), block(TQ_PIECE);
         if (g == 1) {
-            if (three) hipLaunchKernelGGL((tq_replay_kernel<1, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
-            else hipLaunchKernelGGL((tq_replay_kernel<1, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            if (three) COMMET_LAUNCH((tq_replay_kernel<1, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            else COMMET_LAUNCH((tq_replay_kernel<1, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
         } else {
-            if (three) hipLaunchKernelGGL((tq_replay_kernel<2, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
-            else hipLaunchKernelGGL((tq_replay_kernel<2, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            if (three) COMMET_LAUNCH((tq_replay_kernel<2, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+            else COMMET_LAUNCH((tq_replay_kernel<2, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
         }
     }
     HIP_OK(hipGetLastError());
@@ -1627,7 +1646,7 @@ int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *
     HIP_OK(hipFuncSetAttribute((const void *) slice_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     {
         KScope ks(c, "slice_build_kernel", c->stream);
-        hipLaunchKernelGGL(slice_build_kernel, dim3(4 * tiles, (unsigned) g), dim3(1024), lds, c->stream, rs->view(), d_sel,
+        COMMET_LAUNCH(slice_build_kernel, dim3(4 * tiles, (unsigned) g), dim3(1024), lds, c->stream, rs->view(), d_sel,
                            c->d_slice_chunks + ci, c->k, tile_bits, tiles, c->slice_stage);
     }
     HIP_OK(hipGetLastError());
@@ -1635,10 +1654,10 @@ int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *
     {
         KScope ks(c, "slice_transpose_kernel", c->stream);
         switch (gw) {
-        case 1: hipLaunchKernelGGL(slice_transpose_kernel<1>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
-        case 2: hipLaunchKernelGGL(slice_transpose_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
-        case 4: hipLaunchKernelGGL(slice_transpose_kernel<4>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
-        default: hipLaunchKernelGGL(slice_transpose_kernel<8>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        case 1: COMMET_LAUNCH(slice_transpose_kernel<1>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        case 2: COMMET_LAUNCH(slice_transpose_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        case 4: COMMET_LAUNCH(slice_transpose_kernel<4>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
+        default: COMMET_LAUNCH(slice_transpose_kernel<8>, dim3(grid), dim3(256), 0, c->stream, c->slice_stage, c->k, g, tables, row_words, col0); break;
         }
     }
     HIP_OK(hipGetLastError());
@@ -1653,10 +1672,10 @@ int launch_search_sliced(commet_ctx *c, const commet_readset *rs, int g, int gw,
     const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
     KScope ks(c, "search_sliced_kernel", c->stream);
     switch (gw) {
-    case 1: hipLaunchKernelGGL(search_sliced_kernel<1>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    case 2: hipLaunchKernelGGL(search_sliced_kernel<2>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    case 4: hipLaunchKernelGGL(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    default: hipLaunchKernelGGL(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 1: COMMET_LAUNCH(search_sliced_kernel<1>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 2: COMMET_LAUNCH(search_sliced_kernel<2>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 4: COMMET_LAUNCH(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    default: COMMET_LAUNCH(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -1665,7 +1684,7 @@ int launch_search_sliced(commet_ctx *c, const commet_readset *rs, int g, int gw,
 // ---- wide rows (slice_search.hpp): every chunk filter of the job — or as many as the table budget allows — in one table ----
 struct WidePlan {
     uint32_t nw = 0;              // words per row that hold chunks (a multiple of WIDE_GROUP_WORDS); 0 = no wide pass
-    uint32_t rw = 0;              // row stride in words (a multiple of 16: rows start on 64-byte boundaries)
+    uint32_t rw = 0;              // row stride in words (a multiple of 32: rows start on 128-byte lines)
     uint64_t chunks_per_pass = 0;
     int lpr = 0, np = 0;          // lanes per read, 16-byte pieces per lane
 };
@@ -1688,7 +1707,7 @@ WidePlan wide_plan(const commet_ctx *c, uint64_t n_chunks, int slice_gw)
     const uint64_t passes = (groups * WIDE_GROUP_WORDS + cap - 1) / cap;
     const uint64_t groups_per_pass = (groups + passes - 1) / passes;
     w.nw = (uint32_t) (groups_per_pass * WIDE_GROUP_WORDS);
-    w.rw = (w.nw + 15u) & ~15u;
+    w.rw = (w.nw + 31u) & ~31u;   // rows start on 128-byte lines: a row of 1312 bytes is 11 lines, never 12
     w.chunks_per_pass = groups_per_pass * 256;
     const uint32_t pieces = w.nw / 4;
     w.lpr = pieces <= 8 ? 8 : pieces <= 16 ? 16 : pieces <= 32 ? 32 : 64;
@@ -1721,7 +1740,7 @@ int launch_search_wide(commet_ctx *c, const commet_readset *rs, const WidePlan &
     const dim3 grid((unsigned) blocks), block(256);
     const int t = t_eff(c, rs);
     KScope ks(c, "search_wide_kernel", c->stream);
-#define COMMET_WIDE(LPR, NP) hipLaunchKernelGGL((search_wide_kernel<LPR, NP>), grid, block, 0, c->stream, rs->view(), c->wide_tables, c->k, t, g, w.nw, w.rw, d_sel, d_tags, d_counters, cstride)
+#define COMMET_WIDE(LPR, NP) COMMET_LAUNCH((search_wide_kernel<LPR, NP>), grid, block, 0, c->stream, rs->view(), c->wide_tables, c->k, t, g, w.nw, w.rw, d_sel, d_tags, d_counters, cstride)
     if (w.np == 2) COMMET_WIDE(64, 2);
     else if (w.lpr == 64) COMMET_WIDE(64, 1);
     else if (w.lpr == 32) COMMET_WIDE(32, 1);
@@ -1859,7 +1878,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         if (index_select && upload_bits(c, index_rs->d_sel, index_select, index_rs->n_reads)) return 1;
         {
             KScope ks(c, "block_kmer_sums_kernel", c->stream);
-            hipLaunchKernelGGL(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt,
+            COMMET_LAUNCH(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, index_rs->d_kcnt,
                                index_select ? index_rs->d_sel : nullptr, index_rs->n_reads, c->d_plansum);
         }
         HIP_OK(hipGetLastError());
@@ -2339,12 +2358,24 @@ int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_byt
     uint8_t *d_out = nullptr;
     HIP_OK(hipMalloc((void **) &d_out, nbytes));
     const uint64_t blocks = std::min<uint64_t>((nbytes + 255) / 256, 1u << 20);   // grid-stride beyond
-    hipLaunchKernelGGL(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), c->k, nbytes, d_out);
+    COMMET_LAUNCH(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), c->k, nbytes, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void) hipFree(d_out);
     if (e != hipSuccess) return fail("filter export failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int commet_launched_kernels(const void **out, int cap, int *n_out)
+{
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    int i = 0;
+    for (const void *e : g_launched) {
+        if (i < cap && out) out[i] = e;
+        ++i;
+    }
+    if (n_out) *n_out = i;
     return 0;
 }
 
@@ -2429,7 +2460,7 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         HIP_OK(hipEventCreate(&e1));
         for (int rep = 0; rep < 2; ++rep) {
             HIP_OK(hipEventRecord(e0, c->stream));
-            hipLaunchKernelGGL(membench_window_kernel, dim3(grid), dim3(256), 0, c->stream, table, n_windows, win_words, iters, xcd, sink);
+            COMMET_LAUNCH(membench_window_kernel, dim3(grid), dim3(256), 0, c->stream, table, n_windows, win_words, iters, xcd, sink);
             HIP_OK(hipEventRecord(e1, c->stream));
         }
         HIP_OK(hipStreamSynchronize(c->stream));
@@ -2457,10 +2488,10 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         HIP_OK(hipEventRecord(e0, c->stream));
         const dim3 g((unsigned) (threads / 256)), b(256);
         switch (atomic) {
-        case 1: hipLaunchKernelGGL(membench_kernel<1>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
-        case 2: hipLaunchKernelGGL(membench_kernel<2>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
-        case 3: hipLaunchKernelGGL(membench_kernel<3>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
-        default: hipLaunchKernelGGL(membench_kernel<0>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        case 1: COMMET_LAUNCH(membench_kernel<1>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        case 2: COMMET_LAUNCH(membench_kernel<2>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        case 3: COMMET_LAUNCH(membench_kernel<3>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
+        default: COMMET_LAUNCH(membench_kernel<0>, g, b, 0, c->stream, table, words - 1, iters, sink); break;
         }
         HIP_OK(hipEventRecord(e1, c->stream));
     }

@@ -71,6 +71,7 @@ SIGNATURES = {
     "commet_filter_export_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_last_kernel_ms": (C.c_int, [C.c_void_p, f64p, f64p]),
     "commet_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
+    "commet_launched_kernels": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
     "commet_membench": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, f64p]),
     "commet_ldsbench": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, f64p]),
 }

@@ -227,6 +227,11 @@ typedef struct {
     double   total_ms;
 } commet_kernel_time;
 int commet_kernel_times(commet_ctx *ctx, commet_kernel_time *out, int cap, int *n_out);
+/* Entry points (host-side kernel handles, addresses inside this library) of every kernel the library has launched in
+ * this process so far, whatever the context.  The test-suite resolves them against the library's symbol table to check
+ * that every kernel instantiation compiled into the library is reached by a parity test.  Fills at most cap entries,
+ * *n_out = how many there are. */
+int commet_launched_kernels(const void **out, int cap, int *n_out);
 /* Random 4-byte-gather / atomic-OR microbenchmarks over a table of
  * table_bytes (practical random-access ceilings): n_access
  * accesses, returns elapsed device ms in *ms.  atomic: 0 plain gather, 1 atomic

@@ -13,7 +13,8 @@ import json
 import os
 import sys
 
-STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1", "interleave_a")   # wide coalesced readers
+STREAMING = ("part_scatter2", "part_build", "part_hist", "part_scatter1", "interleave_a",   # wide coalesced readers
+             "search_wide")   # rows of 1.3 KB fetched 16 bytes per lane: FETCH_SIZE 8.32 TB per launch against 13.86 TB of rows asked for (r03_c5)
 
 
 def short(name):
