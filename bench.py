@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--matrix-sets", type=int, default=10)
     ap.add_argument("--matrix-reads", type=int, default=None,
                     help="reads per set of the matrix leg (default: 10 M = configs[2] on one GPU, 50 M = configs[3] on several)")
+    ap.add_argument("--skew", type=float, default=0.0,
+                    help="fraction of every set's reads replaced by low-complexity / repeated reads (poly-A, tandem repeats, a shared "
+                         "1000-read library): the non-uniform data leg, synth.skew_set")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, meet at the barriers, print the line's launch fields and leave (no GPU work: the CPU test of the launch path)")
     return ap.parse_args()
@@ -278,8 +281,12 @@ def main():
 
     n, L, k, t = args.reads, args.read_len, args.k, args.t
     # every rank owns one (i, j) job of the N x N matrix: sets (2r, 2r+1)
-    b0, o0 = synth.synth_set(2 * rank, n, L, base_set=2 * rank)
-    b1, o1 = synth.synth_set(2 * rank + 1, n, L, base_set=2 * rank)
+    if args.skew > 0:
+        b0, o0 = synth.synth_set_skewed(2 * rank, n, L, args.skew, base_set=2 * rank)
+        b1, o1 = synth.synth_set_skewed(2 * rank + 1, n, L, args.skew, base_set=2 * rank)
+    else:
+        b0, o0 = synth.synth_set(2 * rank, n, L, base_set=2 * rank)
+        b1, o1 = synth.synth_set(2 * rank + 1, n, L, base_set=2 * rank)
 
     # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
     device = int(os.environ.get("COMMET_FORCE_DEVICE", local_rank))
@@ -362,6 +369,8 @@ def main():
         which = {(10_000_000, 100, 32, 2): "BASELINE configs[1]", (20_000_000, 150, 21, 5): "BASELINE configs[4]"}.get((n, L, k, t), "custom size")
         workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
                     f"per GPU ({which}), inputs resident in HBM")
+        if args.skew > 0:
+            workload += f"; {100 * args.skew:g} % of every set's reads low-complexity / repeated (poly-A, tandem repeats, shared 1000-read library)"
         kmers = info["kmers_indexed"]
         idx_ms = acc["index_kernel_ms"] / steps
         srch_ms = acc["search_ms"] / steps

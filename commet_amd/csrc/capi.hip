@@ -192,6 +192,9 @@ struct commet_ctx {
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
     // environment knobs of A/B runs, read ONCE in commet_create (nothing on the launch path calls getenv)
     int tq_sbits = 0;                 // COMMET_TQ_SBITS: log2 bits per address slice of the query list (0 = TQ_SBITS)
+    int tq_parts = 1;                 // COMMET_TQ_PARTS / option "tq_parts": runs of pieces whose replay overlaps the next run's probe.  Off:
+                                      // measured on configs[1] 19.76 ms per step in one part, 21.8 / 23.2 / 24.6 / 25.3 in 2 / 3 / 4 / 6 (the
+                                      // replay of one part and the probe of the next contend for the same memory system, r03_parts_*.json)
     unsigned tq_wpx = 64;             // COMMET_TQ_WPX: probe workgroups per XCD (a multiple of the 32 CUs of an XCD keeps the sweep even;
                                       // measured: 32 or 64 (1 or 2 per CU) 2.3-2.6 ms, 128: 3.7, 256: 4.8)
     bool stage_reads = true;          // COMMET_NO_STAGE_READS: search_group_kernel without the LDS copy of the lanes' reads
@@ -396,6 +399,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (const char *e = getenv("COMMET_TILED")) c->tiled_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("COMMET_TQ_SBITS")) c->tq_sbits = atoi(e);
     if (const char *e = getenv("COMMET_TQ_WPX")) c->tq_wpx = (unsigned) std::max(1, atoi(e));
+    if (const char *e = getenv("COMMET_TQ_PARTS")) c->tq_parts = std::max(1, std::min(16, atoi(e)));
     c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
     c->job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
     c->ingest_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
@@ -1434,10 +1438,12 @@ bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 constexpr int TQ_SBITS = 24;          // slice = 2^24 bits of plane A's address space: 2 MiB per chunk filter, 4 MiB for a group of two
                                       // (measured on configs[1]: 22 / 23 / 24 -> probe 2.43 / 2.56 / 2.35 ms, gpurun_out/r02_tq_ab2.log)
 
+constexpr int TQ_MAX_K = 34;          // 64-bit keys from k = 33 (the reference's default k, index_and_search.cpp:71): 2^(k - 24) <= 1024 slices
+
 bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
 {
     if (c->tiled_mode == 1 || c->count_probes || rs->ql.failed) return false;
-    if (c->k <= TQ_SBITS || c->k > 32 || g < 1 || g > 2) return false;
+    if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || g < 1 || g > 2) return false;
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
     if (rs->n_reads >= (1ull << 32)) return false;
@@ -1479,8 +1485,12 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         const size_t lds = (size_t) ql.n_slices * 4;
         {
             KScope ks(c, "tq_count_kernel", c->stream);
-            COMMET_LAUNCH(tq_count_kernel, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
-                               ql.n_pieces, ql.d_tile_off);
+            if (c->k <= 32)
+                COMMET_LAUNCH(tq_count_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                              ql.n_pieces, ql.d_tile_off);
+            else
+                COMMET_LAUNCH(tq_count_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                              ql.n_pieces, ql.d_tile_off);
         }
         {
             KScope ks(c, "tq_scan_kernels", c->stream);
@@ -1510,11 +1520,16 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
             uint32_t rpr = TQ_PIECE;
             while (rpr > 1 && (uint64_t) rpr * (uint64_t) fhw > TQ_FILL_CAP) rpr /= 2;
             const size_t lds_fill = ((size_t) 4 * ql.n_slices + 2 * TQ_FILL_CAP) * 4;
-            e = hipFuncSetAttribute((const void *) tq_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
+            e = hipFuncSetAttribute(c->k <= 32 ? (const void *) tq_fill_kernel<uint32_t> : (const void *) tq_fill_kernel<uint64_t>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
             if (e == hipSuccess) {
                 KScope ks(c, "tq_fill_kernel", c->stream);
-                COMMET_LAUNCH(tq_fill_kernel, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
-                                   ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+                if (c->k <= 32)
+                    COMMET_LAUNCH(tq_fill_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+                else
+                    COMMET_LAUNCH(tq_fill_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
                 e = hipGetLastError();
             }
         }
@@ -1572,25 +1587,54 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
     fg.slot_words = 4 * c->plane_words;
     fg.plane_words = c->plane_words;
     fg.g = g;
-    {
-        KScope ks(c, "tq_probe_kernel", c->stream);
-        const unsigned wpx = c->tq_wpx;
-        if (g == 1) COMMET_LAUNCH(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
-        else COMMET_LAUNCH(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, c->stream, v, fg.il_a, c->d_qres);
-    }
-    HIP_OK(hipGetLastError());
+    // The probe is bound by L2 gathers, the replay by L2-MISSING requests and bookkeeping: different walls.  The set is cut
+    // into `parts` runs of pieces; part i's probe and replay go to stream i % 2, every probe waiting for the probe before it
+    // (one slice sweep at a time keeps the slice's filter words in L2), so the replay of part i runs beside the probe of
+    // part i + 1.  With per-kernel timing on (durations must add up) or a small set: one part, one stream.
     const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;
     const int t = t_eff(c, rs);
-    {
-        KScope ks(c, "tq_replay_kernel", c->stream);
-        const dim3 grid(q.n_pieces), block(TQ_PIECE);
-        if (g == 1) {
-            if (three) COMMET_LAUNCH((tq_replay_kernel<1, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
-            else COMMET_LAUNCH((tq_replay_kernel<1, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
-        } else {
-            if (three) COMMET_LAUNCH((tq_replay_kernel<2, 3>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
-            else COMMET_LAUNCH((tq_replay_kernel<2, 2>), grid, block, 0, c->stream, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride);
+    uint32_t parts = (c->kclock.on || q.n_pieces < 4096) ? 1u : (uint32_t) std::max(1, std::min(16, c->tq_parts));
+    const unsigned wpx = c->tq_wpx;
+    hipEvent_t ev_probe = c->ev_fork, ev_done = c->ev_join;
+    for (uint32_t pi = 0; pi < parts; ++pi) {
+        const uint32_t p0 = (uint32_t) ((uint64_t) q.n_pieces * pi / parts), p1 = (uint32_t) ((uint64_t) q.n_pieces * (pi + 1) / parts);
+        hipStream_t st = (pi & 1u) ? c->aux_stream : c->stream;
+        if (pi) HIP_OK(hipStreamWaitEvent(st, ev_probe, 0));      // behind the previous part's probe (and so behind the filter build)
+        {
+            KScope ks(c, "tq_probe_kernel", st);
+            if (g == 1) COMMET_LAUNCH(tq_probe_kernel<1>, dim3(8 * wpx), dim3(256), 0, st, v, fg.il_a, c->d_qres, p0, p1);
+            else COMMET_LAUNCH(tq_probe_kernel<2>, dim3(8 * wpx), dim3(256), 0, st, v, fg.il_a, c->d_qres, p0, p1);
         }
+        HIP_OK(hipGetLastError());
+        if (pi + 1 < parts) HIP_OK(hipEventRecord(ev_probe, st));
+        {
+            KScope ks(c, "tq_replay_kernel", st);
+            const dim3 grid(p1 - p0), block(TQ_PIECE);
+#define COMMET_TQ_REPLAY(W, GS, MW) COMMET_LAUNCH((tq_replay_kernel<W, GS, MW>), grid, block, 0, st, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride, p0)
+            if (c->k <= 32) {
+                if (g == 1) {
+                    if (three) COMMET_TQ_REPLAY(uint32_t, 1, 3);
+                    else COMMET_TQ_REPLAY(uint32_t, 1, 2);
+                } else {
+                    if (three) COMMET_TQ_REPLAY(uint32_t, 2, 3);
+                    else COMMET_TQ_REPLAY(uint32_t, 2, 2);
+                }
+            } else {
+                if (g == 1) {
+                    if (three) COMMET_TQ_REPLAY(uint64_t, 1, 3);
+                    else COMMET_TQ_REPLAY(uint64_t, 1, 2);
+                } else {
+                    if (three) COMMET_TQ_REPLAY(uint64_t, 2, 3);
+                    else COMMET_TQ_REPLAY(uint64_t, 2, 2);
+                }
+            }
+#undef COMMET_TQ_REPLAY
+        }
+        HIP_OK(hipGetLastError());
+    }
+    if (parts > 1) {   // the second stream's replays join the main stream (the even parts are on it already)
+        HIP_OK(hipEventRecord(ev_done, c->aux_stream));
+        HIP_OK(hipStreamWaitEvent(c->stream, ev_done, 0));
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -2294,6 +2338,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "tiled_search")) {      // 0 auto, 1 never, 2 whenever the set and the group allow it (tests)
         if (value < 0 || value > 2) return fail("tiled_search must be 0, 1 or 2");
         c->tiled_mode = (int) value;
+        return 0;
+    }
+    if (!strcmp(name, "tq_parts")) {          // tiled search: parts of the set whose replay runs beside the next part's probe (1 = off)
+        if (value < 1 || value > 16) return fail("tq_parts must be 1..16");
+        c->tq_parts = (int) value;
         return 0;
     }
     if (!strcmp(name, "slice_mode")) {        // 0 auto (8 chunks or more, 12 <= k <= 24), 1 never, 2 whenever k allows it

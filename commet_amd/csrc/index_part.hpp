@@ -961,8 +961,36 @@ __global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(
             }
         }
         if (threadIdx.x < nsub) cnt[threadIdx.x] = 0;
-        __syncthreads();
+        // Hot final buckets (poly-A reads, tandem repeats: every k-mer of a read makes the same key, so its keys lie in a
+        // row in the coarse bucket): LDS atomics of one wave instruction on ONE counter run one lane after the other
+        // (0.5 per clock and CU against 5-7 on spread addresses, commet_ldsbench with a 1-word table), and the slabs of a
+        // hot coarse bucket are on few CUs at any time — 12.1 instead of 3.9 ms per step with 3 % of the keys poly-A.
+        // A slab whose first four keys of some thread all go to one final bucket takes the aggregated path below: the
+        // lanes of a wave whose four keys share a bucket elect one lane per bucket value that adds for all of them.
+        // i.i.d. keys never qualify (2^-21 per thread), so the usual path pays three compares per slab and thread.
+        bool hot = false;
         if (whole) {
+            const uint32_t a0 = key[0] >> TILE_BITS;
+            hot = (a0 == (key[1] >> TILE_BITS)) & (a0 == (key[2] >> TILE_BITS)) & (a0 == (key[3] >> TILE_BITS));
+        }
+        hot = __syncthreads_or(hot);
+        const uint32_t lane = threadIdx.x & 63u;
+        if (COMMET_ABLATE & 256) {
+        } else if (hot) {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; q += 4) {
+                const uint32_t b0 = key[q] >> TILE_BITS, b1 = key[q + 1] >> TILE_BITS, b2 = key[q + 2] >> TILE_BITS, b3 = key[q + 3] >> TILE_BITS;
+                const bool run = (b0 == b1) & (b0 == b2) & (b0 == b3);
+                for (uint64_t rem = __ballot(run); rem;) {          // (uniform over the wave)
+                    const int l = __ffsll((long long) rem) - 1;
+                    const uint32_t v = (uint32_t) __shfl((int) b0, l, 64);
+                    const uint64_t same = __ballot(run && b0 == v);
+                    if ((int) lane == l) atomicAdd(&cnt[v], 4u * (uint32_t) __popcll(same));
+                    rem &= ~same;
+                }
+                if (!run) atomicAdd(&cnt[b0], 1u), atomicAdd(&cnt[b1], 1u), atomicAdd(&cnt[b2], 1u), atomicAdd(&cnt[b3], 1u);
+            }
+        } else if (whole) {
 #pragma unroll
             for (uint32_t q = 0; q < S2_PER_THREAD; ++q) atomicAdd(&cnt[key[q] >> TILE_BITS], 1u);
         } else {
@@ -980,7 +1008,7 @@ __global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(
         unsigned long long at = 0;
         if (threadIdx.x < nsub) {
             fill[threadIdx.x] = 3u * ex;
-            if (c) at = atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + threadIdx.x], (unsigned long long) ((c + 2) / 3));
+            if (c && !(COMMET_ABLATE & 128)) at = atomicAdd(&cursor2[((uint64_t) c1 << g.b2) + threadIdx.x], (unsigned long long) ((c + 2) / 3));
         }
         __syncthreads();
         auto place = [&](uint32_t kq) {
@@ -989,7 +1017,33 @@ __global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(
             sorted[slot] = kq & TILE_MASK;
             if (slot == 3u * grp) gid[grp] = (uint8_t) sb;
         };
-        if (whole) {
+        if (COMMET_ABLATE & 32) {
+        } else if (hot) {
+#pragma unroll
+            for (uint32_t q = 0; q < S2_PER_THREAD; q += 4) {
+                const uint32_t b0 = key[q] >> TILE_BITS, b1 = key[q + 1] >> TILE_BITS, b2 = key[q + 2] >> TILE_BITS, b3 = key[q + 3] >> TILE_BITS;
+                const bool run = (b0 == b1) & (b0 == b2) & (b0 == b3);
+                for (uint64_t rem = __ballot(run); rem;) {
+                    const int l = __ffsll((long long) rem) - 1;
+                    const uint32_t v = (uint32_t) __shfl((int) b0, l, 64);
+                    const uint64_t same = __ballot(run && b0 == v);
+                    uint32_t first = 0;
+                    if ((int) lane == l) first = atomicAdd(&fill[v], 4u * (uint32_t) __popcll(same));
+                    first = (uint32_t) __shfl((int) first, l, 64);
+                    if (run && b0 == v) {                            // this lane's four slots, in lane order
+                        const uint32_t slot0 = first + 4u * (uint32_t) __popcll(same & ((1ull << lane) - 1ull));
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t slot = slot0 + u;
+                            sorted[slot] = key[q + u] & TILE_MASK;
+                            if (slot % 3u == 0u) gid[slot / 3u] = (uint8_t) v;
+                        }
+                    }
+                    rem &= ~same;
+                }
+                if (!run) place(key[q]), place(key[q + 1]), place(key[q + 2]), place(key[q + 3]);
+            }
+        } else if (whole) {
 #pragma unroll
             for (uint32_t q = 0; q < S2_PER_THREAD; ++q) place(key[q]);
         } else {
@@ -1008,7 +1062,7 @@ __global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(
             }
         }
         __syncthreads();
-        for (uint32_t f = threadIdx.x; f < n_groups; f += NT) {
+        for (uint32_t f = threadIdx.x; f < n_groups && !(COMMET_ABLATE & 64); f += NT) {
             const uint32_t k0 = sorted[3u * f], k1 = sorted[3u * f + 1], k2 = sorted[3u * f + 2];
             out[gbase[gid[f]] + f] = make_uint2(k0 | (k1 << 19), (k1 >> 13) | (k2 << 6));
         }

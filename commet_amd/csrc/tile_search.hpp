@@ -46,31 +46,36 @@ struct QueryListView {
 };
 
 // first-hit windows of read r: complete windows ending at q in [k-1, pe], pe = len-1-(t-1)k; f(win = q-(k-1), psi address, self-paired)
-template <typename F>
+// (W = uint32_t for k <= 32, uint64_t above: the address then has up to 34 bits, its slice and its place in the slice
+// still fit 32 bits each)
+template <typename W, typename F>
 __device__ __forceinline__ void tq_for_each_window(const ReadsView &rv, uint64_t r, int k, int t, F &&f)
 {
+    using T = KeyTraits<W>;
     uint64_t t0;
     uint32_t len;
     read_extent(rv, r, t0, len);
     const uint32_t *p = rv.planes + 3 * t0;
     const int pe = (int) len - 1 - (t - 1) * k;
-    const int sh = 32 - k;
-    uint32_t wh = 0, run = 0;
+    const int sh = T::BITS - k;
+    W wh = 0;
+    uint32_t run = 0;
     for (uint32_t w = 0; (int) (w * 32u) <= pe; ++w) {
         const uint32_t hi = p[3 * w], va = p[3 * w + 2];
         const uint32_t nb = (uint32_t) min(32, pe - (int) (w * 32u) + 1);
         for (uint32_t j = 0; j < nb; ++j) {
-            wh = (wh >> 1) | (((hi >> j) & 1u) << (k - 1));
+            wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
             run = ((va >> j) & 1u) ? run + 1 : 0;
             if (run < (uint32_t) k) continue;
             bool selfp;
-            const uint32_t addr = psi_a<uint32_t>(__brev(wh) >> sh, k, selfp);
+            const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
             f(32u * w + j - (uint32_t) (k - 1), addr, selfp);
         }
     }
 }
 
 // cnt[slice * n_pieces + piece] = records of the tile.  One workgroup per piece.
+template <typename W>
 __global__ __launch_bounds__(256) void tq_count_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
                                                        unsigned long long *__restrict__ cnt)
 {
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void tq_count_kernel(ReadsView rv, int k, int 
     for (uint32_t i = threadIdx.x; i < TQ_PIECE; i += 256) {
         const uint64_t r = r0 + i;
         if (r >= rv.n) break;
-        tq_for_each_window(rv, r, k, t, [&](uint32_t, uint32_t addr, bool) { atomicAdd(&h[addr >> sbits], 1u); });
+        tq_for_each_window<W>(rv, r, k, t, [&](uint32_t, W addr, bool) { atomicAdd(&h[(uint32_t) (addr >> sbits)], 1u); });
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < n_slices; s += 256) cnt[(uint64_t) s * n_pieces + blockIdx.x] = h[s];
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long
 // record by record straight from the window loop, each 4-byte store reached HBM on its own (18.7 GB written for 3 GB of
 // records, 11 ms per 10 M-read set).
 constexpr uint32_t TQ_FILL_CAP = 6144;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
+template <typename W>
 __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
                                                       uint32_t rpr, const unsigned long long *__restrict__ tile_off,
                                                       uint32_t *__restrict__ qaddr, uint16_t *__restrict__ qwho)
@@ -200,14 +206,14 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
         __syncthreads();
         const uint32_t i = rr + threadIdx.x;
         const bool mine = threadIdx.x < rpr && i < TQ_PIECE && r0 + i < rv.n;
-        if (mine) tq_for_each_window(rv, r0 + i, k, t, [&](uint32_t, uint32_t addr, bool) { atomicAdd(&cnt[addr >> sbits], 1u); });
+        if (mine) tq_for_each_window<W>(rv, r0 + i, k, t, [&](uint32_t, W addr, bool) { atomicAdd(&cnt[(uint32_t) (addr >> sbits)], 1u); });
         __syncthreads();
         lds_scan<256>(cnt, base, n_slices, wsum);
         if (mine)
-            tq_for_each_window(rv, r0 + i, k, t, [&](uint32_t win, uint32_t addr, bool selfp) {
-                const uint32_t s = addr >> sbits;
+            tq_for_each_window<W>(rv, r0 + i, k, t, [&](uint32_t win, W addr, bool selfp) {
+                const uint32_t s = (uint32_t) (addr >> sbits);
                 const uint32_t at = base[s] + atomicAdd(&fill[s], 1u);
-                rec_a[at] = (addr & smask) | (selfp ? 0x80000000u : 0u);
+                rec_a[at] = ((uint32_t) addr & smask) | (selfp ? 0x80000000u : 0u);
                 rec_w[at] = i | (win << 8);
             });
         __syncthreads();
@@ -245,14 +251,17 @@ __device__ __forceinline__ uint32_t tq_probe_one(const uint32_t *__restrict__ ba
     }
 }
 
+// [p0, p1): the pieces whose records are probed (a part of the set: the host runs the replay of one part beside the probe
+// of the next, capi.hip launch_search_tiled); a slice's records of consecutive pieces are contiguous.
 template <int GS>
-__global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const uint32_t *__restrict__ planes_a, uint8_t *__restrict__ qres)
+__global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const uint32_t *__restrict__ planes_a, uint8_t *__restrict__ qres,
+                                                       uint32_t p0, uint32_t p1)
 {
     const uint32_t x = blockIdx.x % 8, j = blockIdx.x / 8, wpx = gridDim.x / 8;
     const uint32_t s_lo = (uint32_t) ((uint64_t) x * ql.n_slices / 8), s_hi = (uint32_t) ((uint64_t) (x + 1) * ql.n_slices / 8);
-    unsigned long long a = ql.tile_off[(uint64_t) s_lo * ql.n_pieces];
     for (uint32_t s = s_lo; s < s_hi; ++s) {
-        const unsigned long long e = ql.tile_off[(uint64_t) (s + 1) * ql.n_pieces];
+        unsigned long long a = ql.tile_off[(uint64_t) s * ql.n_pieces + p0];
+        const unsigned long long e = ql.tile_off[(uint64_t) s * ql.n_pieces + p1];
         const uint32_t *base = planes_a + (((uint64_t) s << ql.sbits) >> 5) * GS;
         // whole groups of four records [4m, 4m + 4) inside [a, e): one 16-byte load of addresses, four gathers, one 4-byte
         // store of results.  The address and result streams are read / written once: non-temporal, so that they do not
@@ -281,17 +290,17 @@ __global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const u
             }
             if (mine) qres[i] = (uint8_t) tq_probe_one<GS>(base, ql.qaddr[i]);
         }
-        a = e;
     }
 }
 
 // replay: one workgroup per piece, one thread per read.
-template <int GS, int MW>
+template <typename W, int GS, int MW>
 __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, QueryListView ql, const uint8_t *__restrict__ qres,
                                                              FilterGroupView fg, int k, int t, const uint64_t *__restrict__ sel,
                                                              uint64_t *__restrict__ tags, unsigned long long *__restrict__ counters,
-                                                             uint32_t cstride)
+                                                             uint32_t cstride, uint32_t piece0)
 {
+    const uint32_t piece = blockIdx.x + piece0;          // (the launch covers pieces piece0 .. piece0 + gridDim.x - 1)
     __shared__ uint32_t masks[GS * 2 * MW * TQ_PIECE];   // [chunk][strand][word][read]
     auto mask_at = [&](int c, int strand, int h, uint32_t rd) -> uint32_t & { return masks[(((c * 2 + strand) * MW) + h) * TQ_PIECE + rd]; };
     for (uint32_t i = threadIdx.x; i < GS * 2 * MW * TQ_PIECE; i += TQ_PIECE) masks[i] = 0;
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
             const uint32_t sl = s0 + lane * NWAVE;                       // this lane's tile of the batch
             unsigned long long ta = 0, te = 0;
             if (sl < ql.n_slices) {
-                ta = ql.tstart[(uint64_t) blockIdx.x * ql.n_slices + sl];           // piece-major: a piece's bounds are contiguous
-                te = ta + ql.tlen[(uint64_t) blockIdx.x * ql.n_slices + sl];
+                ta = ql.tstart[(uint64_t) piece * ql.n_slices + sl];           // piece-major: a piece's bounds are contiguous
+                te = ta + ql.tlen[(uint64_t) piece * ql.n_slices + sl];
             }
             const uint32_t len = (uint32_t) (te - ta);
             uint32_t inc = len;                                           // inclusive prefix of the tile lengths over the lanes
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
     constexpr int NS = 2 * GS;                           // scan index = chunk * 2 + strand
     auto word_at = [&](uint32_t *arr, int i, int h, uint32_t rd) -> uint32_t & { return arr[((i * MW) + h) * TQ_PIECE + rd]; };
     if (threadIdx.x < 2 * GS) wg_cnt[threadIdx.x] = 0;
-    const uint64_t r = (uint64_t) blockIdx.x * TQ_PIECE + threadIdx.x;
+    const uint64_t r = (uint64_t) piece * TQ_PIECE + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
     const bool in_range = (word << 6) < rv.n;
@@ -371,8 +380,9 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         if (tags) tagw = tags[word];
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
-    const int sh = 32 - k;
-    const uint32_t kmask = k == 32 ? ~0u : ((1u << k) - 1u);
+    using T = KeyTraits<W>;
+    const int sh = T::BITS - k;
+    const W kmask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -402,16 +412,16 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
     }
     const bool heavy = hv != 0;
     // words of another read of the piece around window end q
-    auto keys_of = [&](uint32_t owner, int strand, int q, uint32_t &ka, uint32_t &kb) {
+    auto keys_of = [&](uint32_t owner, int strand, int q, W &ka, W &kb) {
         uint64_t t0;
         uint32_t len;
-        read_extent(rv, (uint64_t) blockIdx.x * TQ_PIECE + owner, t0, len);
-        ItemWords<uint32_t> it;
+        read_extent(rv, (uint64_t) piece * TQ_PIECE + owner, t0, len);
+        ItemWords<W> it;
         it.load(rv.planes + 3 * t0, (uint32_t) q >> 5);
-        uint32_t wh, wl;
+        W wh, wl;
         (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);           // complete: only complete windows are in the list
         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
-        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+        else ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
     };
     // one balanced sweep over the set bits of `src` (heavy scans are not in it), four candidates per thread and round so that
     // four probes are in flight per lane: word_of(owner, scan, window end) -> {filter word address, bit} of the first plane
@@ -428,7 +438,8 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         __syncthreads();
         constexpr int U = 2;
         for (uint32_t f0 = threadIdx.x; f0 < total; f0 += U * TQ_PIECE) {
-            uint32_t owner[U], bitn[U], ka[U], kb[U], fw[U], fbit[U];
+            uint32_t owner[U], bitn[U], fw[U], fbit[U];
+            W ka[U], kb[U];
             int sc[U], hw[U];
             bool have[U];
 #pragma unroll
@@ -483,14 +494,14 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         // loads).  A second balanced sweep for C / D (1.2 K survivors per piece) cost more in prefix sums and barriers
         // than the divergence it avoided.
         sweep(masks,
-              [&](int i, uint32_t, uint32_t kb, uint32_t &bit) -> const uint32_t * {
-                  bit = kb & 31u;
+              [&](int i, W, W kb, uint32_t &bit) -> const uint32_t * {
+                  bit = (uint32_t) kb & 31u;
                   return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words + (kb >> 5);
               },
-              [&](uint32_t owner, int i, int h, uint32_t b, uint32_t ka, uint32_t kb) {
+              [&](uint32_t owner, int i, int h, uint32_t b, W ka, W kb) {
                   const uint32_t *pc = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 2 * fg.plane_words, *pd = pc + fg.plane_words;
                   const uint32_t vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
-                  if ((vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u) atomicOr(&word_at(pass, i, h, owner), 1u << b);
+                  if ((vc >> ((uint32_t) (ka ^ kb) & 31u)) & (vd >> ((uint32_t) (ka | kb) & 31u)) & 1u) atomicOr(&word_at(pass, i, h, owner), 1u << b);
               });
     }
     // (3) the reference's control flow (search_reads.h:45-83) on the full hits of this thread's read: per chunk, strand 0
@@ -539,16 +550,16 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                         break;
                     }
                     if (hscan) {
-                        ItemWords<uint32_t> it;
+                        ItemWords<W> it;
                         it.load(p, (uint32_t) q >> 5);
-                        uint32_t wh, wl, ka, kb;
+                        W wh, wl, ka, kb;
                         (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);
                         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
-                        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                        else ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
                         // three independent loads, one round trip: a heavy scan's candidates are almost all true k-mers of the
                         // index set, the short circuit b -> c -> d would only serialise them
                         const uint32_t vb = pb[kb >> 5], vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
-                        if (!((vb >> (kb & 31u)) & (vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u)) continue;
+                        if (!((vb >> ((uint32_t) kb & 31u)) & (vc >> ((uint32_t) (ka ^ kb) & 31u)) & (vd >> ((uint32_t) (ka | kb) & 31u)) & 1u)) continue;
                     }
                     ++seen;
                     next_ok = q + k;
@@ -575,16 +586,16 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                     const int q = (int) (rq >> 8) + (int) w;
                     uint64_t ot0;
                     uint32_t olen;
-                    read_extent(rv, (uint64_t) blockIdx.x * TQ_PIECE + owner, ot0, olen);
+                    read_extent(rv, (uint64_t) piece * TQ_PIECE + owner, ot0, olen);
                     if (q >= (int) olen) continue;
-                    ItemWords<uint32_t> it;
+                    ItemWords<W> it;
                     it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
-                    uint32_t wh, wl;
+                    W wh, wl;
                     if (!it.window((uint32_t) q & 31u, k, kmask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
-                    const uint32_t ka = strand ? (~wh & kmask) : (__brev(wh) >> sh);
-                    const uint32_t addr = psi_a<uint32_t>(ka, k);
+                    const W ka = strand ? (W) (~wh & kmask) : (W) (T::brev(wh) >> sh);
+                    const W addr = psi_a<W>(ka, k);
                     const uint32_t v = fg.il_a[(uint64_t) (addr >> 5) * GS + (uint32_t) (i >> 1)];
-                    if ((v >> (addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << w);
+                    if ((v >> ((uint32_t) addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << w);
                 }
                 __syncthreads();
                 if (want) {
@@ -597,14 +608,14 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                             dead = true;
                             break;
                         }
-                        ItemWords<uint32_t> it;
+                        ItemWords<W> it;
                         it.load(p, (uint32_t) q >> 5);
-                        uint32_t wh, wl, ka, kb;
+                        W wh, wl, ka, kb;
                         (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);
                         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
-                        else ka = __brev(wh) >> sh, kb = __brev(wl) >> sh;
+                        else ka = T::brev(wh) >> sh, kb = T::brev(wl) >> sh;
                         const uint32_t vb = pb[kb >> 5], vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];   // one round trip
-                        if ((vb >> (kb & 31u)) & (vc >> ((ka ^ kb) & 31u)) & (vd >> ((ka | kb) & 31u)) & 1u) {
+                        if ((vb >> ((uint32_t) kb & 31u)) & (vc >> ((uint32_t) (ka ^ kb) & 31u)) & (vd >> ((uint32_t) (ka | kb) & 31u)) & 1u) {
                             ++seen;
                             next_ok = q + k;
                             if (seen >= t) found = true;

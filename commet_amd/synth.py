@@ -51,6 +51,44 @@ def synth_set(set_id, n_reads, read_len, seed_base=1000, copy_frac=0.25, sub_rat
     return bases, offsets
 
 
+def skew_set(bases, n_reads, read_len, set_id, frac=0.10, seed_base=7000, library_reads=1000):
+    """Overwrites a `frac` of the reads of a synthetic set, in place, with what real data is full of and i.i.d. reads
+    never show (SURVEY 7's keyd / hot-bucket warning): a third poly-A (one base in a hundred substituted), a third short
+    tandem repeats (a random unit of 2..6 bases repeated over the read), a third reads drawn from a library of
+    `library_reads` fixed reads that every set shares (seed_base alone), i.e. ~frac/3 * n / library_reads copies of each.
+    Which reads are replaced depends on the set (seed_base + set_id).  Returns the indices replaced."""
+    rng = np.random.default_rng(seed_base + 1 + set_id)
+    m = int(n_reads * frac)
+    if m == 0:
+        return np.zeros(0, dtype=np.int64)
+    idx = rng.choice(n_reads, m, replace=False)
+    view = np.asarray(bases).reshape(n_reads, read_len)
+    a, b = m // 3, 2 * (m // 3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    # poly-A with 1 % substitutions
+    pa = np.full((a, read_len), ord("A"), dtype=np.uint8)
+    nsub = int(rng.binomial(a * read_len, 0.01))
+    pa.reshape(-1)[rng.integers(0, a * read_len, size=nsub)] = acgt[rng.integers(1, 4, size=nsub)]
+    view[idx[:a]] = pa
+    # short tandem repeats: unit length 2..6
+    ulen = rng.integers(2, 7, size=b - a)
+    units = acgt[rng.integers(0, 4, size=(b - a, 6))]
+    pos = np.arange(read_len)[None, :] % ulen[:, None]
+    view[idx[a:b]] = np.take_along_axis(units, pos, axis=1)
+    # the shared repeat library
+    lib = acgt[np.random.default_rng(seed_base).integers(0, 4, size=(library_reads, read_len))]
+    view[idx[b:]] = lib[rng.integers(0, library_reads, size=m - b)]
+    return idx
+
+
+def synth_set_skewed(set_id, n_reads, read_len, frac=0.10, **kw):
+    """synth_set with a `frac` of the reads replaced by low-complexity / repeated ones (skew_set)"""
+    bases, offsets = synth_set(set_id, n_reads, read_len, **kw)
+    bases = np.array(bases)          # (synth_set's buffer is read-only)
+    skew_set(bases, n_reads, read_len, set_id, frac)
+    return bases, offsets
+
+
 def write_fasta(path, bases, offsets, width=0, lowercase_every=0):
     """Header '>i', one sequence line (or `width`-column lines)."""
     b = np.asarray(bases, dtype=np.uint8).tobytes()

@@ -104,6 +104,83 @@ def test_c2_properties(c2):
         assert fs[clean & ~dropped].all()
 
 
+def test_k33_default_k_sample_is_bit_exact_against_cpu_checker(c2):
+    """the reference's DEFAULT k (index_and_search.cpp:71, Commet.py:453) on configs[1]'s sets: 64-bit keys, a 4 GiB filter,
+    one chunk (6.8e8 k-mers < max_kmer = 1e9), the tiled search on 64-bit keys (tq_*<uint64_t>); bit-exact on a sample,
+    and the same bits from the plain search kernel"""
+    import commet_amd
+    k, t, n, L = 33, 2, c2["n"], c2["L"]
+    with commet_amd.Context(k=k, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(c2["b0"], c2["o0"])])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(c2["b1"], c2["o1"])])
+        kc = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        assert info["n_chunks"] == 1 and "tq_replay_kernel" in times and "search_kernel" not in times
+        assert qrs.cache_bytes > 0
+        ctx.set_option("tiled_search", 1)
+        tags_g, stats_g, _ = ctx.index_and_search(irs, [qrs])
+        assert np.array_equal(tags_g[0], tags[0])
+        assert (stats_g[0]["indexed"], stats_g[0]["searched"], stats_g[0]["shared"]) == (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"])
+    chunks = _chunks_from_counts(kc, ob.max_kmer(k))
+    assert len(chunks) == 1 and stats[0]["indexed"] == n
+    rng = np.random.default_rng(33)
+    sample = np.sort(np.concatenate([rng.choice(n // 4, 6000, replace=False), n // 4 + rng.choice(n - n // 4, 14000, replace=False)]))
+    sb = c2["b1"].reshape(n, L)[sample].reshape(-1)
+    so = np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L)
+    f = ob.Bloom(k)
+    fed = f.index(c2["b0"], c2["o0"])
+    assert fed == int(kc.sum()) == info["kmers_indexed"]
+    fnd, _ = f.search(t, sb, so, np.full(len(sample) // 8 + 1, 255, dtype=np.uint8))
+    f.close()
+    got = util.bools_from_bits(tags[0], n)[sample]
+    assert np.array_equal(got, util.bools_from_bits(fnd, len(sample)))
+    assert got.sum() > 4000 and stats[0]["shared"] == int(util.bools_from_bits(tags[0], n).sum())
+
+
+def test_c2_sized_skewed_sets_sample_is_bit_exact_against_cpu_checker():
+    """configs[1]'s size with 10 % of every set's reads low-complexity or repeated (poly-A, tandem repeats, a shared
+    library of 1000 reads: synth.skew_set) — hot buckets in hist / scatter / build (split tiles), heavy scans in the
+    search.  Bit-exact on a sample that holds 4000 of the replaced reads; atomic and bucketed constructions agree."""
+    import commet_amd
+    from commet_amd import synth
+    k, t, n, L = 32, 2, 10_000_000, 100
+    b0, o0 = synth.synth_set_skewed(0, n, L, 0.10)
+    b1, o1 = synth.synth_set_skewed(1, n, L, 0.10)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
+        kc = irs.kmer_counts()
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        ctx.set_option("index_mode", 1)
+        ctx.set_option("tiled_search", 1)
+        tags_a, stats_a, _ = ctx.index_and_search(irs, [qrs])            # atomic index kernel, gather search kernels
+        assert np.array_equal(tags_a[0], tags[0]) and stats_a[0]["shared"] == stats[0]["shared"]
+    chunks = _chunks_from_counts(kc, ob.max_kmer(k))
+    assert len(chunks) == info["n_chunks"] == 2
+    rng = np.random.default_rng(17)
+    replaced = synth.skew_set(np.array(b1), n, L, 1, 0.10)               # (the same draw: which reads of set 1 were replaced)
+    sample = np.unique(np.concatenate([rng.choice(n // 4, 5000, replace=False), n // 4 + rng.choice(n - n // 4, 11000, replace=False),
+                                       rng.choice(replaced, 4000, replace=False)]))
+    sb = np.ascontiguousarray(b1.reshape(n, L)[sample]).reshape(-1)
+    so = np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L)
+    found = np.zeros(len(sample) // 8 + 1, dtype=np.uint8)
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        fed = f.index(b0[a * L: e * L], o0[a: e + 1] - o0[a])
+        assert fed == int(kc[a:e].sum())
+        fnd, _ = f.search(t, sb, so, ~found)
+        found |= fnd
+        f.close()
+    got = util.bools_from_bits(tags[0], n)[sample]
+    assert np.array_equal(got, util.bools_from_bits(found, len(sample)))
+    # the replaced reads are mostly shared (every set holds poly-A reads, the same repeat units, the same library)
+    is_rep = np.isin(sample, replaced)
+    assert got[is_rep].mean() > 0.6 and got.sum() > 5000
+
+
 @pytest.mark.parametrize("n_index,n_query", [(30000, 30000)])
 def test_c5_shape_many_small_chunks(n_index, n_query):
     """k=21, t=5, 150 bp: max_kmer = 244 140 -> ~1880-read chunks, 1 MiB filter; full replay on the CPU checker"""

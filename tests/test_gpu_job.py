@@ -128,13 +128,13 @@ def test_job_wide_rows_match_oracle(tmp_path, seed):
                 pos += n
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(48))
 def test_job_tiled_search_matches_oracle(tmp_path, seed):
     """the tiled search (tile_search.hpp: the set's lane-a addresses sorted by address slice once, probed slice by slice out
     of L2, replayed piece by piece) forced on the randomised scenarios, for groups of one and of two chunk filters (larger
     groups keep the gather kernels; the last group of a job may still be tiled)"""
     import commet_amd as commet
-    k = [24, 25, 26, 28, 30, 32][seed % 6]
+    k = [25, 26, 28, 30, 32, 33, 34, 32][seed % 8]          # 33, 34: 64-bit keys (tq_*<uint64_t>)
     scn = Scenario(str(tmp_path / "scn"), 900 + seed, k=k, n_scale=[1.0, 6.0, 20.0][seed % 3])
     out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
     rc, res, chunks, kmers = run_oracle(scn, out_o, log_o)
@@ -147,15 +147,15 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
             srs.append(r)
             ssel.append(s)
         ctx.set_option("tiled_search", 2)
-        ctx.set_option("max_kmer", [0, 3000, 900][(seed // 6) % 3])          # more chunks from small sets (test hook)
-        ctx.set_option("chunk_group", [2, 1, 3][(seed // 18) % 3 if seed >= 18 else seed % 2])
+        ctx.set_option("max_kmer", [0, 3000, 900][(seed // 8) % 3])          # more chunks from small sets (test hook)
+        ctx.set_option("chunk_group", [2, 1, 3][(seed // 3) % 3])
         got = ctx.index_and_search(irs, srs, isel, ssel)
         ctx.set_option("tiled_search", 1)
         ref = ctx.index_and_search(irs, srs, isel, ssel)                       # the gather kernels, same chunking
         for a, b in zip(got[0], ref[0]):
             assert np.array_equal(a, b)
         assert [(s["indexed"], s["searched"], s["shared"]) for s in got[1]] == [(s["indexed"], s["searched"], s["shared"]) for s in ref[1]]
-        if [0, 3000, 900][(seed // 6) % 3] == 0:                              # the reference's own chunk size: the CPU checker's bits
+        if [0, 3000, 900][(seed // 8) % 3] == 0:                              # the reference's own chunk size: the CPU checker's bits
             tags, stats, info = got
             assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
             by_name = {r["name"]: r for r in res}
