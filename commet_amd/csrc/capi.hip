@@ -1158,11 +1158,11 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     {
         const unsigned grid = (grid1 + 1) / 2;
         const bool full = g.nb <= HIST_MAX_BUCKETS;
-        const void *fns[8] = {(const void *) part_hist_kernel<uint32_t, false, false>, (const void *) part_hist_kernel<uint32_t, false, true>,
-                              (const void *) part_hist_kernel<uint32_t, true, false>,  (const void *) part_hist_kernel<uint32_t, true, true>,
-                              (const void *) part_hist_kernel<uint64_t, false, false>, (const void *) part_hist_kernel<uint64_t, false, true>,
-                              (const void *) part_hist_kernel<uint64_t, true, false>,  (const void *) part_hist_kernel<uint64_t, true, true>};
-        const void *fn = fns[(wide ? 4 : 0) + (uni ? 2 : 0) + (full ? 1 : 0)];
+        // 32-bit keys (k <= 32): at most 2^15 buckets, the LDS histogram always covers them all (FULL); 64-bit keys: never.
+        // Only those four instantiations exist (tests/test_gpu_zz_dispatch_coverage.py checks that each is reached).
+        if (full == wide) return fail("internal error: histogram geometry (k = %d, %u buckets)", c->k, g.nb);
+        const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true, false> : (const void *) part_hist_kernel<uint64_t, false, false>)
+                              : (uni ? (const void *) part_hist_kernel<uint32_t, true, true> : (const void *) part_hist_kernel<uint32_t, false, true>);
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
             const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
@@ -2003,7 +2003,12 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         return 0;
     };
     // the many-small-chunks regime: the chunk filters of a group live bit-sliced in one set of tables (slice_search.hpp)
-    const int slice_gw = slice_words(c, n_chunks);
+    int slice_gw = slice_words(c, n_chunks);
+    // no room for the staging planes / tables of that regime: the job takes the slot loop below (slower, same bits)
+    if (slice_gw && ensure_slice_buffers(c, c->slice_wide == 1 || (c->slice_wide == 0 && n_chunks <= 256) ? slice_gw : 8, n_chunks)) {
+        (void) hipGetLastError();
+        slice_gw = 0;
+    }
     const bool timed = (info != nullptr || stats != nullptr) &&
                        (slice_gw ? (n_chunks / (32 * slice_gw) + 1) * (uint64_t) (n_search + 2) : n_chunks * (uint64_t) (n_search + 4)) <= 16384;
     std::vector<hipEvent_t> e_idx0, e_idx1, e_zero0, e_zero1;
@@ -2030,7 +2035,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         }
         WidePlan wide = wide_plan(c, n_chunks, slice_gw);
         if (wide.nw && ensure_wide_tables(c, wide)) wide = WidePlan();   // no room for the wide tables: groups of 256 chunks as before
-        if (ensure_slice_buffers(c, wide.nw ? 8 : slice_gw, n_chunks)) rc = 1;
+        if (ensure_slice_buffers(c, wide.nw ? 8 : slice_gw, n_chunks)) rc = 1;   // (sized above already; a wide plan that fell back may need less)
         if (!rc && hipMemcpy(c->d_slice_chunks, hc.data(), n_chunks * sizeof(SliceChunk), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail("chunk descriptor upload failed");
         // wide rows: the filters of a pass's chunks (all of them when the tables fit) are built 256 at a time into their

@@ -46,7 +46,8 @@ constexpr uint32_t S1_ITEMS = S1_NT;                        // octet items per r
 constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
 constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
 constexpr uint32_t S2_PER_THREAD = S2_KEYS / S2_NT;
-constexpr uint32_t S2P_MAX_SUB = 128;                       // packed scatter-2: final buckets per coarse bucket (k <= 32; keeps the LDS at 38.7 KiB: four workgroups per CU)
+constexpr uint32_t S2P_MAX_SUB = 256;                       // packed scatter-2: final buckets per coarse bucket (k <= 33: the reference's default k takes the packed
+                                                            // geometry too; 41.9 KiB of LDS, three workgroups of 80 VGPRs per CU either way)
 constexpr int      HIST_NT = 1024;                          // histogram workgroup size
 #ifndef BUILD_NT
 #define BUILD_NT 1024   // build workgroup: its loads in flight are what the kernel runs on (256 / 512 / 1024 threads: 2.75 / 2.52 / 2.36 ms per configs[1] step)

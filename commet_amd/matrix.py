@@ -274,9 +274,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         t0 = time.perf_counter()
         sets = {}
         solo = pipelined and world == 1                           # (then the loading thread parses, too)
-        for s in ([] if solo else owned):
-            if s not in needed and s not in needed_by_others:
-                continue
+
+        def parse_own(s):
+            """one of this rank's sets: parsed here and nowhere else; its packed image published for the ranks that need it
+            (commet_readset_save writes a .tmp and renames it: the file appears complete or not at all)"""
             w0 = time.perf_counter()
             rs = eng.parse(files[s])
             prof["parse_s"] += time.perf_counter() - w0
@@ -289,7 +290,12 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 sets[s] = rs
             else:
                 eng.release(rs)
-        ranks.barrier()                                          # every image is in place
+
+        if not pipelined:
+            for s in owned:
+                if s in needed or s in needed_by_others:
+                    parse_own(s)
+            ranks.barrier()                                      # every image is in place
         counts, sel, considered_mine = {}, {}, {}
 
         def prepare(s):
@@ -340,20 +346,45 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             loader_stop = threading.Event()
             load_err = []
             load_end = [t0]
+            filters_ready = threading.Event()
             if solo:
                 order = list(range(N - 1, -1, -1))
                 considered = [0] * N
+                own_first = []
             else:
                 order = []
                 for ref in refs:
                     for s in [ref] + [i for (r, i) in mine if r == ref]:
                         if s not in order:
                             order.append(s)
-                filters_done()                                   # (they ran beside the parsing; a barrier: other ranks' filters too)
-                considered = diagonal()
+                # Several ranks: nobody waits at a barrier for every set of the node to be parsed.  This rank parses its own
+                # sets first — the ones most ranks wait for first — and publishes their images; then it takes the other
+                # ranks' images, in the order its jobs want them, as soon as each file appears.  Its first job starts when
+                # the two sets of that job are there, whatever the other ranks are still parsing.
+                wanted_by = {s_: sum(1 for r in range(world) if any(s_ in pairs[c] for c in runs[r])) for s_ in owned}
+                own_first = sorted((s_ for s_ in owned if s_ in needed or s_ in needed_by_others), key=lambda s_: (-wanted_by[s_], s_))
+
+            def wait_image(s):
+                """another rank's packed image: there once its owner has parsed the set (or never, if that rank died:
+                the launcher then ends this process; the deadline only bounds a stray wait)"""
+                path = os.path.join(scratch, f"set{s}.pk")
+                deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
+                w0 = time.perf_counter()
+                while not os.path.exists(path):
+                    if loader_stop.is_set():
+                        return False
+                    if time.perf_counter() > deadline:
+                        raise RuntimeError(f"packed image of set {s} did not appear in {scratch}")
+                    time.sleep(0.002)
+                prof["image_wait_s"] = prof.get("image_wait_s", 0.0) + time.perf_counter() - w0
+                return True
 
             def load_all():
                 try:
+                    for s in own_first:
+                        if loader_stop.is_set():
+                            return
+                        parse_own(s)
                     for s in order:
                         if loader_stop.is_set():                 # the job thread has failed
                             break
@@ -364,8 +395,14 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             prof["sets_parsed"] += 1
                             filter_done_for(s)
                             considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
-                        elif s not in sets:
-                            fetch(s)
+                        else:
+                            if s not in sets:
+                                if not wait_image(s):
+                                    break
+                                fetch(s)
+                            while not filters_ready.wait(0.05):  # every rank's filter files are written (the job thread says so)
+                                if loader_stop.is_set():
+                                    return
                         prepare(s)
                         ready[s].set()
                 except BaseException as ex:          # handed to the job thread, which is waiting for a set
@@ -377,6 +414,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
             loader = threading.Thread(target=load_all, name="commet-set-loader", daemon=True)
             loader.start()
+            if not solo:
+                # the collectives stay on this thread: the filters of all ranks (they ran beside the parsing), the diagonal
+                try:
+                    filters_done()
+                    considered = diagonal()
+                    filters_ready.set()
+                except BaseException:
+                    loader_stop.set()
+                    raise
 
         set_wait = [0.0]
 

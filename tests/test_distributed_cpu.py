@@ -112,6 +112,12 @@ def test_matrix_driver_host_logic_over_gloo_ranks(tmp_path, world):
     assert sum(r["sets_parsed"] for r in res["per_rank"]) == len(names)          # one parse per set on the node
     assert sum(r["pairs"] for r in res["per_rank"]) == 10
     assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + world
+    # the static cut: every rank's predicted share of the pairs' cost is within one pair of the mean, and they add up
+    shares = [r["predicted_share"] for r in res["per_rank"]]
+    sizes = [sum(os.path.getsize(tmp_path / f) for f in fl) for fl in files]
+    one_pair = 2.0 * max(sizes) / sum(sizes[a] + sizes[b] for a in range(5) for b in range(a + 1, 5))
+    assert abs(sum(shares) - 1.0) < 1e-2 and max(shares) - min(shares) <= 2 * one_pair + 1e-3
+    assert res["load_overlaps_jobs"] is True                                     # own sets parsed beside the jobs, no barrier
     assert not [f for f in os.listdir(tmp_path) if f.startswith("commet_pk_")]   # the scratch images are gone
 
     def cfg(si, restrict_to=None):

@@ -342,3 +342,78 @@ def test_wide_rows_instantiations_match_cpu_checker(k, t, L, n_chunks, cap_words
         assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
         assert sg[0]["searched"] == searched_last and sg[0]["indexed"] == sum(e - a for a, e in chunks)
     assert stats[0]["shared"] > 60
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# instantiations the randomised scenarios do not reach (tests/test_gpu_zz_dispatch_coverage.py keeps the list honest)
+# ---------------------------------------------------------------------------------------------------------------
+def _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, n_q):
+    found = np.zeros(n_q // 8 + 1, dtype=np.uint8)
+    searched_last = 0
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
+        active = ~found
+        searched_last = int(util.bools_from_bits(active, n_q).sum())
+        fnd, _ = f.search(t, qb, qo, active)
+        found |= fnd
+        f.close()
+    return found, searched_last
+
+
+@pytest.mark.parametrize("k,t,L,max_kmer,group", [(33, 2, 100, 40000, 2), (34, 2, 110, 30000, 4)])
+def test_probe_counting_group_kernels_with_64_bit_keys(k, t, L, max_kmer, group):
+    """search_group_kernel<uint64_t, 2 | 4, COUNT = true>: the builds that reproduce the reference's probe count, on 64-bit
+    keys, for groups of chunk filters: the CPU checker's bits, and the probe count of the one-filter-at-a-time kernel"""
+    import commet_amd
+    rng = np.random.default_rng(5 * k + group)
+    idx_reads = util.random_reads(rng, 3000, L, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 4000, L - 20, L + 20, share=0.5, n_rate=0.002)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    res = {}
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("count_probes", 1)
+        irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+        kc = irs.kmer_counts()
+        for g in (group, 1):
+            ctx.set_option("chunk_group", g)
+            res[g] = ctx.index_and_search(irs, [qrs])
+    chunks = oracle_pool.chunks_from_counts(kc, max_kmer)
+    assert len(chunks) >= 4 and res[group][2]["search_launches"] == -(-len(chunks) // group) and res[1][2]["search_launches"] == len(chunks)
+    found, searched_last = _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, len(q_reads))
+    for g in (group, 1):
+        tags, stats, info = res[g]
+        assert np.array_equal(tags[0], found), g
+        assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum())), g
+    assert res[group][2]["probes"] == res[1][2]["probes"] > 0
+    assert res[1][1][0]["shared"] > 500
+
+
+@pytest.mark.parametrize("k,t,L,max_kmer", [(26, 1, 110, 90000), (33, 1, 120, 90000)])
+def test_tiled_replay_three_mask_words_two_filters(k, t, L, max_kmer):
+    """tq_replay_kernel<W, 2, 3>: 65..96 first-hit windows per read (three mask words) against a group of two chunk filters"""
+    import commet_amd
+    rng = np.random.default_rng(11 * k)
+    idx_reads = util.random_reads(rng, 4000, L, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 6000, L, L, share=0.5, n_rate=0.002)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("tiled_search", 2)
+        ctx.set_option("chunk_group", 2)
+        irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+        kc = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        assert "tq_replay_kernel" in ctx.kernel_times() and qrs.cache_bytes > 0
+    chunks = oracle_pool.chunks_from_counts(kc, max_kmer)
+    assert len(chunks) >= 4 and 64 < L - t * k + 1 <= 96
+    found, searched_last = _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, len(q_reads))
+    assert np.array_equal(tags[0], found)
+    assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum()))
+    assert stats[0]["shared"] > 1000
