@@ -211,6 +211,31 @@ def test_bucketed_index_matches_oracle(commet, k):
         rs.close()
 
 
+@pytest.mark.parametrize("k,uniform", [(30, True), (32, True), (32, False), (33, True)])
+def test_bucketed_index_filter_bytes_at_large_k(commet, k, uniform):
+    """the bucketed construction against the CPU checker's filter BYTES at the sizes the benchmark runs (k = 32: 2 GiB,
+    k = 33: 4 GiB, the packed scatter2 and both hist / scatter1 item paths) — smaller k are compared in
+    test_bucketed_index_matches_oracle; here the reads include hot buckets (poly-A, a tandem repeat)"""
+    rng = np.random.default_rng(7 * k + int(uniform))
+    L = 100
+    reads = util.random_reads(rng, 150000, L, L, n_rate=0.002) if uniform else util.random_reads(rng, 150000, 40, 160, n_rate=0.002)
+    reads += ([b"A" * L] * 3000 + [(b"ACG" * L)[:L]] * 2000) if uniform else ([b"A" * 130] * 3000 + [(b"ACG" * 50)[:117]] * 2000)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    bases, offs = util.to_batch(reads)
+    with commet.Context(k=k, t=2) as ctx:
+        ctx.set_option("index_mode", 2)
+        rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+        ctx.filter_reset()
+        fed = ctx.index_reads(rs)
+        f = ob.Bloom(k)
+        assert fed == f.index(bases, offs)
+        got, want = ctx.export_filter_reference(), f.bytes()
+        f.close()
+        assert got.shape == want.shape and np.array_equal(got, want)
+        rs.close()
+
+
 @pytest.mark.parametrize("k,L", [(20, 20), (21, 100), (24, 37), (26, 150), (28, 64), (32, 100), (33, 101), (34, 250)])
 def test_bucketed_index_uniform_length_fast_path(commet, k, L):
     """reads of one length and no selection take the arithmetic item path of hist / scatter1 (index_part.hpp, UNI):
