@@ -125,12 +125,17 @@ def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
     sb_i = np.ascontiguousarray(b_i.reshape(n, L)[smp_i]).reshape(-1)
     sb_ref = np.ascontiguousarray(b_ref.reshape(n, L)[smp_ref]).reshape(-1)
     scratch = str(tmp_path)
-    f1, nch1 = _replay(scratch, "j1", b_ref, L, None, kc_ref, k, t, sb_i)
+    # the three replays side by side (each one runs its chunks in worker processes; J2 / J3 take the GPU's T1 / T2 as their
+    # index selections, so they do not wait for one another)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as pool:
+        r1 = pool.submit(_replay, scratch, "j1", b_ref, L, None, kc_ref, k, t, sb_i)
+        r2 = pool.submit(_replay, scratch, "j2", b_i, L, T1, kc_i, k, t, sb_ref)      # index set restricted to J1's result
+        r3 = pool.submit(_replay, scratch, "j3", b_ref, L, T2, kc_ref, k, t, sb_i)
+        (f1, nch1), (f2, _), (f3, _) = r1.result(), r2.result(), r3.result()
     assert nch1 == inf1["n_chunks"] == 2
     assert np.array_equal(T1[smp_i], f1)
-    f2, _ = _replay(scratch, "j2", b_i, L, T1, kc_i, k, t, sb_ref)         # index set restricted to J1's result
     assert np.array_equal(T2[smp_ref], f2)
-    f3, _ = _replay(scratch, "j3", b_ref, L, T2, kc_ref, k, t, sb_i)
     assert np.array_equal(T3[smp_i], f3)
     assert f1.sum() > 4000 and f2.sum() > 4000 and f3.sum() > 4000      # the samples do contain shared reads
 
@@ -180,13 +185,16 @@ def test_c4_sized_pair_seven_chunks(tmp_path):
     smp, smp0 = _sample(rng, n, 6000, 14000), _sample(rng, n, 6000, 14000)
     sb = np.ascontiguousarray(b1.reshape(n, L)[smp]).reshape(-1)
     sb0 = np.ascontiguousarray(b0.reshape(n, L)[smp0]).reshape(-1)
-    want, nch = _replay(str(tmp_path), "c4", b0, L, None, kc, k, t, sb)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as pool:   # 7 + 2 + 2 chunk filters, each built by a worker process of its own
+        r1 = pool.submit(_replay, str(tmp_path), "c4", b0, L, None, kc, k, t, sb)
+        r2 = pool.submit(_replay, str(tmp_path), "c4j2", b1, L, found, kc1, k, t, sb0)   # index set restricted to J1's result
+        r3 = pool.submit(_replay, str(tmp_path), "c4j3", b0, L, T2, kc, k, t, sb)
+        (want, nch), (want2, nch2), (want3, nch3) = r1.result(), r2.result(), r3.result()
     assert nch == 7
     assert np.array_equal(found[smp], want)
     assert want.sum() > 4000
-    want2, nch2 = _replay(str(tmp_path), "c4j2", b1, L, found, kc1, k, t, sb0)      # index set restricted to J1's result
     assert nch2 == 2 and np.array_equal(T2[smp0], want2)
-    want3, nch3 = _replay(str(tmp_path), "c4j3", b0, L, T2, kc, k, t, sb)
     assert nch3 == 2 and np.array_equal(T3[smp], want3)
     assert want2.sum() > 4000 and want3.sum() > 4000
 

@@ -44,6 +44,87 @@ def c2():
     ctx.close()
 
 
+def _sample_of(rng, n, extra=None):
+    parts = [rng.choice(n // 4, 6000, replace=False), n // 4 + rng.choice(n - n // 4, 14000, replace=False)]
+    if extra is not None:
+        parts.append(extra)
+    return np.unique(np.concatenate(parts))
+
+
+def _cpu_checker_on_sample(k, t, b0, o0, L, chunks, kc, sb):
+    """the reference's chunk loop on the CPU checker: every chunk's filter from the whole index set, the sample searched
+    against it (reads found in an earlier chunk are skipped, as FileManager's tags make the reference do)"""
+    ns = sb.size // L
+    so = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
+    found = np.zeros(ns // 8 + 1, dtype=np.uint8)
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        fed = f.index(b0[a * L: e * L], o0[a: e + 1] - o0[a])
+        assert fed == int(kc[a:e].sum())
+        fnd, _ = f.search(t, sb, so, ~found)
+        found |= fnd
+        f.close()
+    return util.bools_from_bits(found, ns)
+
+
+@pytest.fixture(scope="module")
+def cpu_runs(c2):
+    """The three full-size sample replays of this file (configs[1] at k = 32, the same sets at the reference's default
+    k = 33, configs[1]'s size with skewed sets) need ~45 s of ONE host core each — the CPU checker is the reference's
+    sequential algorithm — so the GPU jobs are run first and the three replays then run side by side in threads (the
+    checker is called through ctypes, which releases the interpreter lock)."""
+    import commet_amd
+    from commet_amd import synth
+    from concurrent.futures import ThreadPoolExecutor
+    n, L, t = c2["n"], c2["L"], 2
+    out = {}
+    # (a) configs[1], k = 32: the module's GPU job
+    kc32 = c2["irs"].kmer_counts()
+    ch32 = _chunks_from_counts(kc32, ob.max_kmer(32))
+    smp32 = _sample_of(np.random.default_rng(7), n)
+    out["c2"] = dict(sample=smp32, chunks=ch32)
+    # (b) the same sets at k = 33: 64-bit keys, a 4 GiB filter, one chunk, the tiled search on 64-bit keys
+    with commet_amd.Context(k=33, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(c2["b0"], c2["o0"])])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(c2["b1"], c2["o1"])])
+        kc33 = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        cache = qrs.cache_bytes
+        ctx.set_option("tiled_search", 1)
+        tags_g, stats_g, _ = ctx.index_and_search(irs, [qrs])
+    smp33 = _sample_of(np.random.default_rng(33), n)
+    out["k33"] = dict(tags=tags[0], stats=stats[0], info=info, times=times, cache=cache, tags_plain=tags_g[0], stats_plain=stats_g[0],
+                      sample=smp33, chunks=_chunks_from_counts(kc33, ob.max_kmer(33)), kc=kc33)
+    # (c) configs[1]'s size, 10 % of the reads low-complexity / repeated
+    sb0, so0 = synth.synth_set_skewed(0, n, L, 0.10)
+    sb1, so1 = synth.synth_set_skewed(1, n, L, 0.10)
+    with commet_amd.Context(k=32, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(sb0, so0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(sb1, so1)])
+        kcs = irs.kmer_counts()
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        ctx.set_option("index_mode", 1)
+        ctx.set_option("tiled_search", 1)
+        tags_a, stats_a, _ = ctx.index_and_search(irs, [qrs])            # atomic index kernel, gather search kernels
+    replaced = synth.skew_set(np.array(sb1), n, L, 1, 0.10)              # (the same draw: which reads of set 1 were replaced)
+    smps = _sample_of(np.random.default_rng(17), n, np.random.default_rng(18).choice(replaced, 4000, replace=False))
+    out["skew"] = dict(tags=tags[0], stats=stats[0], info=info, tags_atomic=tags_a[0], stats_atomic=stats_a[0], sample=smps,
+                       replaced=replaced, chunks=_chunks_from_counts(kcs, ob.max_kmer(32)))
+
+    def pick(b, smp):
+        return np.ascontiguousarray(b.reshape(n, L)[smp]).reshape(-1)
+
+    with ThreadPoolExecutor(3) as pool:
+        fa = pool.submit(_cpu_checker_on_sample, 32, t, c2["b0"], c2["o0"], L, ch32, kc32, pick(c2["b1"], smp32))
+        fb = pool.submit(_cpu_checker_on_sample, 33, t, c2["b0"], c2["o0"], L, out["k33"]["chunks"], kc33, pick(c2["b1"], smp33))
+        fc = pool.submit(_cpu_checker_on_sample, 32, t, sb0, so0, L, out["skew"]["chunks"], kcs, pick(sb1, smps))
+        out["c2"]["want"], out["k33"]["want"], out["skew"]["want"] = fa.result(), fb.result(), fc.result()
+    return out
+
+
 def test_c2_counts_are_consistent(c2):
     n = c2["n"]
     found = util.bools_from_bits(c2["tags"], n)
@@ -55,26 +136,11 @@ def test_c2_counts_are_consistent(c2):
     assert found[: n // 4].mean() > 0.85 and found[n // 4:].mean() < 0.01
 
 
-def test_c2_sample_is_bit_exact_against_cpu_checker(c2):
-    k, t, n, L = 32, 2, c2["n"], c2["L"]
-    kc = c2["irs"].kmer_counts()
-    chunks = _chunks_from_counts(kc, ob.max_kmer(k))
-    assert len(chunks) == c2["info"]["n_chunks"]
-    rng = np.random.default_rng(7)
-    sample = np.sort(np.concatenate([rng.choice(n // 4, 6000, replace=False), n // 4 + rng.choice(n - n // 4, 14000, replace=False)]))
-    sb = c2["b1"].reshape(n, L)[sample].reshape(-1)
-    so = np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L)
-    found = np.zeros(len(sample) // 8 + 1, dtype=np.uint8)
-    for (a, e) in chunks:
-        f = ob.Bloom(k)
-        fed = f.index(c2["b0"][a * L: e * L], c2["o0"][a: e + 1] - c2["o0"][a])
-        assert fed == int(kc[a:e].sum())
-        active = ~found
-        fnd, _ = f.search(t, sb, so, active)
-        found |= fnd
-        f.close()
-    got = util.bools_from_bits(c2["tags"], n)[sample]
-    assert np.array_equal(got, util.bools_from_bits(found, len(sample)))
+def test_c2_sample_is_bit_exact_against_cpu_checker(c2, cpu_runs):
+    run = cpu_runs["c2"]
+    assert len(run["chunks"]) == c2["info"]["n_chunks"]
+    got = util.bools_from_bits(c2["tags"], c2["n"])[run["sample"]]
+    assert np.array_equal(got, run["want"])
     assert got.sum() > 4000                                               # the sample does contain shared reads
 
 
@@ -104,81 +170,34 @@ def test_c2_properties(c2):
         assert fs[clean & ~dropped].all()
 
 
-def test_k33_default_k_sample_is_bit_exact_against_cpu_checker(c2):
+def test_k33_default_k_sample_is_bit_exact_against_cpu_checker(c2, cpu_runs):
     """the reference's DEFAULT k (index_and_search.cpp:71, Commet.py:453) on configs[1]'s sets: 64-bit keys, a 4 GiB filter,
     one chunk (6.8e8 k-mers < max_kmer = 1e9), the tiled search on 64-bit keys (tq_*<uint64_t>); bit-exact on a sample,
     and the same bits from the plain search kernel"""
-    import commet_amd
-    k, t, n, L = 33, 2, c2["n"], c2["L"]
-    with commet_amd.Context(k=k, t=t) as ctx:
-        irs = commet_amd.ReadSet.from_files(ctx, [(c2["b0"], c2["o0"])])
-        qrs = commet_amd.ReadSet.from_files(ctx, [(c2["b1"], c2["o1"])])
-        kc = irs.kmer_counts()
-        ctx.set_option("kernel_timing", 1)
-        tags, stats, info = ctx.index_and_search(irs, [qrs])
-        times = ctx.kernel_times()
-        ctx.set_option("kernel_timing", 0)
-        assert info["n_chunks"] == 1 and "tq_replay_kernel" in times and "search_kernel" not in times
-        assert qrs.cache_bytes > 0
-        ctx.set_option("tiled_search", 1)
-        tags_g, stats_g, _ = ctx.index_and_search(irs, [qrs])
-        assert np.array_equal(tags_g[0], tags[0])
-        assert (stats_g[0]["indexed"], stats_g[0]["searched"], stats_g[0]["shared"]) == (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"])
-    chunks = _chunks_from_counts(kc, ob.max_kmer(k))
-    assert len(chunks) == 1 and stats[0]["indexed"] == n
-    rng = np.random.default_rng(33)
-    sample = np.sort(np.concatenate([rng.choice(n // 4, 6000, replace=False), n // 4 + rng.choice(n - n // 4, 14000, replace=False)]))
-    sb = c2["b1"].reshape(n, L)[sample].reshape(-1)
-    so = np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L)
-    f = ob.Bloom(k)
-    fed = f.index(c2["b0"], c2["o0"])
-    assert fed == int(kc.sum()) == info["kmers_indexed"]
-    fnd, _ = f.search(t, sb, so, np.full(len(sample) // 8 + 1, 255, dtype=np.uint8))
-    f.close()
-    got = util.bools_from_bits(tags[0], n)[sample]
-    assert np.array_equal(got, util.bools_from_bits(fnd, len(sample)))
-    assert got.sum() > 4000 and stats[0]["shared"] == int(util.bools_from_bits(tags[0], n).sum())
+    run, n = cpu_runs["k33"], c2["n"]
+    assert run["info"]["n_chunks"] == 1 == len(run["chunks"]) and run["stats"]["indexed"] == n
+    assert "tq_replay_kernel" in run["times"] and "search_kernel" not in run["times"] and run["cache"] > 0
+    assert np.array_equal(run["tags_plain"], run["tags"])
+    assert [run["stats_plain"][f] for f in ("indexed", "searched", "shared")] == [run["stats"][f] for f in ("indexed", "searched", "shared")]
+    assert run["info"]["kmers_indexed"] == int(run["kc"].sum())
+    got = util.bools_from_bits(run["tags"], n)[run["sample"]]
+    assert np.array_equal(got, run["want"])
+    assert got.sum() > 4000 and run["stats"]["shared"] == int(util.bools_from_bits(run["tags"], n).sum())
 
 
-def test_c2_sized_skewed_sets_sample_is_bit_exact_against_cpu_checker():
+def test_c2_sized_skewed_sets_sample_is_bit_exact_against_cpu_checker(c2, cpu_runs):
     """configs[1]'s size with 10 % of every set's reads low-complexity or repeated (poly-A, tandem repeats, a shared
-    library of 1000 reads: synth.skew_set) — hot buckets in hist / scatter / build (split tiles), heavy scans in the
-    search.  Bit-exact on a sample that holds 4000 of the replaced reads; atomic and bucketed constructions agree."""
-    import commet_amd
-    from commet_amd import synth
-    k, t, n, L = 32, 2, 10_000_000, 100
-    b0, o0 = synth.synth_set_skewed(0, n, L, 0.10)
-    b1, o1 = synth.synth_set_skewed(1, n, L, 0.10)
-    with commet_amd.Context(k=k, t=t) as ctx:
-        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
-        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
-        kc = irs.kmer_counts()
-        tags, stats, info = ctx.index_and_search(irs, [qrs])
-        ctx.set_option("index_mode", 1)
-        ctx.set_option("tiled_search", 1)
-        tags_a, stats_a, _ = ctx.index_and_search(irs, [qrs])            # atomic index kernel, gather search kernels
-        assert np.array_equal(tags_a[0], tags[0]) and stats_a[0]["shared"] == stats[0]["shared"]
-    chunks = _chunks_from_counts(kc, ob.max_kmer(k))
-    assert len(chunks) == info["n_chunks"] == 2
-    rng = np.random.default_rng(17)
-    replaced = synth.skew_set(np.array(b1), n, L, 1, 0.10)               # (the same draw: which reads of set 1 were replaced)
-    sample = np.unique(np.concatenate([rng.choice(n // 4, 5000, replace=False), n // 4 + rng.choice(n - n // 4, 11000, replace=False),
-                                       rng.choice(replaced, 4000, replace=False)]))
-    sb = np.ascontiguousarray(b1.reshape(n, L)[sample]).reshape(-1)
-    so = np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L)
-    found = np.zeros(len(sample) // 8 + 1, dtype=np.uint8)
-    for (a, e) in chunks:
-        f = ob.Bloom(k)
-        fed = f.index(b0[a * L: e * L], o0[a: e + 1] - o0[a])
-        assert fed == int(kc[a:e].sum())
-        fnd, _ = f.search(t, sb, so, ~found)
-        found |= fnd
-        f.close()
-    got = util.bools_from_bits(tags[0], n)[sample]
-    assert np.array_equal(got, util.bools_from_bits(found, len(sample)))
+    library of 1000 reads: synth.skew_set) — hot buckets in hist / scatter / build (split tiles, the aggregated atomics
+    of scatter2), heavy scans in the search.  Bit-exact on a sample that holds 4000 of the replaced reads; atomic and
+    bucketed constructions agree."""
+    run, n = cpu_runs["skew"], c2["n"]
+    assert np.array_equal(run["tags_atomic"], run["tags"]) and run["stats_atomic"]["shared"] == run["stats"]["shared"]
+    assert len(run["chunks"]) == run["info"]["n_chunks"] == 2
+    got = util.bools_from_bits(run["tags"], n)[run["sample"]]
+    assert np.array_equal(got, run["want"])
     # the replaced reads are mostly shared (every set holds poly-A reads, the same repeat units, the same library)
-    is_rep = np.isin(sample, replaced)
-    assert got[is_rep].mean() > 0.6 and got.sum() > 5000
+    is_rep = np.isin(run["sample"], run["replaced"])
+    assert is_rep.sum() >= 4000 and got[is_rep].mean() > 0.6 and got.sum() > 5000
 
 
 @pytest.mark.parametrize("n_index,n_query", [(30000, 30000)])

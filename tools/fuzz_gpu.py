@@ -68,7 +68,7 @@ def main():
                     ctx.set_option("index_mode", 0)   # forced on a set it does not take (k, or a read of more than 4096 k-mers)
                     tags, stats, info = ctx.index_and_search(irs, [x[0] for x in loaded], isel, [x[1] for x in loaded])
                 if hook:
-                    for opt, v in (("slice_mode", 1), ("slice_wide", 1), ("tiled_search", 1), ("chunk_group", 1)):
+                    for opt, v in (("slice_mode", 1), ("slice_wide", 1), ("tiled_search", 1), ("chunk_group", 1), ("index_mode", 0)):
                         ctx.set_option(opt, v)   # one chunk filter at a time, search_kernel: the reference's own order
                     t2, s2, i2 = ctx.index_and_search(irs, [x[0] for x in loaded], isel, [x[1] for x in loaded])
                     ok = info["n_chunks"] == i2["n_chunks"] and info["kmers_indexed"] == i2["kmers_indexed"]   # (other chunks drop other look-ahead reads than the checker's)
