@@ -169,6 +169,44 @@ __device__ __forceinline__ void for_each_bucket32(const uint32_t *p, uint32_t le
     }
 }
 
+// The same for 64-bit keys (k = 33, 34; round 3): the rolling part only looks at the bases that enter — position - TILE_BITS
+// for the oldest groups, the position itself for the newest — which lie in word triples w - 1 and w whatever k; only the
+// octet's first window needs the three-word extraction.  planes: the planes whose buckets the pass counts (two passes of
+// two planes at k = 33, four of one at k = 34: 2^16 / 2^17 counters do not fit the LDS).
+template <typename F>
+__device__ __forceinline__ void for_each_bucket64(const uint32_t *p, uint32_t len, uint32_t q, int k, uint32_t planes, F &&f)
+{
+    const uint32_t w = q >> 2, j0 = (q & 3u) * 8u;
+    ItemWords<uint64_t> it;
+    it.load(p, w);
+    const int nbits = k - TILE_BITS;                      // 14, 15 <= k / 2
+    const uint64_t mask = (1ull << k) - 1ull;
+    const uint32_t nmask = (1u << nbits) - 1u;
+    uint64_t wh, wl;
+    (void) it.window(j0, k, mask, wh, wl);
+    const uint64_t vw = ItemWords<uint64_t>::ext(it.va, 65u + j0 - (uint32_t) k, mask);
+    uint32_t a_top = (uint32_t) (__brevll(wh) >> (64 - nbits)), b_top = (uint32_t) (__brevll(wl) >> (64 - nbits));
+    uint32_t w_top = (uint32_t) (wh >> (k - nbits));
+    uint32_t run = (uint32_t) __clzll((long long) ~(vw << (64 - k)));   // valid bases in a row up to j0, counted up to k
+    const uint64_t hi64 = ((uint64_t) it.hi[2] << 32) | it.hi[1], lo64 = ((uint64_t) it.lo[2] << 32) | it.lo[1];
+    const uint32_t cA = (uint32_t) (hi64 >> (32u - TILE_BITS + j0)), cB = (uint32_t) (lo64 >> (32u - TILE_BITS + j0));
+    const uint32_t cW = it.hi[2] >> j0, cV = it.va[2] >> j0;
+#pragma unroll
+    for (uint32_t jj = 0; jj < 8; ++jj) {
+        if (jj) {
+            a_top = ((a_top << 1) | ((cA >> jj) & 1u)) & nmask;
+            b_top = ((b_top << 1) | ((cB >> jj) & 1u)) & nmask;
+            w_top = (w_top >> 1) | (((cW >> jj) & 1u) << (nbits - 1));
+            run = ((cV >> jj) & 1u) ? run + 1u : 0u;
+        }
+        if (run < (uint32_t) k || 32u * w + j0 + jj >= len) continue;
+        if (planes & 1u) f(0u, a_top ^ w_top ^ nmask);
+        if (planes & 2u) f(1u, b_top);
+        if (planes & 4u) f(2u, a_top ^ b_top);
+        if (planes & 8u) f(3u, a_top | b_top);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // block-level helpers (256 threads)
 // ---------------------------------------------------------------------------
@@ -397,7 +435,11 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     if (FULL) planes = 15u;
     // k <= 32 (always FULL): the buckets come from rolled top bits (for_each_bucket32)
     constexpr bool ROLL = FULL && sizeof(W) == 4 && HIST_ROLLING;
+    constexpr bool ROLL64 = !FULL && sizeof(W) == 8 && HIST_ROLLING;       // k = 33, 34: the same rolling, pass by pass
     auto add_bucket = [&](uint32_t plane, uint32_t bucket) { atomicAdd(h + (plane << g.plane_shift) + bucket, 1u); };
+    // (a pass of 64-bit keys covers whole planes: HIST_MAX_BUCKETS is a multiple of a plane's 2^(k - 19) buckets, so the
+    // planes mask alone decides and the bucket's place in the pass is its number minus b_lo)
+    auto add_bucket_rel = [&](uint32_t plane, uint32_t bucket) { atomicAdd(h + ((plane << g.plane_shift) + bucket - b_lo), 1u); };
     auto add = [&](uint32_t plane, W key) {
         if (FULL) {
             atomicAdd(h + (plane << g.plane_shift) + (uint32_t) (key >> TILE_BITS), 1u);
@@ -421,6 +463,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
             const uint32_t dpos = NT / opr, dq = NT % opr;
             for (uint64_t id = threadIdx.x; id < total; id += NT) {
                 if constexpr (ROLL) for_each_bucket32(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add_bucket);
+                else if constexpr (ROLL64) for_each_bucket64(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, planes, add_bucket_rel);
                 else for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add, planes);
                 rd += dpos, q += dq;
                 if (q >= opr) q -= opr, ++rd;
@@ -433,6 +476,7 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
                     uint32_t slot, q;
                     item_lookup(istart, rp.n_reads, id, g.k, slot, q);
                     if constexpr (ROLL) for_each_bucket32(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add_bucket);
+                    else if constexpr (ROLL64) for_each_bucket64(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, planes, add_bucket_rel);
                     else for_each_key<W, true>(rv.planes + 3 * rd_t0[slot], rd_len[slot], q, g.k, add, planes);
                 }
                 __syncthreads();
