@@ -222,6 +222,7 @@ struct commet_ctx {
     std::mutex ql_mu;                                 // guards the registry and every query list of the context
     std::vector<commet_readset *> sets;               // read sets alive on this context
     uint64_t ql_bytes = 0, ql_budget = 64ull << 30, ql_clock = 0, ql_evictions = 0;
+    uint64_t ql_max_list = 4ull << 30;                // auto mode: sets whose list (8 bytes per first-hit window, estimated) is larger keep the gather kernels
 
     uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
     FilterView view() const
@@ -403,6 +404,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
     c->job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
     c->ingest_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
+    if (const char *e = getenv("COMMET_QUERY_LIST_MAX_GB")) c->ql_max_list = (uint64_t) (std::max(0.0, atof(e)) * (double) (1ull << 30));
     if (const char *e = getenv("COMMET_QUERY_LIST_GB")) c->ql_budget = (uint64_t) (std::max(0.0, atof(e)) * (double) (1ull << 30));
     if (const char *e = getenv("COMMET_SLICE_MODE")) c->slice_mode = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
     if (const char *e = getenv("COMMET_SLICE_WIDE")) c->slice_wide = std::max(0, std::min(2, atoi(e)));     // A/B runs of bench.py
@@ -1450,7 +1452,8 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     if (c->tiled_mode == 2) return true;
     // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB.  Measured
     // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
-    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= (4ull << 30);
+    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= c->ql_max_list &&
+           rs->n_reads * (uint64_t) first_hit_windows < (1ull << 32);   // (record numbers are 32 bits)
 }
 
 // the set's query list for this context's (k, t): counted, scanned, filled; kept with the set
@@ -2311,6 +2314,11 @@ int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, u
 
 int commet_set_option(commet_ctx *c, const char *name, int64_t value)
 {
+    if (!strcmp(name, "query_list_max_mb")) {      // auto mode: largest list (estimated) a set may get; larger sets keep the gather kernels
+        if (value < 0) return fail("query_list_max_mb must be >= 0");
+        c->ql_max_list = (uint64_t) value << 20;
+        return 0;
+    }
     if (!strcmp(name, "query_list_budget_mb")) {   // HBM the cached query lists of this context's read sets may hold (default 64 GiB)
         if (value < 0) return fail("query_list_budget_mb must be >= 0");
         std::lock_guard<std::mutex> lk(c->ql_mu);
