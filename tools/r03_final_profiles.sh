@@ -1,0 +1,5 @@
+# the round's final rocprofv3 passes: configs[1] (r03_final) and configs[4] (r03_c5), bench lines priced with them
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+bash $R/tools/profile_bench.sh r03_final --cpu-sample 0 > $O/r03_final.log 2>&1; tail -1 $O/r03_final.log | cut -c1-900
+bash $R/tools/profile_bench.sh r03_c5 -k 21 -t 5 --reads 20000000 --read-len 150 --steps 1 --warmup 0 --cpu-sample 0 --no-probe-count --kt-steps 1 > $O/r03_c5.log 2>&1; tail -1 $O/r03_c5.log | cut -c1-1200
