@@ -195,7 +195,7 @@ int commet_index_and_search(commet_ctx *ctx,
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
  *                        for read sets with at most 96 first-hit windows per read, else 4)
- *   tiled_search (0/1/2) large search sets against 1 or 2 chunk filters (24 <= k <= 32): lane-a gathers served from L2 slice
+ *   tiled_search (0/1/2) large search sets against 1 or 2 chunk filters (25 <= k <= 34): lane-a gathers served from L2 slice
  *                        by slice from the set's cached query list; 0 = sets of 2^20 reads or more whose list fits 4 GiB,
  *                        1 = never, 2 = whenever possible
  *   slice_mode (0/1/2)   many-small-chunks regime (12 <= k <= 24): the filters of 32..256 chunks bit-sliced in one table
@@ -205,6 +205,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        group of lanes per read (search_wide_kernel): 0 = jobs of more than 256 chunks, 1 = never, 2 = always
  *   slice_wide_words     cap on the words per wide row (a multiple of 8, 32 chunk filters per word; 0 = by the memory free)
  *   query_list_budget_mb HBM the cached query lists of the context's read sets may hold (see commet_readset_cache_bytes)
+ *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096
+ *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
  *   kernel_timing (0/1)  time every kernel launch of commet_index_and_search (commet_kernel_times)
