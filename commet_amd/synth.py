@@ -41,9 +41,11 @@ def synth_set(set_id, n_reads, read_len, seed_base=1000, copy_frac=0.25, sub_rat
                 cp[idx] = 3 - (cp[idx, ::-1] & 3)        # A<->T, C<->G
             codes[:ncopy * read_len] = flat
             del cp, flat, raw0
-    del codes
-    bases = np.frombuffer(raw.translate(_FOLD), dtype=np.uint8)
-    del raw
+    # codes -> ASCII in place, a block at a time (a 50 M-read set is 5 GB: no second copy of it)
+    lut = np.frombuffer(_FOLD, dtype=np.uint8)
+    for i in range(0, total, 1 << 26):
+        codes[i:i + (1 << 26)] = lut[codes[i:i + (1 << 26)]]
+    bases = codes
     nn = int(rng.binomial(total, n_rate)) if n_rate > 0 else 0
     if nn:
         bases[rng.integers(0, total, size=nn)] = ord("N")
@@ -84,7 +86,8 @@ def skew_set(bases, n_reads, read_len, set_id, frac=0.10, seed_base=7000, librar
 def synth_set_skewed(set_id, n_reads, read_len, frac=0.10, **kw):
     """synth_set with a `frac` of the reads replaced by low-complexity / repeated ones (skew_set)"""
     bases, offsets = synth_set(set_id, n_reads, read_len, **kw)
-    bases = np.array(bases)          # (synth_set's buffer is read-only)
+    if not bases.flags.writeable:
+        bases = np.array(bases)
     skew_set(bases, n_reads, read_len, set_id, frac)
     return bases, offsets
 
@@ -108,17 +111,21 @@ def write_fasta(path, bases, offsets, width=0, lowercase_every=0):
 def write_fasta_fast(path, bases, n_reads, read_len, digits=9):
     """Vectorised writer for fixed-length sets: header '>%0<digits>d', one sequence line."""
     rec = 1 + digits + 1 + read_len + 1
-    buf = np.empty((n_reads, rec), dtype=np.uint8)
-    buf[:, 0] = ord(">")
-    idx = np.arange(n_reads, dtype=np.int64)
-    for d in range(digits):
-        buf[:, digits - d] = (idx % 10 + ord("0")).astype(np.uint8)
-        idx //= 10
-    buf[:, 1 + digits] = ord("\n")
-    buf[:, 2 + digits:2 + digits + read_len] = np.asarray(bases, dtype=np.uint8).reshape(n_reads, read_len)
-    buf[:, -1] = ord("\n")
+    view = np.asarray(bases, dtype=np.uint8).reshape(n_reads, read_len)
+    block = 1 << 20                                       # records per write: the file image is never held whole
     with open(path, "wb") as fh:
-        fh.write(buf.tobytes())
+        for r0 in range(0, n_reads, block):
+            m = min(block, n_reads - r0)
+            buf = np.empty((m, rec), dtype=np.uint8)
+            buf[:, 0] = ord(">")
+            idx = np.arange(r0, r0 + m, dtype=np.int64)
+            for d in range(digits):
+                buf[:, digits - d] = (idx % 10 + ord("0")).astype(np.uint8)
+                idx //= 10
+            buf[:, 1 + digits] = ord("\n")
+            buf[:, 2 + digits:2 + digits + read_len] = view[r0:r0 + m]
+            buf[:, -1] = ord("\n")
+            fh.write(buf.data)
 
 
 def write_set_fasta(args):
