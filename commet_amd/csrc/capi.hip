@@ -129,6 +129,8 @@ struct commet_ctx {
         }
     } part[2];
     unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
+    uint32_t *d_ids = nullptr, *d_idblk = nullptr;   // read numbers of the index selection of the running job, in order (sel_ids_kernel)
+    uint64_t ids_cap = 0, idblk_cap = 0;
     unsigned long long *d_plansum = nullptr;  // per-block k-mer sums of a selection (host planner input)
     uint64_t plansum_cap = 0;
     uint64_t jobcnt_cap = 0;
@@ -464,6 +466,8 @@ void commet_destroy(commet_ctx *c)
     (void) hipFree(c->il_a);
     (void) hipFree(c->d_jobcnt);
     (void) hipFree(c->d_plansum);
+    (void) hipFree(c->d_ids);
+    (void) hipFree(c->d_idblk);
     c->part[0].release();
     c->part[1].release();
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
@@ -1108,10 +1112,15 @@ bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
 // Bucketed construction of the filter for one chunk (index_part.hpp).  The
 // filter must have been zeroed on the stream before.  kmers = exact number of
 // complete k-mers of the selected reads of [first, first+count).
+// d_ids != nullptr (fixed-length sets only): the chunk's selected reads are ids[pos_first .. pos_first + pos_count) (sel_ids_kernel);
+// hist and scatter1 then take the arithmetic item path over that list instead of planning rounds over the bitmap
 int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
-                             uint64_t kmers, bool additive, bool zero_fill, int lane = 0)
+                             uint64_t kmers, bool additive, bool zero_fill, int lane = 0, const uint32_t *d_ids = nullptr,
+                             uint64_t pos_first = 0, uint64_t pos_count = 0)
 {
     if (count == 0 || kmers == 0) return 0;
+    if (d_ids && rs->uniform_len != 0 && !c->part_no_uni && pos_count) first = pos_first, count = pos_count, d_sel = nullptr;
+    else d_ids = nullptr;
     commet_ctx::PartWs &ws = c->part[lane];
     hipStream_t stream = lane ? c->aux_stream : c->stream;
     uint32_t *const slot = c->slot_ptr(c->cur_slot);
@@ -1153,7 +1162,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     }
     const bool wide = c->k > 32;
     // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
-    const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;
+    const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;   // (d_ids: positions in the list of selected reads)
     HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
     // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
     const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
@@ -1173,7 +1182,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             const uint32_t *kc = rs->d_kcnt;
             uint32_t *hist = ws.hist, *bcnt = ws.blockcnt;
             uint32_t nblk = grid1;
-            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt};
+            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt, &d_ids};
             KScope ks(c, "part_hist_kernel", stream);
             note_launch(fn);
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
@@ -1202,7 +1211,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         ReadsView rv = rs->view();
         const uint32_t *kc = rs->d_kcnt;
         const unsigned long long *boff = ws.blockoff;
-        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out};
+        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out, &d_ids};
         KScope ks(c, "part_scatter1_kernel", stream);
         note_launch(fn);
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
@@ -1257,7 +1266,7 @@ bool would_partition(const commet_ctx *c, const commet_readset *rs, uint64_t kme
 // zero-fills what it does not set; the atomic kernel always needs a zeroed filter).
 int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
                  unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false, bool filter_zeroed = true,
-                 int lane = 0)
+                 int lane = 0, const uint32_t *d_ids = nullptr, uint64_t pos_first = 0, uint64_t pos_count = 0)
 {
     if (c->index_mode == 2) {
         if (!partition_eligible(c, rs)) return fail("bucketed index construction needs 20 <= k <= 34 and reads of at most %u k-mers", S1_KEYS / 4);
@@ -1273,7 +1282,8 @@ int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64
         HIP_OK(hipMemcpyAsync(d_fed, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
-    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed, lane);
+    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed, lane, d_ids, pos_first,
+                                    pos_count);
 }
 
 // min_hits as the kernels get it: a read of max_len bases holds at most max_len / k non-overlapping k-mers, so every
@@ -1963,6 +1973,39 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     lap(ph_plan);
     // a dense plan indexes whole read ranges: no bitmap needed on the device
     if (!plan.dense && upload_bits(c, index_rs->d_sel, plan.indexed_bits.data(), index_rs->n_reads)) return 1;
+    // a selection on a fixed-length set (Commet.py's J2 / J3 jobs): the selected reads' numbers as a list, so that the
+    // bucketed build walks them arithmetically (index_part.hpp, sel_ids_kernel); chunk j's reads are the next n_reads of the list
+    const uint32_t *d_ids = nullptr;
+    std::vector<uint64_t> chunk_pos;
+    uint64_t ids_expected = ~0ull;
+    if (!plan.dense && index_rs->uniform_len != 0 && !c->part_no_uni && plan.indexed_reads && c->index_mode != 1) {
+        const uint64_t n_words = bitmap_words(index_rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
+        bool ok = true;
+        if (c->ids_cap < plan.indexed_reads || c->idblk_cap < nb + 1) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void) hipFree(c->d_ids), (void) hipFree(c->d_idblk);
+            c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(plan.indexed_reads, index_rs->n_reads / 2);   // (grown rarely)
+            ok = dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true) == hipSuccess &&
+                 dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true) == hipSuccess;
+            if (ok) c->ids_cap = cap, c->idblk_cap = nb + 1;
+            else (void) hipGetLastError();              // no room: the round planner walks the bitmap, as before
+        }
+        if (ok) {
+            KScope ks(c, "sel_ids_kernels", c->stream);
+            COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, index_rs->d_sel, n_words, c->d_idblk);
+            COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_idblk, (uint32_t) nb);
+            COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, index_rs->d_sel, n_words, c->d_idblk, c->d_ids);
+            HIP_OK(hipGetLastError());
+            // (the list must hold exactly the plan's indexed reads: checked when the job's stream is next synchronised)
+            c->h_counters[N_COUNTERS - 1] = ~0ull;
+            HIP_OK(hipMemcpyAsync(&c->h_counters[N_COUNTERS - 1], c->d_idblk + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            ids_expected = plan.indexed_reads;
+            d_ids = c->d_ids;
+            uint64_t at = 0;
+            for (const Chunk &ch : plan.chunks) chunk_pos.push_back(at), at += ch.n_reads;
+        }
+    }
     lap(ph_upload);
     for (int s = 0; s < n_search; ++s) {
         const commet_readset *rs = search_rs[s];
@@ -2152,7 +2195,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
             }
             if (ch.n_reads) {
                 if (launch_index(c, index_rs, ch.first, ch.last - ch.first + 1, plan.dense ? nullptr : index_rs->d_sel, nullptr, ch.kmers, true, !self_zeroing,
-                                 lanes ? (i & 1) : 0)) { rc = 1; break; }
+                                 lanes ? (i & 1) : 0, d_ids, d_ids ? chunk_pos[ci + i] : 0, ch.n_reads)) { rc = 1; break; }
                 ++n_index_launches;
             }
         }
@@ -2218,6 +2261,9 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
     c->kclock.collect();
     lap(ph_wait);
+    if (!rc && d_ids && (c->h_counters[N_COUNTERS - 1] & 0xFFFFFFFFull) != (ids_expected & 0xFFFFFFFFull))
+        rc = fail("internal error: the selection list holds %llu reads, the plan indexes %llu", (unsigned long long) (c->h_counters[N_COUNTERS - 1] & 0xFFFFFFFFull),
+                  (unsigned long long) ids_expected);
 
     if (!rc) {
         uint64_t scans = 0;

@@ -399,6 +399,59 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
 }
 
 // ---------------------------------------------------------------------------
+// Read numbers of the set bits of a selection bitmap, in order (round 3).  Commet.py's J2 / J3 jobs index a set restricted
+// to the previous job's result (Commet.py:220, 233): ~22 % of the reads.  Walking such a selection with the round planner
+// (plan_round: two block scans and barriers per 512 items, most of the reads it looks at not selected) made hist and
+// scatter1 2.3x as expensive per indexed read as the arithmetic item path of unselected fixed-length sets.  With the
+// selected reads' numbers in a list, item i of a piece is octet i % opr of read ids[i / opr]: the same arithmetic path.
+// Three small launches per job: set bits per block of 4096 reads, their exclusive scan, the ids.
+// ---------------------------------------------------------------------------
+constexpr uint32_t IDS_BLOCK_WORDS = 64;                  // bitmap words (64 reads each) per block
+__global__ __launch_bounds__(64) void sel_count_kernel(const uint64_t *__restrict__ sel, uint64_t n_words, uint32_t *__restrict__ blk)
+{
+    const uint64_t w = (uint64_t) blockIdx.x * IDS_BLOCK_WORDS + threadIdx.x;
+    uint32_t c = w < n_words ? (uint32_t) __popcll(sel[w]) : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (threadIdx.x == 0) blk[blockIdx.x] = c;
+}
+
+// in-place exclusive scan of blk[0 .. nb), blk[nb] = total; one workgroup, strips of 1024
+__global__ __launch_bounds__(1024) void sel_scan_kernel(uint32_t *__restrict__ blk, uint32_t nb)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? blk[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan<1024>(v, wsum, &tot);
+        const uint32_t c = carry;
+        if (i < nb) blk[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blk[nb] = carry;
+}
+
+__global__ __launch_bounds__(64) void sel_ids_kernel(const uint64_t *__restrict__ sel, uint64_t n_words, const uint32_t *__restrict__ blk,
+                                                     uint32_t *__restrict__ ids)
+{
+    const uint64_t w = (uint64_t) blockIdx.x * IDS_BLOCK_WORDS + threadIdx.x;
+    uint64_t bits = w < n_words ? sel[w] : 0ull;
+    const uint32_t c = (uint32_t) __popcll(bits);
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(inc, o, 64);
+        if ((int) threadIdx.x >= o) inc += x;
+    }
+    uint32_t at = blk[blockIdx.x] + inc - c;
+    for (; bits; bits &= bits - 1ull) ids[at++] = (uint32_t) (w * 64ull + (uint64_t) (__ffsll((long long) bits) - 1));
+}
+
+// ---------------------------------------------------------------------------
 // hist: bucket histogram of the chunk, buckets [b_lo, b_lo + n_b) in LDS
 // ---------------------------------------------------------------------------
 // UNI: every read has rv.uniform_len bases and no selection bitmap applies.  Item i of a block's read range is then
@@ -414,8 +467,9 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
                                                             const uint64_t *__restrict__ sel, uint64_t first,
                                                             uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
                                                             uint32_t *__restrict__ hist, uint32_t n_blk1,
-                                                            uint32_t *__restrict__ blockcnt)
+                                                            uint32_t *__restrict__ blockcnt, const uint32_t *__restrict__ ids)
 {
+    // UNI with ids != nullptr: [first, first + count) are POSITIONS in the list of selected reads (sel_ids_kernel)
     constexpr int NT = HIST_NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *h = smem;                            // n_b counters
@@ -462,9 +516,11 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
             uint32_t q = threadIdx.x % opr;
             const uint32_t dpos = NT / opr, dq = NT % opr;
             for (uint64_t id = threadIdx.x; id < total; id += NT) {
-                if constexpr (ROLL) for_each_bucket32(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add_bucket);
-                else if constexpr (ROLL64) for_each_bucket64(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, planes, add_bucket_rel);
-                else for_each_key<W, true>(rv.planes + 3 * (((rd * L) >> 5) + rd), L, q + q_first, g.k, add, planes);
+                const uint64_t rn = ids ? (uint64_t) ids[rd] : rd;          // the read's number
+                const uint32_t *rp = rv.planes + 3 * (((rn * L) >> 5) + rn);
+                if constexpr (ROLL) for_each_bucket32(rp, L, q + q_first, g.k, add_bucket);
+                else if constexpr (ROLL64) for_each_bucket64(rp, L, q + q_first, g.k, planes, add_bucket_rel);
+                else for_each_key<W, true>(rp, L, q + q_first, g.k, add, planes);
                 rd += dpos, q += dq;
                 if (q >= opr) q -= opr, ++rd;
             }
@@ -628,8 +684,9 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
                                                               const uint64_t *__restrict__ sel, uint64_t first,
                                                               uint64_t count, PartGeom g,
                                                               const unsigned long long *__restrict__ blockoff,
-                                                              uint32_t *__restrict__ out)
+                                                              uint32_t *__restrict__ out, const uint32_t *__restrict__ ids)
 {
+    // UNI with ids != nullptr: [first, first + count) are POSITIONS in the list of selected reads (sel_ids_kernel)
     constexpr int NT = S1_NT;
     constexpr bool WIDE = sizeof(W) == 8;          // 33 <= k <= 34: keys of 33 / 34 bits
     constexpr uint32_t NTR = WIDE ? 3u : 2u;       // word triples a k-mer window can span
@@ -686,10 +743,22 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     };
     // (threads without an item load the block's first triple instead: an unconditional load needs no register copies,
     // which the compiler would otherwise park right behind the load together with a wait)
+    // ids: the read number of an item is a load of its own; the one of the item AFTER the coming one is fetched a round ahead
+    // (nid), so that the prefetch of the words never waits for it
+    auto read_no = [&](uint64_t pos) -> uint64_t { return ids ? (uint64_t) ids[pos] : pos; };
+    auto advance = [&](uint64_t &rd, uint32_t &q) {
+        rd += u_dpos, q += u_dq;
+        if (q >= opr) q -= opr, ++rd;
+    };
+    uint64_t nid = 0;                                    // read number of the item of the round after the coming one
     if (UNI && u_total) {
         const bool in = threadIdx.x < u_total;
-        pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
+        pre_load(uni_ptr(read_no(in ? u_rd : r)), in ? (u_q + q_first) >> 2 : 0u);
         pre_claim();
+        uint64_t rd2 = u_rd;
+        uint32_t q2 = u_q;
+        advance(rd2, q2);
+        nid = read_no((uint64_t) NT + threadIdx.x < u_total ? rd2 : r);
     }
     while (UNI ? u_done < u_total : r < r_end) {
         RoundPlan rp;
@@ -756,10 +825,13 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         }
         if (UNI) {   // next round's item; its words travel while this round is sorted and written
             u_done += NT;
-            u_rd += u_dpos, u_q += u_dq;
-            if (u_q >= opr) u_q -= opr, ++u_rd;
+            advance(u_rd, u_q);
             const bool in = u_done + threadIdx.x < u_total;
-            pre_load(uni_ptr(in ? u_rd : r), in ? (u_q + q_first) >> 2 : 0u);
+            pre_load(uni_ptr(nid), in ? (u_q + q_first) >> 2 : 0u);          // (nid = the block's first read when there is no item)
+            uint64_t rd2 = u_rd;
+            uint32_t q2 = u_q;
+            advance(rd2, q2);
+            nid = read_no(u_done + NT + threadIdx.x < u_total ? rd2 : r);    // used a round from now
         }
         __syncthreads();
         if (!ALIGNED) {
