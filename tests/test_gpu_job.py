@@ -295,3 +295,55 @@ def test_record_longer_than_a_staging_buffer(tmp_path):
         assert (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]) == (res[0]["indexed"], res[0]["searched"], res[0]["shared"])
         assert np.array_equal(util.bools_from_bits(tags[0], n), util.bools_from_bits(bits, n))
         assert stats[0]["shared"] >= 250
+
+
+@pytest.mark.parametrize("k,L,density,max_kmer", [(25, 100, 0.02, 0), (25, 100, 0.3, 300000), (32, 100, 0.25, 0), (33, 101, 0.5, 400000), (21, 60, 0.9, 150000)])
+def test_selected_index_reads_as_a_list_match_the_round_planner(k, L, density, max_kmer):
+    """an index selection on a fixed-length set (Commet.py's J2 / J3 jobs) is compacted into a list of read numbers that
+    hist / scatter1 walk arithmetically (index_part.hpp, sel_ids_kernel): same bits as the round planner over the bitmap
+    (part_no_uni), as the atomic kernel, and as the CPU checker fed the selected reads chunk by chunk"""
+    import commet_amd as commet
+    import oracle_pool
+    rng = np.random.default_rng(1000 * k + int(100 * density))
+    n = 40000
+    idx_reads = util.random_reads(rng, n, L, L, n_rate=0.003)
+    q_reads = util.related_reads(rng, idx_reads, 20000, L, L, share=0.6, n_rate=0.003)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    sel = rng.random(n) < density
+    sel[:3] = [True, False, True]
+    sb = util.bits_from_bools(sel)
+    res = {}
+    with commet.Context(k=k, t=2) as ctx:
+        if max_kmer:
+            ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("index_mode", 2)
+        irs = commet.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+        kc = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        res["list"] = ctx.index_and_search(irs, [qrs], index_select=sb)
+        assert "sel_ids_kernels" in ctx.kernel_times()
+        ctx.set_option("kernel_timing", 1)
+        ctx.set_option("part_no_uni", 1)
+        res["planner"] = ctx.index_and_search(irs, [qrs], index_select=sb)
+        assert "sel_ids_kernels" not in ctx.kernel_times()
+        ctx.set_option("part_no_uni", 0)
+        ctx.set_option("index_mode", 1)
+        res["atomic"] = ctx.index_and_search(irs, [qrs], index_select=sb)
+    ids = np.flatnonzero(sel)
+    sib = np.ascontiguousarray(ib.reshape(n, L)[ids]).reshape(-1)
+    sio = np.arange(len(ids) + 1, dtype=np.uint64) * np.uint64(L)
+    chunks = oracle_pool.chunks_from_counts(kc[ids], max_kmer or ob.max_kmer(k))
+    found = np.zeros(len(q_reads) // 8 + 1, dtype=np.uint8)
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        f.index(sib[a * L: e * L], sio[a: e + 1] - sio[a])
+        fnd, _ = f.search(2, qb, qo, ~found)
+        found |= fnd
+        f.close()
+    for name, (tags, stats, info) in res.items():
+        assert info["n_chunks"] == len(chunks), name
+        assert np.array_equal(tags[0], found), name
+        assert stats[0]["indexed"] == sum(e - a for a, e in chunks), name
+    assert res["list"][1][0]["shared"] > 50
