@@ -200,6 +200,25 @@ class ReadSet:
         rs.finalize()
         return rs
 
+    def export(self):
+        """Descriptor + HIP IPC handles of the set's device buffers (bytes): another process of the node imports the set
+        from it, device to device, without a file.  This set must stay alive until every importer has returned."""
+        n = C.c_uint64(0)
+        self._check(self._lib.commet_readset_export(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._check(self._lib.commet_readset_export(self._h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    @classmethod
+    def import_(cls, ctx, blob):
+        """A set exported by another process of the node (ReadSet.export), copied device to device; finalizes."""
+        h = ctx._lib.commet_readset_import(ctx._h, blob, len(blob))
+        if not h:
+            raise CommetError(_err(ctx._lib))
+        rs = cls(ctx, 0, 0, _handle=h)
+        rs.finalize()
+        return rs
+
     def file_reads(self):
         return [int(self._lib.commet_readset_file_reads(self._h, i)) for i in range(self.num_files)]
 

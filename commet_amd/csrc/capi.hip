@@ -1053,6 +1053,101 @@ commet_readset *commet_readset_load(commet_ctx *c, const char *path)
     return rs;
 }
 
+/* ---- a resident set handed to another process of the node without a file ---------------------------------------- */
+namespace {
+struct ExportTail {                 // behind PackHeader + file spans + empty reads, 8-byte aligned
+    hipIpcMemHandle_t planes, goff;
+    int32_t device, has_goff;
+};
+}  // namespace
+
+int commet_readset_export(const commet_readset *rs, void *blob, uint64_t cap, uint64_t *blob_bytes)
+{
+    if (!rs->finalized) return fail("read set not finalized");
+    commet_ctx *c = rs->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    PackHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "CMTIPC1", 8);
+    h.n_reads = rs->n_reads, h.n_bases = rs->n_bases, h.triples = (rs->n_bases >> 5) + rs->n_reads + 1;
+    h.n_files = rs->files.size(), h.n_empty = rs->empty_reads.size();
+    h.uniform_len = rs->uniform_len, h.min_len = rs->min_len, h.max_len = rs->max_len;
+    const uint64_t files_at = align64(sizeof h), empty_at = files_at + h.n_files * sizeof(FileSpan);
+    const uint64_t tail_at = align64(empty_at + h.n_empty * 8), total = tail_at + sizeof(ExportTail);
+    if (blob_bytes) *blob_bytes = total;
+    if (!blob || cap < total) return blob ? fail("export buffer too small (%llu bytes needed)", (unsigned long long) total) : 0;   // (size query)
+    uint8_t *m = (uint8_t *) blob;
+    memset(m, 0, total);
+    memcpy(m, &h, sizeof h);
+    if (h.n_files) memcpy(m + files_at, rs->files.data(), h.n_files * sizeof(FileSpan));
+    if (h.n_empty) memcpy(m + empty_at, rs->empty_reads.data(), h.n_empty * 8);
+    ExportTail t;
+    memset(&t, 0, sizeof t);
+    t.device = c->device, t.has_goff = h.uniform_len ? 0 : 1;
+    HIP_OK(hipStreamSynchronize(c->load_stream));        // the planes are complete
+    HIP_OK(hipIpcGetMemHandle(&t.planes, rs->d_planes));
+    if (t.has_goff) HIP_OK(hipIpcGetMemHandle(&t.goff, rs->d_goff));
+    memcpy(m + tail_at, &t, sizeof t);
+    return 0;
+}
+
+commet_readset *commet_readset_import(commet_ctx *c, const void *blob, uint64_t blob_bytes)
+{
+    PackHeader h;
+    if (!blob || blob_bytes < sizeof h) {
+        fail("not an exported read set");
+        return nullptr;
+    }
+    memcpy(&h, blob, sizeof h);
+    const uint64_t files_at = align64(sizeof h);
+    if (memcmp(h.magic, "CMTIPC1", 8) != 0 || h.n_files > blob_bytes / sizeof(FileSpan) || h.n_empty > blob_bytes / 8 ||
+        h.triples != (h.n_bases >> 5) + h.n_reads + 1) {
+        fail("not an exported read set");
+        return nullptr;
+    }
+    const uint64_t empty_at = files_at + h.n_files * sizeof(FileSpan), tail_at = align64(empty_at + h.n_empty * 8);
+    if (tail_at + sizeof(ExportTail) != blob_bytes) {
+        fail("inconsistent exported read set");
+        return nullptr;
+    }
+    const uint8_t *m = (const uint8_t *) blob;
+    ExportTail t;
+    memcpy(&t, m + tail_at, sizeof t);
+    commet_readset *rs = commet_readset_create(c, h.n_reads, h.n_bases);
+    if (!rs) return nullptr;
+    const FileSpan *fs = (const FileSpan *) (m + files_at);
+    rs->files.assign(fs, fs + h.n_files);
+    const uint64_t *er = (const uint64_t *) (m + empty_at);
+    rs->empty_reads.assign(er, er + h.n_empty);
+    rs->n_reads = h.n_reads;
+    rs->n_bases = h.n_bases;
+    // the owner's buffers, mapped into this process (another device of the node: over xGMI), copied device to device
+    void *src_planes = nullptr, *src_goff = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&src_planes, t.planes, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess && t.has_goff) e = hipIpcOpenMemHandle(&src_goff, t.goff, hipIpcMemLazyEnablePeerAccess);
+    const uint32_t mm[3] = {h.n_reads ? h.min_len : 0xFFFFFFFFu, h.max_len, 0u};
+    if (e == hipSuccess) e = hipMemcpyAsync(rs->d_lenmm, mm, sizeof mm, hipMemcpyHostToDevice, c->load_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rs->d_planes, src_planes, h.triples * 12, hipMemcpyDeviceToDevice, c->load_stream);
+    if (e == hipSuccess && t.has_goff) e = hipMemcpyAsync(rs->d_goff, src_goff, (h.n_reads + 1) * 8, hipMemcpyDeviceToDevice, c->load_stream);
+    if (e == hipSuccess && h.n_reads) {
+        ReadsView v = rs->view();
+        v.uniform_len = h.uniform_len;
+        COMMET_LAUNCH(kmer_counts_kernel, dim3((unsigned) ((h.n_reads + 255) / 256)), dim3(256), 0, c->load_stream, v, c->k, rs->d_kcnt,
+                      rs->d_lenmm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->load_stream);
+    if (src_planes) (void) hipIpcCloseMemHandle(src_planes);
+    if (src_goff) (void) hipIpcCloseMemHandle(src_goff);
+    if (e != hipSuccess) {
+        fail("read set import failed (device %d -> %d): %s", t.device, c->device, hipGetErrorString(e));
+        (void) hipGetLastError();
+        commet_readset_destroy(rs);
+        return nullptr;
+    }
+    return rs;
+}
+
 uint64_t commet_readset_num_reads(const commet_readset *rs) { return rs->n_reads; }
 uint64_t commet_readset_num_files(const commet_readset *rs) { return rs->files.size(); }
 

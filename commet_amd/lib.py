@@ -53,6 +53,8 @@ SIGNATURES = {
     "commet_readset_from_buffers": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_char_p), u64p, C.c_int]),
     "commet_readset_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "commet_readset_load": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+    "commet_readset_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "commet_readset_import": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_readset_file_reads": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "commet_readset_finalize": (C.c_int, [C.c_void_p]),
     "commet_readset_num_reads": (C.c_uint64, [C.c_void_p]),

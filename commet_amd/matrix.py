@@ -155,6 +155,19 @@ class HipEngine:
     def load(self, path):
         return self._api.ReadSet.load(self.ctx, path)
 
+    def parse_probe(self):
+        """a tiny set of this rank's own, for the hand-over probe"""
+        b = np.frombuffer(b"ACGTTGCAACGTACGTTTGACCAGTACGATCGATCGGCTA" * 4, dtype=np.uint8)
+        o = np.arange(5, dtype=np.uint64) * np.uint64(40)
+        return self._api.ReadSet.from_files(self.ctx, [(b, o)])
+
+    def export_set(self, rs):
+        """bytes another rank imports the set from, device to device (HIP IPC); rs must outlive every import"""
+        return rs.export()
+
+    def import_set(self, blob):
+        return self._api.ReadSet.import_(self.ctx, blob)
+
     def file_reads(self, rs):
         return rs.file_reads()
 
@@ -265,9 +278,36 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # sets are made resident by a second thread while the jobs run (COMMET_MATRIX_PIPELINE=0: everything first)
     pipelined = N >= 2 and os.environ.get("COMMET_MATRIX_PIPELINE", "1") != "0"
     eng = (engine_factory or HipEngine)(k, t, ranks.local_rank)
+    # How a set parsed by one rank reaches the others: device to device over HIP IPC (the owner exports its buffers, the
+    # others copy them over xGMI: no file, tens of ms for a 50 M-read set) when every rank can import a probe set of its
+    # neighbour and of rank 0; else as a packed image in the scratch directory (0.5 s to write, 0.2 s to read).
+    use_ipc = False
+    if world > 1 and os.environ.get("COMMET_MATRIX_IPC", "1") != "0" and hasattr(eng, "export_set"):
+        probe = blob = None
+        try:
+            probe = eng.parse_probe()
+            blob = eng.export_set(probe)
+        except Exception as ex:
+            say(f"device-to-device hand-over of sets not available ({ex}): packed images instead")
+        blobs = ranks.gather_objects(blob)                        # (every rank, whatever happened above)
+        ok = int(blob is not None)
+        if ok:
+            try:
+                for src in sorted({0, (rank + 1) % world} - {rank}):
+                    if blobs[src] is None:
+                        ok = 0
+                    else:
+                        eng.release(eng.import_set(blobs[src]))
+            except Exception as ex:
+                say(f"device-to-device hand-over of sets not available ({ex}): packed images instead")
+                ok = 0
+        use_ipc = ranks.sum_int(ok) == world                      # (also: every import of the probes is done)
+        if probe is not None:
+            eng.release(probe)
+    exported = {}                                                 # sets this rank keeps alive for the others' imports
     loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
-                jobs=0, call_ms=0.0, device_ms=0.0,
+                jobs=0, call_ms=0.0, device_ms=0.0, handover="ipc" if use_ipc else "image",
                 predicted_share=round(sum(pair_cost[c] for c in runs[rank]) / max(sum(pair_cost), 1e-9), 4))   # what the static cut expects of this rank
     try:
         # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
@@ -284,11 +324,18 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             prof["sets_parsed"] += 1
             if s in needed_by_others:
                 w0 = time.perf_counter()
-                eng.save(rs, os.path.join(scratch, f"set{s}.pk"))
+                if use_ipc:                                       # a small descriptor file; the set stays alive for the importers
+                    path = os.path.join(scratch, f"set{s}.ipc")
+                    with open(path + ".tmp", "wb") as fh:
+                        fh.write(eng.export_set(rs))
+                    os.rename(path + ".tmp", path)
+                    exported[s] = rs
+                else:
+                    eng.save(rs, os.path.join(scratch, f"set{s}.pk"))
                 prof["save_s"] += time.perf_counter() - w0
             if s in needed:
                 sets[s] = rs
-            else:
+            elif s not in exported:
                 eng.release(rs)
 
         if not pipelined:
@@ -308,9 +355,13 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             _, sel[s] = concat_bits(parts)
 
         def fetch(s):
-            """another rank's set from its packed image"""
+            """another rank's set: from its owner's device buffers, or from its packed image"""
             w0 = time.perf_counter()
-            sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
+            if use_ipc:
+                with open(os.path.join(scratch, f"set{s}.ipc"), "rb") as fh:
+                    sets[s] = eng.import_set(fh.read())
+            else:
+                sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
             prof["load_s"] += time.perf_counter() - w0
             prof["sets_loaded"] += 1
 
@@ -367,7 +418,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             def wait_image(s):
                 """another rank's packed image: there once its owner has parsed the set (or never, if that rank died:
                 the launcher then ends this process; the deadline only bounds a stray wait)"""
-                path = os.path.join(scratch, f"set{s}.pk")
+                path = os.path.join(scratch, f"set{s}.ipc" if use_ipc else f"set{s}.pk")
                 deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
                 w0 = time.perf_counter()
                 while not os.path.exists(path):
@@ -512,6 +563,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                           reads_per_s_incl_load_and_filter=total_searched / total_s if total_s > 0 else 0.0)
             say(f"{total_searched} reads searched in {slowest:.3f} s of jobs on {world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s "
                 f"({result['reads_per_s_incl_load_and_filter'] / 1e6:.1f} M reads/s with filter {slowest_filter:.2f} s + load {slowest_load:.2f} s)")
+        # (the gathers above come after every rank's loading: no import of an exported set is still under way)
+        for s_, rs in exported.items():
+            if s_ not in sets:
+                eng.release(rs)
         for rs in sets.values():
             eng.release(rs)
         return result
@@ -530,10 +585,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     shutil.rmtree(scratch, ignore_errors=True)
             else:
                 for s in owned:
-                    try:
-                        os.remove(os.path.join(scratch, f"set{s}.pk"))
-                    except OSError:
-                        pass
+                    for ext in ("pk", "ipc"):
+                        try:
+                            os.remove(os.path.join(scratch, f"set{s}.{ext}"))
+                        except OSError:
+                            pass
         if own_ranks and sys.exc_info()[0] is None:
             ranks.close()
 
@@ -551,7 +607,11 @@ def main(argv=None):
     ap.add_argument("-m", type=int, default=-1)
     a = ap.parse_args(argv)
     try:
-        run(a.input_file, a.directory, k=a.k, t=a.t, l=a.l, n=a.n, e=a.e, m=a.m, bin_dir=a.bin_dir)
+        res = run(a.input_file, a.directory, k=a.k, t=a.t, l=a.l, n=a.n, e=a.e, m=a.m, bin_dir=a.bin_dir)
+        if res is not None and os.environ.get("COMMET_MATRIX_REPORT"):   # rank 0: times and per-rank profile, as JSON
+            import json
+            with open(os.environ["COMMET_MATRIX_REPORT"], "w") as fh:
+                json.dump({f: v for f, v in res.items() if f != "rank0_profile"}, fh)
     except BaseException:
         # a rank that fails must not leave its peers in a barrier: report and leave at once, skipping the process
         # group's shutdown handshake; torch.distributed.run then terminates the other ranks and exits non-zero

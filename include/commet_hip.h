@@ -107,6 +107,14 @@ int             commet_readset_finalize(commet_readset *rs);
  * has no counterpart: every index_and_search process re-parses its files (file_manager.h:117-171). */
 int             commet_readset_save(const commet_readset *rs, const char *path);
 commet_readset *commet_readset_load(commet_ctx *ctx, const char *path);
+/* The same hand-over WITHOUT a file, for the processes of one node: export writes a descriptor (file spans, lengths, and the
+ * HIP IPC handles of the set's device buffers — dmabuf mode, HSA_ENABLE_IPC_MODE_LEGACY=0) into blob (blob == NULL: only
+ * *blob_bytes, the size needed); import, in another process on any device of the node that reaches the owner's (xGMI), or
+ * on the same device, opens the handles, copies the planes device to device into a set of its own (2.4 GB of a 50 M-read
+ * set: a few tens of ms, against 0.5 s to write and 0.2 s to read the image through /dev/shm) and closes them.  The
+ * imported set still has to be finalized.  The OWNER'S SET MUST STAY ALIVE until every importer has returned. */
+int             commet_readset_export(const commet_readset *rs, void *blob, uint64_t cap, uint64_t *blob_bytes);
+commet_readset *commet_readset_import(commet_ctx *ctx, const void *blob, uint64_t blob_bytes);
 uint64_t        commet_readset_num_reads(const commet_readset *rs);
 uint64_t        commet_readset_num_files(const commet_readset *rs);
 /* kmers_out[n_reads]: complete k-mers of each read (valid after finalize) */

@@ -113,17 +113,19 @@ def test_matrix_driver_matches_oracle_on_synthetic_sets(tmp_path, monkeypatch):
                 assert res["matrix"][a][b] == int(tot)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world):
+@pytest.mark.parametrize("world,handover", [(2, "ipc"), (4, "ipc"), (2, "image")])
+def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world, handover):
     """N > 1: `world` processes (torch.distributed.run, gloo) take contiguous runs of the pair list, every set is
-    parsed by one rank only and reaches the others as a packed image (commet_readset_save / _load), the ranks write
+    parsed by one rank only and reaches the others device to device (commet_readset_export / _import: HIP IPC handles of
+    the owner's buffers) or, with COMMET_MATRIX_IPC=0, as a packed image (commet_readset_save / _load); the ranks write
     their .bv files side by side and rank 0 assembles the matrices.  All ranks use GPU 0 here (COMMET_FORCE_DEVICE);
     outputs must equal Commet.py's."""
     import subprocess
     gold = os.path.join(GOLD, "abcde", "commet_py", "five_sets")
     monkeypatch.chdir(abcde)
     open("sets.txt", "w").write(open(os.path.join(gold, "sets.txt")).read())
-    env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT)
+    env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT, COMMET_MATRIX_IPC="1" if handover == "ipc" else "0",
+               COMMET_MATRIX_REPORT="report.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + (os.getpid() + world) % 300), "-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -131,6 +133,49 @@ def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world):
     for f in sorted(os.listdir(gold)):
         if f.endswith((".csv", ".bv")):
             assert open(os.path.join("out2", f), "rb").read() == open(os.path.join(gold, f), "rb").read(), f
+    import json
+    rep = json.load(open("report.json"))
+    assert {r["handover"] for r in rep["per_rank"]} == {handover}                   # (the probe between the ranks passed)
+    assert sum(r["sets_parsed"] for r in rep["per_rank"]) == 5 and sum(r["sets_loaded"] for r in rep["per_rank"]) > 0
+    os.remove("report.json")
+
+
+def test_exported_set_is_imported_by_another_process(tmp_path):
+    """commet_readset_export / _import across two processes on one device: the importer's copy gives the same per-file
+    read counts, k-mer counts (at ITS k) and job results as a set it parses itself; ragged reads (the offsets travel too)"""
+    import subprocess
+    import commet_amd
+    import util
+    rng = np.random.default_rng(21)
+    reads = util.random_reads(rng, 5000, 5, 260, n_rate=0.02)
+    b, o = util.to_batch(reads)
+    np.save(tmp_path / "b.npy", b)
+    np.save(tmp_path / "o.npy", o)
+    child = f'''
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+import commet_amd
+blob = open({str(tmp_path / "set.blob")!r}, "rb").read()
+b, o = np.load({str(tmp_path / "b.npy")!r}), np.load({str(tmp_path / "o.npy")!r})
+with commet_amd.Context(k=20, t=2) as ctx:
+    got = commet_amd.ReadSet.import_(ctx, blob)
+    own = commet_amd.ReadSet.from_files(ctx, [(b[: int(o[3000])], o[:3001]), (b[int(o[3000]):], o[3000:] - o[3000])])
+    assert got.file_reads() == own.file_reads() == [3000, 2000], got.file_reads()
+    assert np.array_equal(got.kmer_counts(), own.kmer_counts())
+    q = commet_amd.ReadSet.from_files(ctx, [(b[: int(o[1500])], o[:1501])])
+    r1, r2 = ctx.index_and_search(got, [q]), ctx.index_and_search(own, [q])
+    assert np.array_equal(r1[0][0], r2[0][0]) and r1[1][0]["shared"] == r2[1][0]["shared"] > 1000
+    r3, r4 = ctx.index_and_search(q, [got]), ctx.index_and_search(q, [own])
+    assert np.array_equal(r3[0][0], r4[0][0])
+print("imported ok")
+'''
+    with commet_amd.Context(k=31, t=2) as ctx:                            # (the exporter's k plays no role)
+        rs = commet_amd.ReadSet.from_files(ctx, [(b[: int(o[3000])], o[:3001]), (b[int(o[3000]):], o[3000:] - o[3000])])
+        open(tmp_path / "set.blob", "wb").write(rs.export())
+        p = subprocess.run([sys.executable, "-c", child], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0 and b"imported ok" in p.stdout, p.stdout.decode()[-2000:]
+        with pytest.raises(commet_amd.CommetError):
+            commet_amd.ReadSet.import_(ctx, b"not a descriptor")
 
 
 def test_packed_image_round_trip(tmp_path):
