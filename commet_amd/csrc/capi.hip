@@ -2179,6 +2179,61 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         if (ensure_slice_buffers(c, wide.nw ? 8 : slice_gw, n_chunks)) rc = 1;   // (sized above already; a wide plan that fell back may need less)
         if (!rc && hipMemcpy(c->d_slice_chunks, hc.data(), n_chunks * sizeof(SliceChunk), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail("chunk descriptor upload failed");
+        // Wide rows or narrow tables?  The wide pass looks at EVERY chunk filter for every read; the narrow tables take 256
+        // chunks per pass and skip, in later passes, the reads that earlier ones have found — 2.5x the cost per chunk and
+        // read (configs[4]: 8.3 s against 2.6 s), but when most reads are found early there is little left to pay it on
+        // (10 M x 100 bp reads, t = 2: k = 20 narrow 628 ms / wide 850 ms, k = 18 664 / 1391, k = 16 649 / 1709 — random
+        // reads share that many short k-mers — but k = 22 491 / 384, k = 24 307 / 256).  In auto mode the first 64 chunk
+        // filters are therefore searched with the narrow tables against a sample of every search set (one 64-read word in 128 of a large set); with
+        // p = the share of them that a group of 256 chunks would find at that rate, the reads still unfound after g groups
+        // are taken as (1 - p)^g of the set, a narrow pass is priced at 3.7x a wide one per chunk and read (the largest
+        // ratio measured: reads that are found leave the narrow kernel early, too), and the cheaper plan runs.  The probe's
+        // reads are searched for real (tags and counters): whichever plan follows skips the found ones and finds nothing
+        // new in those chunks for the others.
+        if (!rc && wide.nw && c->slice_wide == 0) {
+            const int g0 = (int) std::min<uint64_t>(64, n_chunks);
+            if (launch_slice_build(c, index_rs, plan.dense ? nullptr : index_rs->d_sel, 0, g0, 2)) rc = 1;
+            n_index_launches += 2;
+            uint64_t sampled = 0;
+            std::vector<uint64_t> smp;
+            for (int s = 0; s < n_search && !rc; ++s) {
+                const commet_readset *rs = search_rs[s];
+                if (!rs->n_reads) continue;
+                const uint64_t nw64 = bitmap_words(rs->n_reads);
+                smp.assign(nw64, 0);
+                const uint64_t *vw = all_visited[s] ? nullptr : (const uint64_t *) vis[s].data();   // (n/8+1 bytes: the last word may be partial)
+                const uint64_t stride = rs->n_reads >= (4ull << 20) ? 128 : rs->n_reads >= (1ull << 20) ? 32 : 8;   // >= ~16 k sampled reads
+                for (uint64_t w = 0; w < nw64; w += stride) {
+                    uint64_t bits = ~0ull;
+                    if (vw) {
+                        bits = 0;
+                        const uint64_t nbytes = bitmap_bytes_host(rs->n_reads), o = w * 8;
+                        memcpy(&bits, vis[s].data() + o, (size_t) std::min<uint64_t>(8, nbytes > o ? nbytes - o : 0));
+                    }
+                    if (w * 64 >= rs->n_reads) bits = 0;                                              // (bitmaps have a spare word)
+                    else if (rs->n_reads - w * 64 < 64) bits &= (1ull << (rs->n_reads - w * 64)) - 1ull;   // reads past the end
+                    smp[w] = bits;
+                    sampled += (uint64_t) __builtin_popcountll(bits);
+                }
+                if (hipMemcpyAsync(rs->d_found, smp.data(), nw64 * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail("probe bitmap upload failed"); break; }   // (smp is reused)
+                if (launch_search_sliced(c, rs, g0, 2, rs->d_found, rs->d_tags, d_cnt + 2 * (uint64_t) s, (uint32_t) (2 * n_search))) { rc = 1; break; }
+                ++n_search_launches;
+            }
+            std::vector<unsigned long long> pc((size_t) 2 * g0 * n_search);
+            if (!rc && (hipMemcpyAsync(pc.data(), d_cnt, pc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                        hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail("probe counter copy failed");
+            if (!rc) {
+                uint64_t found = 0;
+                for (size_t i = 1; i < pc.size(); i += 2) found += pc[i];
+                const double p0 = sampled ? std::min(1.0, (double) found / (double) sampled) : 0.0;   // found in g0 chunks
+                const double pf = 1.0 - std::pow(1.0 - p0, 256.0 / (double) g0);                       // ... in a group of 256, at that rate
+                const uint64_t groups = (n_chunks + 255) / 256;
+                double left = 1.0, narrow_cost = 0.0;
+                for (uint64_t gi = 0; gi < groups; ++gi) narrow_cost += 3.7 * 256.0 * left, left *= 1.0 - pf;
+                if (narrow_cost < (double) n_chunks) wide = WidePlan();   // most reads are found early: the narrow tables, group by group
+            }
+        }
         // wide rows: the filters of a pass's chunks (all of them when the tables fit) are built 256 at a time into their
         // columns of the rows, then every search set is scanned ONCE per pass
         for (uint64_t c0 = 0; wide.nw && c0 < n_chunks && !rc; c0 += wide.chunks_per_pass) {

@@ -210,7 +210,9 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        set and searched in ONE pass; 0 = from 8 chunks on, 1 = never, 2 = always
  *   slice_words          chunk filters per pass / 32 in that regime (0 auto, 1, 2, 4, 8)
  *   slice_wide (0/1/2)   that regime with EVERY chunk filter (up to 16 384 per pass) side by side in rows of one table and a
- *                        group of lanes per read (search_wide_kernel): 0 = jobs of more than 256 chunks, 1 = never, 2 = always
+ *                        group of lanes per read (search_wide_kernel): 0 = jobs of more than 256 chunks, after a probe of the
+ *                        first 64 chunk filters on a sample of the reads (few reads found early: wide rows; most: the narrow
+ *                        tables, whose later passes skip the reads already found), 1 = never, 2 = always
  *   slice_wide_words     cap on the words per wide row (a multiple of 8, 32 chunk filters per word; 0 = by the memory free)
  *   query_list_budget_mb HBM the cached query lists of the context's read sets may hold (see commet_readset_cache_bytes)
  *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096

@@ -318,6 +318,7 @@ def test_wide_rows_instantiations_match_cpu_checker(k, t, L, n_chunks, cap_words
     with commet_amd.Context(k=k, t=t) as ctx:
         ctx.set_option("max_kmer", 1)
         ctx.set_option("slice_mode", 2)
+        ctx.set_option("slice_wide", 2)                                    # (auto would probe first and might take the narrow tables)
         ctx.set_option("slice_wide_words", cap_words)
         irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
         qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
@@ -425,3 +426,38 @@ def test_tiled_replay_three_mask_words_two_filters(k, t, L, max_kmer):
     assert np.array_equal(tags[0], found)
     assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum()))
     assert stats[0]["shared"] > 1000
+
+
+def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
+    """more than 256 chunk filters in auto mode: the first 256 are searched with the narrow tables against one read in
+    sixteen; when most of those are found there (reads that will be found early whatever the plan) the job goes on with
+    the narrow tables, group by group, else with the wide rows.  Either way the CPU checker's bits."""
+    import commet_amd
+    k, t, L, n_chunks = 16, 2, 80, 4200
+    rng = np.random.default_rng(99)
+    idx_reads = util.random_reads(rng, 2 * n_chunks, L, L, n_rate=0.002)
+    early = [idx_reads[int(i)] for i in rng.integers(0, 500, size=4000)]        # copies of reads of the first 250 chunks
+    late = util.random_reads(rng, 4000, L, L, n_rate=0.002)                      # reads that share nothing
+    ib, io = util.to_batch(idx_reads)
+    for name, q_reads, kernel in (("found early", early, "search_sliced_kernel"), ("not found", late, "search_wide_kernel")):
+        qb, qo = util.to_batch(q_reads)
+        with commet_amd.Context(k=k, t=t) as ctx:
+            ctx.set_option("max_kmer", 1)
+            irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
+            qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
+            kc = irs.kmer_counts()
+            ctx.set_option("kernel_timing", 1)
+            tags, stats, info = ctx.index_and_search(irs, [qrs])
+            times = ctx.kernel_times()
+        chunks = oracle_pool.chunks_from_counts(kc, 1)
+        assert info["n_chunks"] == len(chunks) > 4000
+        groups = (len(chunks) + 255) // 256
+        # the probe is one launch of the narrow kernel; then either every group with it, or one wide pass
+        if kernel == "search_sliced_kernel":
+            assert "search_wide_kernel" not in times and times["search_sliced_kernel"][0] == 1 + groups, (name, times)
+        else:
+            assert times["search_sliced_kernel"][0] == 1 and times["search_wide_kernel"][0] == 1, (name, times)
+        found, searched_last = _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, len(q_reads))
+        assert np.array_equal(tags[0], found), name
+        assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum())), name
+        assert (stats[0]["shared"] > 1500) == (kernel == "search_sliced_kernel"), (name, stats[0]["shared"])
