@@ -1817,17 +1817,18 @@ int launch_slice_build(commet_ctx *c, const commet_readset *rs, const uint64_t *
 }
 
 int launch_search_sliced(commet_ctx *c, const commet_readset *rs, int g, int gw, const uint64_t *d_sel, uint64_t *d_tags,
-                         unsigned long long *d_counters, uint32_t cstride)
+                         unsigned long long *d_counters, uint32_t cstride, uint32_t block_stride = 1)
 {
     if (rs->n_reads == 0) return 0;
     if ((rs->n_reads + 255) / 256 >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
-    const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
+    const uint64_t blocks = (rs->n_reads + 255) / 256;
+    const dim3 grid((unsigned) ((blocks + block_stride - 1) / block_stride)), block(256);
     KScope ks(c, "search_sliced_kernel", c->stream);
     switch (gw) {
-    case 1: COMMET_LAUNCH(search_sliced_kernel<1>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    case 2: COMMET_LAUNCH(search_sliced_kernel<2>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    case 4: COMMET_LAUNCH(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
-    default: COMMET_LAUNCH(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride); break;
+    case 1: COMMET_LAUNCH(search_sliced_kernel<1>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride, block_stride); break;
+    case 2: COMMET_LAUNCH(search_sliced_kernel<2>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride, block_stride); break;
+    case 4: COMMET_LAUNCH(search_sliced_kernel<4>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride, block_stride); break;
+    default: COMMET_LAUNCH(search_sliced_kernel<8>, grid, block, 0, c->stream, rs->view(), c->slice_tables, c->k, t_eff(c, rs), g, d_sel, d_tags, d_counters, cstride, block_stride); break;
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -2203,6 +2204,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 smp.assign(nw64, 0);
                 const uint64_t *vw = all_visited[s] ? nullptr : (const uint64_t *) vis[s].data();   // (n/8+1 bytes: the last word may be partial)
                 const uint64_t stride = rs->n_reads >= (4ull << 20) ? 128 : rs->n_reads >= (1ull << 20) ? 32 : 8;   // >= ~16 k sampled reads
+                // (a block of the kernel is 4 words: only the blocks that hold a sampled word are launched)
                 for (uint64_t w = 0; w < nw64; w += stride) {
                     uint64_t bits = ~0ull;
                     if (vw) {
@@ -2217,7 +2219,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 }
                 if (hipMemcpyAsync(rs->d_found, smp.data(), nw64 * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                     hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail("probe bitmap upload failed"); break; }   // (smp is reused)
-                if (launch_search_sliced(c, rs, g0, 2, rs->d_found, rs->d_tags, d_cnt + 2 * (uint64_t) s, (uint32_t) (2 * n_search))) { rc = 1; break; }
+                if (launch_search_sliced(c, rs, g0, 2, rs->d_found, rs->d_tags, d_cnt + 2 * (uint64_t) s, (uint32_t) (2 * n_search), (uint32_t) (stride / 4))) { rc = 1; break; }
                 ++n_search_launches;
             }
             std::vector<unsigned long long> pc((size_t) 2 * g0 * n_search);

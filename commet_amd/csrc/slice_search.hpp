@@ -156,9 +156,12 @@ template <int GW> struct SliceWord {
 template <int GW>
 __global__ __launch_bounds__(256) void search_sliced_kernel(ReadsView rv, const uint32_t *__restrict__ tables, int k, int t, int g,
                                                             const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
-                                                            unsigned long long *__restrict__ counters, uint32_t cstride)
+                                                            unsigned long long *__restrict__ counters, uint32_t cstride,
+                                                            uint32_t block_stride)
 {
-    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    // block_stride > 1: only every block_stride-th block of 256 reads is launched (the sampling probe of the auto mode,
+    // capi.hip: its selection bitmap has reads in those blocks only)
+    const uint64_t r = (uint64_t) blockIdx.x * block_stride * 256ull + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
     const bool in_range = (word << 6) < rv.n;
