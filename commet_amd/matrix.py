@@ -168,6 +168,17 @@ class HipEngine:
     def import_set(self, blob):
         return self._api.ReadSet.import_(self.ctx, blob)
 
+    def same_set(self, a, b):
+        """the packed images of two resident sets are the same bytes (the hand-over probe: what came over is what was sent)"""
+        d = tempfile.mkdtemp(prefix="commet_probe_", dir=_scratch_root())
+        try:
+            a.save(os.path.join(d, "a.pk"))
+            b.save(os.path.join(d, "b.pk"))
+            with open(os.path.join(d, "a.pk"), "rb") as fa, open(os.path.join(d, "b.pk"), "rb") as fb:
+                return fa.read() == fb.read()
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
     def file_reads(self, rs):
         return rs.file_reads()
 
@@ -297,7 +308,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     if blobs[src] is None:
                         ok = 0
                     else:
-                        eng.release(eng.import_set(blobs[src]))
+                        got = eng.import_set(blobs[src])          # every rank's probe set holds the same reads:
+                        if hasattr(eng, "same_set") and not eng.same_set(got, probe):   # a copy that arrives damaged counts as no hand-over
+                            say("device-to-device hand-over of sets: the probe set did not arrive intact: packed images instead")
+                            ok = 0
+                        eng.release(got)
             except Exception as ex:
                 say(f"device-to-device hand-over of sets not available ({ex}): packed images instead")
                 ok = 0

@@ -167,6 +167,9 @@ with commet_amd.Context(k=20, t=2) as ctx:
     assert np.array_equal(r1[0][0], r2[0][0]) and r1[1][0]["shared"] == r2[1][0]["shared"] > 1000
     r3, r4 = ctx.index_and_search(q, [got]), ctx.index_and_search(q, [own])
     assert np.array_equal(r3[0][0], r4[0][0])
+    from commet_amd import matrix
+    eng = matrix.HipEngine.__new__(matrix.HipEngine)          # the driver's probe check: the packed images are the same bytes
+    assert eng.same_set(got, own) and not eng.same_set(got, q)
 print("imported ok")
 '''
     with commet_amd.Context(k=31, t=2) as ctx:                            # (the exporter's k plays no role)
