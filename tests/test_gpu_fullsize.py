@@ -67,8 +67,26 @@ def _cpu_checker_on_sample(k, t, b0, o0, L, chunks, kc, sb):
     return util.bools_from_bits(found, ns)
 
 
+def _oracle_main_loop(d, k, t, index_fa, query_fa):
+    """ok_index_and_search — the CPU checker's restatement of the tool's own main (set files, FastaFile iteration, the chunk loop
+    of index_and_search.cpp:241-277) — with its chunk trace: (rc, results, chunks, k-mers, trace rows, .bv bits)"""
+    import ctypes as C
+    import os
+    for name, fa in (("index", index_fa), ("search", query_fa)):
+        with open(os.path.join(d, name + ".txt"), "w") as fh:
+            fh.write(("ref:" if name == "index" else "qry:") + fa + "\n")
+    os.makedirs(os.path.join(d, "o")), os.makedirs(os.path.join(d, "l"))
+    trace = np.zeros((64, 4), dtype=np.uint64)
+    ob.load().ok_trace_begin(trace.ctypes.data_as(C.c_void_p), len(trace))
+    rc, res, chunks, kmers = ob.index_and_search(os.path.join(d, "index.txt"), os.path.join(d, "search.txt"), os.path.join(d, "o"),
+                                                 os.path.join(d, "l"), k, t)
+    nch = ob.load().ok_trace_end()
+    _, nbits, bits = util.read_bv(os.path.join(d, "o", os.path.basename(query_fa) + "_in_ref.bv"))
+    return dict(rc=rc, res=res, chunks=chunks, kmers=kmers, trace=trace[:nch].copy(), n=nbits, bits=np.array(bits))
+
+
 @pytest.fixture(scope="module")
-def cpu_runs(c2):
+def cpu_runs(c2, tmp_path_factory):
     """The three full-size sample replays of this file (configs[1] at k = 32, the same sets at the reference's default
     k = 33, configs[1]'s size with skewed sets) need ~45 s of ONE host core each — the CPU checker is the reference's
     sequential algorithm — so the GPU jobs are run first and the three replays then run side by side in threads (the
@@ -117,11 +135,22 @@ def cpu_runs(c2):
     def pick(b, smp):
         return np.ascontiguousarray(b.reshape(n, L)[smp]).reshape(-1)
 
-    with ThreadPoolExecutor(3) as pool:
+    # (d) the checker's own MAIN LOOP over the whole index set of configs[1] (chunk boundaries from the restated tool, not from this
+    #     file's numpy) and a search set of set 1's first reads
+    md = tmp_path_factory.mktemp("c2main")
+    m_q = 4000
+    synth.write_fasta_fast(str(md / "s0.fa"), c2["b0"], n, L)
+    synth.write_fasta_fast(str(md / "q.fa"), c2["b1"][: m_q * L], m_q, L)
+
+    with ThreadPoolExecutor(4) as pool:
+        fd = pool.submit(_oracle_main_loop, str(md), 32, t, str(md / "s0.fa"), str(md / "q.fa"))
         fa = pool.submit(_cpu_checker_on_sample, 32, t, c2["b0"], c2["o0"], L, ch32, kc32, pick(c2["b1"], smp32))
         fb = pool.submit(_cpu_checker_on_sample, 33, t, c2["b0"], c2["o0"], L, out["k33"]["chunks"], kc33, pick(c2["b1"], smp33))
         fc = pool.submit(_cpu_checker_on_sample, 32, t, sb0, so0, L, out["skew"]["chunks"], kcs, pick(sb1, smps))
         out["c2"]["want"], out["k33"]["want"], out["skew"]["want"] = fa.result(), fb.result(), fc.result()
+        out["c2"]["main"] = fd.result()
+    import os
+    os.unlink(md / "s0.fa")
     return out
 
 
@@ -142,6 +171,24 @@ def test_c2_sample_is_bit_exact_against_cpu_checker(c2, cpu_runs):
     got = util.bools_from_bits(c2["tags"], c2["n"])[run["sample"]]
     assert np.array_equal(got, run["want"])
     assert got.sum() > 4000                                               # the sample does contain shared reads
+
+
+def test_c2_chunks_and_first_reads_match_the_checkers_main_loop(c2, cpu_runs):
+    """configs[1]'s whole index set through the CPU checker's restatement of the tool's main (FASTA parsing, FastaFile iteration,
+    the max_kmer chunk loop): its chunk trace — first / last read, reads, k-mers of every chunk — is what the device's plan and
+    this file's numpy boundaries say, and its .bv for a search set of set 1's first 4000 reads equals the job's tags for them"""
+    main, n = cpu_runs["c2"]["main"], c2["n"]
+    assert main["rc"] == 0 and main["chunks"] == c2["info"]["n_chunks"] == len(main["trace"])
+    assert main["kmers"] == c2["info"]["kmers_indexed"]
+    kc = c2["irs"].kmer_counts()
+    for (a, e), row in zip(cpu_runs["c2"]["chunks"], main["trace"]):
+        first, last, reads, kmers = (int(x) for x in row)
+        assert (first, last, reads) == (a, e - 1, e - a) and kmers == int(kc[a:e].sum())
+    assert main["res"][0]["indexed"] == c2["stats"]["indexed"] == n - 1
+    m_q = main["n"]
+    got = util.bools_from_bits(c2["tags"], n)[:m_q]
+    want = util.bools_from_bits(main["bits"], m_q)
+    assert np.array_equal(got, want) and main["res"][0]["shared"] == int(want.sum()) > 3000
 
 
 def test_c2_properties(c2):
