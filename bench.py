@@ -106,6 +106,39 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def host_memory_free(scratch_root):
+    """Bytes of host memory this process can still take: MemAvailable, the cgroup's limit minus its use, and (the matrix inputs are
+    files in it) the free space of the scratch root — the smallest of the three."""
+    free = []
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                free.append(int(line.split()[1]) * 1024)
+    except Exception:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                free.append(int(v) - int(open(cur).read()))
+        except Exception:
+            pass
+    try:
+        st = os.statvfs(scratch_root)
+        free.append(st.f_bavail * st.f_frsize)
+    except Exception:
+        pass
+    return min(free) if free else None
+
+
+def matrix_memory_needed(n_sets, n_reads, read_len, workers):
+    """host bytes of the matrix leg: the FASTA files (in /dev/shm they are memory) + the generator state of the worker processes
+    (~2.5 bytes per base each) + the driver's own parsing of two sets at a time (mapped files: no copy) and its filter .bv files"""
+    fasta = n_sets * n_reads * (read_len + 12)
+    return int(fasta + workers * n_reads * read_len * 2.5 + (2 << 30))
+
+
 def cpu_baseline(args, b0, b1):
     """Times the reference CPU path on the first `cpu_sample` reads of both sets (rank 0, N=1 only): one copy alone,
     then one independent copy per host core (P = 1 and P = all, P stated)."""
@@ -217,6 +250,17 @@ def matrix_leg(args, ranks):
     S, L = args.matrix_sets, args.read_len
     # one GPU: BASELINE configs[2] (10 x 10 M reads); several: configs[3] (10 x 50 M reads, the matrix sharded over the GPUs)
     n = args.matrix_reads or (10_000_000 if ranks.world == 1 else 50_000_000)
+    workers_all = min(S, max(1, host_cores() // 2))                # generator processes of all ranks together (see below)
+    note = None
+    if args.matrix_reads is None:                                  # the default size must fit the host: never drive the box out of memory
+        free = ranks.broadcast_object(host_memory_free(root) if ranks.rank == 0 else None)
+        while free is not None and n > 1_000_000 and matrix_memory_needed(S, n, L, workers_all) * 1.25 > free:
+            note = f"host memory ({free / 2**30:.0f} GiB free) does not hold {S} x {n} reads as FASTA in {root}"
+            n = 10_000_000 if n > 10_000_000 else n // 2
+        if note:
+            note += f": {n} reads per set instead"
+            if ranks.rank == 0:
+                print("bench.py matrix leg: " + note, file=sys.stderr)
     which = {(10, 10_000_000): "BASELINE configs[2]", (10, 50_000_000): "BASELINE configs[3]"}.get((S, n), "custom size")
     try:
         t0 = time.perf_counter()
@@ -246,7 +290,7 @@ def matrix_leg(args, ranks):
     busy = [p["jobs_s"] + p.get("set_wait_s", 0.0) for p in per_rank]
     out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix ({which}) over {ranks.world} GPU(s): "
                         f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",
-               generate_s=round(gen_s, 2),
+               generate_s=round(gen_s, 2), size_note=note,
                # how evenly the static cut of the pairs loaded the ranks: slowest / mean of the ranks' job time (1.0 = even),
                # and what the cut predicted for every rank (its share of the pairs' cost) beside what it took
                imbalance=round(max(busy) / (sum(busy) / len(busy)), 4) if busy and sum(busy) > 0 else None,
