@@ -125,6 +125,64 @@ def test_wide_keys(commet, k):
         qrs.close()
 
 
+def _key_level_search(idx_reads, queries, k, t):
+    """search_reads.h:45-83 over the CPU checker's KEYS (ok_keys_of_read: hash_key.h's add / rv_add per complete window) with the four
+    lanes kept as Python sets — for k whose 2^(k-1)-byte filter the checker cannot allocate on a test host (k = 38: 128 GiB)"""
+    lanes = [set(), set(), set(), set()]
+    for r in idx_reads:
+        keys, _ = ob.keys_of_read(r, k)
+        for j in range(4):
+            lanes[j].update(keys[:, j].tolist())
+    out = np.zeros(len(queries), dtype=bool)
+    for i, q in enumerate(queries):
+        for rev in (False, True):
+            keys, pos = ob.keys_of_read(q, k, reverse=rev)
+            seen, next_end = 0, 0
+            for (a, b, c, d), p in zip(keys.tolist(), pos.tolist()):
+                if p < next_end:                       # hash.clear() after a hit: the next complete window ends k bases later
+                    continue
+                if a in lanes[0] and b in lanes[1] and c in lanes[2] and d in lanes[3]:
+                    seen += 1
+                    if seen >= t:
+                        out[i] = True
+                        break
+                    next_end = p + k
+            if out[i]:
+                break
+    return out
+
+
+@pytest.mark.parametrize("k", [20, 33, 35, 36, 37, 38])
+def test_largest_k_against_the_key_level_checker(commet, k):
+    """k up to the largest the boundary takes (38: four planes of 2^38 bits = 128 GiB of HBM; the reference would need as much host
+    RAM).  The key-level checker is pinned to the CPU checker's filter at k = 20 and 33 in this same test."""
+    rng = np.random.default_rng(1000 + k)
+    t = 2
+    idx_reads = util.random_reads(rng, 250, 40, 170, n_rate=0.01)
+    q_reads = util.related_reads(rng, idx_reads, 700, 1, 170, share=0.6, n_rate=0.01)
+    ib, io = util.to_batch(idx_reads)
+    qb, qo = util.to_batch(q_reads)
+    want = _key_level_search(idx_reads, q_reads, k, t)
+    assert 50 < want.sum() < len(q_reads)
+    if k <= 33:
+        f = ob.Bloom(k)
+        f.index(ib, io)
+        exp, _ = f.search(t, qb, qo)
+        assert np.array_equal(util.bools_from_bits(exp, len(q_reads)), want)
+    with commet.Context(k=k, t=t) as ctx:
+        irs = commet.ReadSet.from_files(ctx, [(ib, io)])
+        qrs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+        assert np.array_equal(irs.kmer_counts(), ob.kmer_counts(ib, io, k))
+        ctx.filter_reset()
+        fed = ctx.index_reads(irs)
+        assert fed == int(ob.kmer_counts(ib, io, k).sum())
+        found, scanned, nfound = ctx.search_reads(qrs)
+        assert np.array_equal(util.bools_from_bits(found, len(q_reads)), want) and nfound == int(want.sum())
+        tags, stats, info = ctx.index_and_search(irs, [qrs])       # the job path (one chunk)
+        assert np.array_equal(util.bools_from_bits(tags[0], len(q_reads)), want) and stats[0]["shared"] == int(want.sum())
+        assert info["n_chunks"] == 1 and info["kmers_indexed"] == fed
+
+
 def test_uniform_and_ragged_layouts_agree(commet):
     """fixed-length sets take the offset-free addressing; results must not depend on it"""
     rng = np.random.default_rng(5)
