@@ -233,6 +233,18 @@ def test_matrix_driver_single_rank_loader_failure_reaches_the_caller(tmp_path, m
     assert time.time() - t0 < 60
 
 
+def test_bench_matrix_leg_sizes_itself_to_the_host(tmp_path):
+    """the default matrix leg (10 x 50 M reads as FASTA in the scratch root when there are several GPUs) must not drive the host out of
+    memory: what it needs is priced and compared with what the host has free"""
+    sys.path.insert(0, ROOT)
+    import bench
+    free = bench.host_memory_free(str(tmp_path))
+    assert free is not None and 0 < free <= os.statvfs(str(tmp_path)).f_bavail * os.statvfs(str(tmp_path)).f_frsize
+    big, small = bench.matrix_memory_needed(10, 50_000_000, 100, 8), bench.matrix_memory_needed(10, 10_000_000, 100, 8)
+    assert big > 10 * 50_000_000 * 100 and small < big / 4            # at least the bases themselves; scales with the reads
+    assert small > 10 * 10_000_000 * 100
+
+
 def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start the two ranks itself — as a
     child process, the parent never touching the GPU — and print ONE line with n_gpus = 2 (the launch path only: the
