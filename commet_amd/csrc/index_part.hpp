@@ -40,8 +40,11 @@ namespace commet {
 constexpr int      TILE_BITS = 19;
 constexpr uint32_t TILE_MASK = (1u << TILE_BITS) - 1;
 constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 KiB
-constexpr int      S1_NT = 512;                             // scatter-1 workgroup size
-constexpr uint32_t S1_KEYS = 16384;                         // keys staged per scatter-1 round (64 KiB)
+#ifndef COMMET_S1_NT
+#define COMMET_S1_NT 512
+#endif
+constexpr int      S1_NT = COMMET_S1_NT;                    // scatter-1 workgroup size
+constexpr uint32_t S1_KEYS = 32u * COMMET_S1_NT;            // keys staged per scatter-1 round (64 KiB)
 constexpr uint32_t S1_ITEMS = S1_NT;                        // octet items per round: one per thread, keys cached
 constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
 constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
@@ -80,7 +83,13 @@ inline PartGeom make_geom(int k)
     PartGeom g;
     g.k = k;
     g.nb_bits = k - 17;
+    // two levels: 2^b1 coarse buckets out of scatter1, 2^b2 final buckets per coarse one out of scatter2.  scatter1 is bound by its
+    // write pattern — one run per coarse bucket, workgroup and round, 2^17 streams open at a time over ~6 GB: 2^8 buckets x 256-byte
+    // runs 1.95 ms per configs[1] chunk for the writes alone, 2^7 x 512 bytes 1.59 ms (tools/exp/s1_pattern_bench.hip) — so 2^7
+    // coarse buckets wherever the packed scatter2 still takes the rest (b2 <= 8): k = 32 is 7 + 8 (was 8 + 7: scatter1 -0.55 … -0.9 ms
+    // per step, scatter2 +0.15 … +0.5)
     g.b1 = g.nb_bits <= 8 ? g.nb_bits : (g.nb_bits + 1) / 2;
+    if (g.b1 > 7 && g.nb_bits - 7 <= 8) g.b1 = 7;
     if (g.b1 > 8) g.b1 = 8;
     g.b2 = g.nb_bits - g.b1;
     g.nb = 1u << g.nb_bits;
