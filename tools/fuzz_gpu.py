@@ -31,9 +31,9 @@ def main():
         d = tempfile.mkdtemp(prefix="fuzz")
         try:
             mode = seed % 3
-            k = None if mode != 2 else [20, 21, 24, 25, 28][seed % 5]
+            k = None if mode != 2 else [20, 21, 24, 25, 28, 32, 31][seed % 7]
             if seed % 11 >= 7:                  # the round-2 paths need k >= 12 (bit-sliced) / k >= 25 (tiled search; 33, 34: 64-bit keys)
-                k = [12, 16, 21, 24, 26, 30, 33, 34][seed % 8]
+                k = [12, 16, 21, 24, 26, 30, 33, 34, 32][seed % 9]
             fmts = ("fa", "fq", "fa.gz", "fq.gz") if seed % 4 == 0 else ("fa",)
             scn = Scenario(os.path.join(d, "s"), seed, k=k, n_scale=1.0 + (seed % 7), formats=fmts,
                            crlf=False if len(fmts) > 1 else None)
