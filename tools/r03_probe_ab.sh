@@ -1,4 +1,6 @@
-# tq_probe_kernel: threads per workgroup x workgroups per XCD (configs[1]); prints the probe's and the step's ms
+# tq_probe_kernel: threads per workgroup x workgroups per XCD (configs[1]); prints the probe's and the step's ms.
+# COMMET_TQ_PNT existed only in the experiment's build (kernel with blockDim.x strides and __launch_bounds__(1024), launch with
+# dim3(c->tq_pnt)); the shipped kernel is fixed at 256 threads, COMMET_TQ_WPX still works.
 R=$GRAFT_REPO_ROOT
 cd /tmp
 for wpx in 64 32 16; do for pnt in 256 512 1024; do
