@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 
 #define OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -76,7 +77,8 @@ int main(int argc, char **argv)
     const int n_allocs = argc > 1 ? atoi(argv[1]) : 6;
     const uint64_t ps = (uint64_t) ROUNDS * RUN_KEYS + 8;        // words per (bucket, piece): like exact counts, not a power of two
     const uint64_t bs = ps * PIECES;
-    const size_t bytes = (size_t) NB * PIECES * 6 * 4096 + (64u << 20);   // room for the 4 KiB-padded variant, too
+    size_t bytes = (size_t) NB * PIECES * 6 * 4096 + (64u << 20);   // room for the 4 KiB-padded variant, too
+    if (getenv("S1_BYTES_MIB")) bytes = std::max<size_t>(bytes, (size_t) atoll(getenv("S1_BYTES_MIB")) << 20);
     hipStream_t s;
     OK(hipStreamCreate(&s));
     printf("buffer %.2f GB, piece stride %llu B, bucket stride %.2f MB\n", bytes / 1e9, (unsigned long long) ps * 4, bs * 4 / 1e6);
