@@ -1,13 +1,13 @@
 """coarse buckets of the bucketed index construction: 2^8 (default at k = 32) against 2^7 (runs of 128 keys = 512 bytes out of scatter1,
 256 final buckets per coarse one in scatter2) — same context, same workspaces, so the allocation plays no part
-  python tools/r03_b1.py [k]"""
+  python tools/r03_b1.py [k] [reads]"""
 import os, sys
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/commet_amd") else os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np
 import commet_amd
 from commet_amd import synth
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-n, L = 10_000_000, 100
+n, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000), 100
 b0, o0 = synth.synth_set(0, n, L)
 b1, o1 = synth.synth_set(1, n, L)
 with commet_amd.Context(k=k, t=2) as ctx:
@@ -15,7 +15,7 @@ with commet_amd.Context(k=k, t=2) as ctx:
     qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
     ref = None
     for rep in range(2):
-        for b1bits in (0, 7, 6):
+        for b1bits in (8, 7):
             ctx.set_option("part_b1", b1bits)
             tags, stats, info = ctx.index_and_search(irs, [qrs])
             if ref is None:
