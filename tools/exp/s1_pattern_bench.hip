@@ -9,12 +9,14 @@
 #include <vector>
 #include <algorithm>
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 constexpr uint32_t PIECES = 1024;
 static uint32_t NB = 256, ROUNDS = 86, RUN_KEYS = 64;
 
 // word offset of (bucket c, piece p, round r): c * bucket_stride + p * piece_stride + r * RUN_KEYS + skew
+template <bool NT>
 __global__ __launch_bounds__(512, 4) void pattern_kernel(uint32_t *out, uint64_t bucket_stride, uint64_t piece_stride, uint32_t skew_mask, uint32_t rounds,
                                                           uint32_t NB, uint32_t RUN_KEYS)
 {
@@ -27,7 +29,10 @@ __global__ __launch_bounds__(512, 4) void pattern_kernel(uint32_t *out, uint64_t
             uint32_t *p = out + (uint64_t) c * bucket_stride + (uint64_t) piece * piece_stride + (uint64_t) r * RUN_KEYS + skew;
             const uint32_t l = lane % lpr;
             // 64 keys = 16 lanes x 4 words; unaligned -> four 4-byte stores per lane when skewed, one 16-byte store when not
-            if (skew_mask == 0) *(uint4 *) (p + 4 * l) = make_uint4(r, c, piece, l);
+            if (skew_mask == 0) {
+                if (NT) { v4u v = {r, c, piece, l}; __builtin_nontemporal_store(v, (v4u *) (p + 4 * l)); }
+                else *(uint4 *) (p + 4 * l) = make_uint4(r, c, piece, l);
+            }
             else { p[4 * l] = r; p[4 * l + 1] = c; p[4 * l + 2] = piece; p[4 * l + 3] = l; }
         }
         __syncthreads();
@@ -44,7 +49,8 @@ __global__ __launch_bounds__(256) void sum_kernel(const uint4 *in, uint64_t n, u
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256) { const uint4 v = in[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
     if (acc == 0x12345678u) *sink = acc;
 }
-static uint64_t g_words_left = 0;   // words of the buffer from the pointer handed to run()
+static uint64_t g_words_left = 0;
+static bool g_nt = false;   // words of the buffer from the pointer handed to run()
 
 static float run(uint32_t *buf, uint64_t bs, uint64_t ps, uint32_t skew_mask, hipStream_t s)
 {
@@ -60,7 +66,8 @@ static float run(uint32_t *buf, uint64_t bs, uint64_t ps, uint32_t skew_mask, hi
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         OK(hipEventRecord(e0, s));
-        hipLaunchKernelGGL(pattern_kernel, dim3(PIECES), dim3(512), 0, s, buf, bs, ps, skew_mask, ROUNDS, NB, RUN_KEYS);
+        if (g_nt) hipLaunchKernelGGL(pattern_kernel<true>, dim3(PIECES), dim3(512), 0, s, buf, bs, ps, skew_mask, ROUNDS, NB, RUN_KEYS);
+        else hipLaunchKernelGGL(pattern_kernel<false>, dim3(PIECES), dim3(512), 0, s, buf, bs, ps, skew_mask, ROUNDS, NB, RUN_KEYS);
         OK(hipEventRecord(e1, s));
         OK(hipStreamSynchronize(s));
         float ms;
@@ -180,6 +187,13 @@ int main(int argc, char **argv)
         for (int a : {0, 1})
             printf("%u buckets x %u-key runs, alloc %d: aligned %.3f ms, unaligned %.3f ms\n", NB, RUN_KEYS, a, run(bufs[a], bs2, ps2, 0, s), run(bufs[a], bs2, ps2, 15u, s));
     }
+    g_nt = true;
+    for (int v = 0; v < 2; ++v) {
+        NB = 256u >> v, RUN_KEYS = 64u << v;
+        const uint64_t ps2 = (uint64_t) ROUNDS * RUN_KEYS + 8, bs2 = ps2 * PIECES;
+        printf("non-temporal stores, %u buckets x %u-key runs, alloc 0: aligned %.3f ms\n", NB, RUN_KEYS, run(bufs[0], bs2, ps2, 0, s));
+    }
+    g_nt = false;
     NB = 256, RUN_KEYS = 64;
     printf("piece stride 4 KiB-padded: %.3f ms\n", run(b, ((ps * 4 + 4095) / 4096 * 1024) * PIECES, (ps * 4 + 4095) / 4096 * 1024, 15u, s));
     printf("bucket stride 2^k (32 MiB): %.3f ms\n", run(b, (32u << 20) / 4, ps, 15u, s));
