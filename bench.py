@@ -240,6 +240,15 @@ def measured_traffic(workload):
     return best
 
 
+_T0 = time.perf_counter()
+
+
+def progress(ranks, msg):
+    """a line on stderr (rank 0): a long leg must not look hung to whoever watches the run; stdout stays the one JSON line"""
+    if ranks is None or ranks.rank == 0:
+        print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def matrix_leg(args, ranks):
     """BASELINE configs[2] through the resident N x N driver, split over the ranks; sets written as FASTA to scratch
     (each rank generates its share), filter + load + jobs all timed by the driver."""
@@ -262,6 +271,7 @@ def matrix_leg(args, ranks):
             if ranks.rank == 0:
                 print("bench.py matrix leg: " + note, file=sys.stderr)
     which = {(10, 10_000_000): "BASELINE configs[2]", (10, 50_000_000): "BASELINE configs[3]"}.get((S, n), "custom size")
+    progress(ranks, f"matrix leg: {S} sets x {n} reads ({which}) over {ranks.world} rank(s): writing the FASTA files under {work}")
     try:
         t0 = time.perf_counter()
         mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
@@ -276,11 +286,15 @@ def matrix_leg(args, ranks):
                     fh.write(f"S{s}: {work}/set{s}.fa\n")
         ranks.barrier()
         gen_s = time.perf_counter() - t0
-        res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False)
+        progress(ranks, f"matrix leg: files written in {gen_s:.1f} s; filter + load + jobs")
+        res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False,
+                         progress=lambda msg: print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] matrix leg, rank {ranks.rank}: {msg}",
+                                                    file=sys.stderr, flush=True))
     finally:
         ranks.barrier()
         if ranks.rank == 0:
             shutil.rmtree(work, ignore_errors=True)
+    progress(ranks, "matrix leg: done")
     if res is None:
         return None
     keep = ("filter_s", "load_s", "jobs_s", "set_wait_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world",
@@ -304,6 +318,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if os.environ.get("BENCH_DUMP_STACKS_S"):          # debugging aid: every thread's Python stack on stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_STACKS_S"]), repeat=False, file=sys.stderr)
     from commet_amd import sharding
     ranks = sharding.Ranks(backend="gloo")   # host-side barrier / MAX only; N=1 needs no torch at all
     world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
@@ -361,7 +378,9 @@ def main():
             acc[f] += info[f]
         last["stats"], last["info"] = stats, info
 
+    progress(ranks, f"sets resident ({n} reads each), {args.warmup} warm-up step(s) done; timing {args.steps} step(s)")
     elapsed = sharding.timed_region(ranks, ctx.synchronize, step, args.steps)
+    progress(ranks, f"timed region: {elapsed * 1000.0 / args.steps:.3f} ms per step")
     stats, info = last["stats"], last["info"]
 
     # the first job on a SET also builds what is cached with the set (the tiled search's query list): not part of the

@@ -206,7 +206,9 @@ def _scratch_root():
 
 
 def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ranks=None, verbose=True,
-        engine_factory=None):
+        engine_factory=None, progress=None):
+    """progress: optional callable(str), called on every rank at the stages of the run (a caller that keeps stdout for itself —
+    bench.py — shows a long run is alive with it)"""
     t_start = time.perf_counter()
     own_ranks = ranks is None
     if ranks is None:
@@ -219,6 +221,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     names, files, bvs = parse_set_file(input_file)
     N = len(names)
     say = print if (verbose and rank == 0) else (lambda *a, **kw: None)
+    note = progress if progress is not None else (lambda msg: None)
 
     if l < k * t and l != 0:                                      # Commet.py:509-513 (l stays 0 by default)
         l = k * t
@@ -293,7 +296,24 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # others copy them over xGMI: no file, tens of ms for a 50 M-read set) when every rank can import a probe set of its
     # neighbour and of rank 0; else as a packed image in the scratch directory (0.5 s to write, 0.2 s to read).
     use_ipc = False
-    if world > 1 and os.environ.get("COMMET_MATRIX_IPC", "1") != "0" and hasattr(eng, "export_set"):
+
+    def import_one_at_a_time(blob):
+        """eng.import_set under a lock file of the node: two processes that attach to each other's buffers at the same moment
+        (rank 0 importing a set of rank 1 while rank 1 imports one of rank 0) were seen to block each other for good inside the
+        HIP IPC attach — both stuck in commet_readset_import, 2 x 50 M-read sets, two ranks; one import at a time on the node
+        costs nothing measurable (an import is tens of ms)"""
+        import fcntl
+        with open(os.path.join(scratch, "import.lock"), "a+") as lf:
+            fcntl.flock(lf, fcntl.LOCK_EX)
+            try:
+                return eng.import_set(blob)
+            finally:
+                fcntl.flock(lf, fcntl.LOCK_UN)
+
+    # Opt-in (COMMET_MATRIX_IPC=1) since the end of round 3: with 2 x 5 sets of 50 M reads on two ranks of one device an import
+    # (commet_readset_import of 1.9 GB) did not return within minutes although imports of the same size between two otherwise
+    # idle processes take 12-22 ms (tools/image_bench.py) and the small multi-rank tests pass; the images are slower and safe.
+    if world > 1 and os.environ.get("COMMET_MATRIX_IPC", "0") == "1" and hasattr(eng, "export_set"):
         probe = blob = None
         try:
             probe = eng.parse_probe()
@@ -308,7 +328,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     if blobs[src] is None:
                         ok = 0
                     else:
-                        got = eng.import_set(blobs[src])          # every rank's probe set holds the same reads:
+                        got = import_one_at_a_time(blobs[src])    # every rank's probe set holds the same reads:
                         if hasattr(eng, "same_set") and not eng.same_set(got, probe):   # a copy that arrives damaged counts as no hand-over
                             say("device-to-device hand-over of sets: the probe set did not arrive intact: packed images instead")
                             ok = 0
@@ -319,6 +339,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         use_ipc = ranks.sum_int(ok) == world                      # (also: every import of the probes is done)
         if probe is not None:
             eng.release(probe)
+    note(f"{N} sets, {len(mine)} of {len(pairs)} pairs on this rank; sets are handed over " + ("device to device" if use_ipc else "as packed images" if world > 1 else "nowhere (one rank)"))
     exported = {}                                                 # sets this rank keeps alive for the others' imports
     loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
@@ -374,7 +395,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             w0 = time.perf_counter()
             if use_ipc:
                 with open(os.path.join(scratch, f"set{s}.ipc"), "rb") as fh:
-                    sets[s] = eng.import_set(fh.read())
+                    sets[s] = import_one_at_a_time(fh.read())
             else:
                 sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
             prof["load_s"] += time.perf_counter() - w0
@@ -471,6 +492,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                                     return
                         prepare(s)
                         ready[s].set()
+                        note(f"set {s} resident")
                 except BaseException as ex:          # handed to the job thread, which is waiting for a set
                     load_err.append(ex)
                     for ev in ready:
@@ -536,6 +558,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
                 shared[(i, ref)] = st3[0]["shared"]
                 reads_searched += considered[ref] + considered[i]
+            note(f"jobs of set {ref} done ({prof['jobs']} so far)")
         eng.synchronize()
         jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
         prof["jobs_s"] = jobs_s
