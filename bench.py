@@ -133,10 +133,11 @@ def host_memory_free(scratch_root):
 
 
 def matrix_memory_needed(n_sets, n_reads, read_len, workers):
-    """host bytes of the matrix leg: the FASTA files (in /dev/shm they are memory) + the generator state of the worker processes
+    """host bytes of the matrix leg: the FASTA files (in /dev/shm they are memory) + the sets' packed images + the generator state of the worker processes
     (~2.5 bytes per base each) + the driver's own parsing of two sets at a time (mapped files: no copy) and its filter .bv files"""
     fasta = n_sets * n_reads * (read_len + 12)
-    return int(fasta + workers * n_reads * read_len * 2.5 + (2 << 30))
+    images = n_sets * n_reads * (read_len * 0.4 + 8)      # several ranks: every set's packed image in the scratch root, too (counted always)
+    return int(fasta + images + workers * n_reads * read_len * 2.5 + (2 << 30))
 
 
 def cpu_baseline(args, b0, b1):
