@@ -13,6 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import json, os, sys, time
 sys.path.insert(0, {root!r})
+if "preload" in sys.argv[4]:    # the fix: the library (and with it the system's ROCm runtime) before torch
+    from commet_amd import lib as _lib
+    _lib.load()
+if "torch" in sys.argv[4]:      # the driver's ranks used to import torch (gloo) before the library was loaded
+    import torch, torch.distributed
 import commet_amd
 from commet_amd import synth
 me, n, K, mode, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
@@ -34,12 +39,28 @@ with commet_amd.Context(k=32, t=2) as ctx:
             time.sleep(0.01)
         probe.close()
         print(json.dumps(dict(proc=me, probe="exported, imported by the other, freed")), flush=True)
+    if "fork" in mode:      # child processes started (fork + exec) beside the parsing, as the driver starts filter_reads
+        import subprocess, threading
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(3)
+        forks = [pool.submit(subprocess.run, ["/bin/sh", "-c", "cat " + os.path.join(d, f"p{{me}}.fa") + " > /dev/null 2>&1; sleep 0.3"]) for _ in range(6)]
     if "fasta" in mode:     # parsed from a FASTA file by the host ingest threads, as the driver's sets are
         fa = os.path.join(d, f"p{{me}}.fa")
         synth.write_fasta_fast(fa, b, n, 100)
-        sets = [commet_amd.ReadSet.from_fasta(ctx, [fa]) for _ in range(K)]
+        if "thread" in mode:  # ... on the loader thread
+            import threading
+            sets = []
+            th = threading.Thread(target=lambda: sets.extend(commet_amd.ReadSet.from_fasta(ctx, [fa]) for _ in range(K)))
+            th.start()
+            th.join()
+        else:
+            sets = [commet_amd.ReadSet.from_fasta(ctx, [fa]) for _ in range(K)]
     else:
         sets = [commet_amd.ReadSet.from_files(ctx, [(b, o)]) for _ in range(K)]
+    if "fork" in mode:
+        for f in forks:
+            f.result()
+        print(json.dumps(dict(proc=me, children="6 started beside the parsing, all done")), flush=True)
     for i, rs in enumerate(sets):
         open(os.path.join(d, f"p{{me}}_s{{i}}.tmp"), "wb").write(rs.export())
         os.rename(os.path.join(d, f"p{{me}}_s{{i}}.tmp"), os.path.join(d, f"p{{me}}_s{{i}}.blob"))
@@ -47,12 +68,20 @@ with commet_amd.Context(k=32, t=2) as ctx:
     other = 1 - me
     while not os.path.exists(os.path.join(d, f"p{{other}}_s{{K - 1}}.blob")):
         time.sleep(0.01)
-    if "both" in mode or me == 0:
+    def imports():
         for i in range(min(K, 2)):
             t0 = time.perf_counter()
             r = commet_amd.ReadSet.import_(ctx, open(os.path.join(d, f"p{{other}}_s{{i}}.blob"), "rb").read())
             print(json.dumps(dict(proc=me, imported=i, seconds=round(time.perf_counter() - t0, 4), reads=r.num_reads)), flush=True)
             r.close()
+    if "both" in mode or me == 0:
+        if "thread" in mode:     # from a second host thread, as the driver's loader does, the main thread waiting
+            import threading
+            th = threading.Thread(target=imports)
+            th.start()
+            th.join()
+        else:
+            imports()
     open(os.path.join(d, f"p{{me}}.done"), "w").write("x")
     while not os.path.exists(os.path.join(d, f"p{{other}}.done")):      # the exported sets stay alive until the other is done
         time.sleep(0.01)
