@@ -242,6 +242,7 @@ def measured_traffic(workload):
 
 
 _T0 = time.perf_counter()
+_WORK_DIRS = []        # scratch directories of the matrix leg (removed by whoever gives the leg up)
 
 
 def progress(ranks, msg):
@@ -257,6 +258,7 @@ def matrix_leg(args, ranks):
     root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
     # rank 0 makes the work directory (mkdtemp: a fresh name, mode 0700 — /dev/shm is shared with other users)
     work = ranks.broadcast_object(tempfile.mkdtemp(prefix="commet_bench_", dir=root) if ranks.rank == 0 else None)
+    _WORK_DIRS.append(work)
     S, L = args.matrix_sets, args.read_len
     # one GPU: BASELINE configs[2] (10 x 10 M reads); several: configs[3] (10 x 50 M reads, the matrix sharded over the GPUs)
     n = args.matrix_reads or (10_000_000 if ranks.world == 1 else 50_000_000)
@@ -417,135 +419,165 @@ def main():
     qrs.close()
     ctx.close()
 
+    import threading
+    emitted = threading.Event()
+
+    def emit(matrix_detail):
+        """rank 0: the one JSON line (once)"""
+        if rank != 0 or emitted.is_set():
+            return
+        emitted.set()
+        if True:
+            steps = args.steps
+            ms_per_step = elapsed * 1000.0 / steps
+            value = world * n * steps / elapsed
+            which = {(10_000_000, 100, 32, 2): "BASELINE configs[1]", (20_000_000, 150, 21, 5): "BASELINE configs[4]"}.get((n, L, k, t), "custom size")
+            workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
+                        f"per GPU ({which}), inputs resident in HBM")
+            if args.skew > 0:
+                workload += f"; {100 * args.skew:g} % of every set's reads low-complexity / repeated (poly-A, tandem repeats, shared 1000-read library)"
+            kmers = info["kmers_indexed"]
+            idx_ms = acc["index_kernel_ms"] / steps
+            srch_ms = acc["search_ms"] / steps
+            roofline = None
+            if ktimes:
+                tr = explicit_traffic(args.traffic) if args.traffic else measured_traffic(workload)
+                table, tr_path, stale = tr if tr else ({}, None, None)
+                step_dev_ms = sum(e["ms_per_step"] for e in ktimes.values())
+                dom = max(ktimes, key=lambda nme: ktimes[nme]["ms_per_step"])
+                e = ktimes[dom]
+
+                def hbm_bytes(nme):
+                    x = table.get(nme)
+                    return x.get("hbm_bytes_per_launch") if x else None
+
+                tb = hbm_bytes(dom)
+                achieved = tb / (e["avg_launch_ms"] * 1e-3) / 1e9 if tb else None
+                step_bytes, covered = 0.0, True
+                for nme, ee in ktimes.items():
+                    x = hbm_bytes(nme)
+                    if x is None:
+                        covered = covered and ee["ms_per_step"] < 0.01 * step_dev_ms     # tiny kernels may be missing from the profile
+                    else:
+                        step_bytes += x * ee["launches_per_step"]
+                fetch = (table.get(dom) or {}).get("fetch_bytes_per_launch")
+                roofline = {
+                    "bound": "hbm", "kernel": dom, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    # as executed: HBM bytes of one launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/) over its live duration
+                    "achieved": round(achieved, 1) if achieved else None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                    "traffic": tb, "traffic_source": tr_path, "traffic_stale": stale,
+                    "avg_launch_ms": round(e["avg_launch_ms"], 4), "launches_per_step": e["launches_per_step"],
+                    "time_share": round(e["ms_per_step"] / step_dev_ms, 4),
+                    "request_rate": None, "whole_step": None,
+                    "kernels": {nme: {"ms_per_step": round(ee["ms_per_step"], 4), "launches_per_step": ee["launches_per_step"],
+                                      "hbm_bytes_per_launch": hbm_bytes(nme),
+                                      "frac": round(hbm_bytes(nme) / (ee["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm_bytes(nme) and ee["avg_launch_ms"] > 0 else None}
+                                for nme, ee in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+                    "note": "durations: hipEvents around every launch in untimed extra steps (one index lane, so they add up); "
+                            "bytes: rocprofv3 PMC passes of this workload (gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py)",
+                }
+                if dom == "search_wide_kernel":
+                    # ALGORITHMIC bytes of the row pass (SURVEY 8d's "bytes per unit x units", for this kernel's own algorithm):
+                    # per read and window that can hold hit J = min(t, 3) of a strand's scan, six rows (planes A, B, C, both
+                    # strands) of one bit per chunk filter; rows are filled in groups of 256 chunks
+                    J = min(t, 3)
+                    windows = max(0, (L - 1 - (t - J) * k) - (k - 1) + 1)
+                    groups = -(-info["n_chunks"] // 256)
+                    passes = -(-groups * 8 // 512)
+                    row_bytes = -(-groups // passes) * 8 * 4
+                    alg = n * windows * 6 * row_bytes * passes
+                    # this kernel has an algorithmic byte count of its own, so the line's `achieved` / `frac` are that (the
+                    # contract's definition); what the counters saw (rows start on 128-byte lines: 1312 of every 1408 bytes are
+                    # asked for; the replay's single-word probes; FETCH_SIZE doubled as for every 16-byte-per-lane stream) is kept
+                    roofline["as_executed"] = {"achieved": roofline["achieved"], "frac": roofline["frac"], "traffic": tb}
+                    roofline["achieved"] = round(alg / (e["ms_per_step"] * 1e-3) / 1e9, 1)
+                    roofline["frac"] = round(alg / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roofline["algorithmic_bytes_per_launch"] = alg // max(1, int(e["launches_per_step"]))
+                    roofline["algorithmic_model"] = (f"{n} reads x {windows} windows x 6 rows x {row_bytes} B (one bit per chunk filter, "
+                                                     f"{info['n_chunks']} chunks in groups of 256) x {passes} pass(es)")
+                if fetch and gather_ceiling and dom.startswith(("search", "tq_")) and dom != "search_wide_kernel":   # (gather kernels: one 64-byte sector per request)
+                    rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
+                    roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),
+                                                "frac": round(rps / gather_ceiling, 4),
+                                                "what": "64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against commet_membench's "
+                                                        "random 4-byte gathers over a filter-sized table, measured in this run"}
+                # what a step cannot avoid moving: both packed sets read once (12 bytes per 32 bases + a triple per read), every
+                # chunk's filter written once and read once (2^(k-1) bytes each way), the tag bits
+                triple_bytes = 12 * (L // 32 + 1)
+                compulsory = (info["reads_indexed"] + n) * triple_bytes + info["n_chunks"] * 2 * (1 << (k - 1)) + n // 8
+                roofline["compulsory_bytes"] = compulsory
+                if step_bytes and covered:
+                    roofline["whole_step"] = {"traffic": round(step_bytes), "device_ms": round(step_dev_ms, 3),
+                                              "GBps": round(step_bytes / (step_dev_ms * 1e-3) / 1e9, 1),
+                                              "frac": round(step_bytes / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    roofline["traffic_over_compulsory"] = round(step_bytes / compulsory, 2)
+            # the contract's figure in REFERENCE probes (SURVEY 8d), kept as detail: one request of ours answers several of them
+            idx_bytes_step = info["reads_indexed"] * (L / 4.0) + 4.0 * kmers * 2 * SECTOR
+            srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR if probes is not None else None
+            out = {
+                "metric": "reads/sec searched (index_and_search, k=%d)" % k,
+                "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u32" if k <= 32 else "u64", "data": "synthetic",
+                "config": {"workload": workload,
+                           "reads_per_set": n, "read_len": L, "k": k, "t": t, "jobs": world,
+                           "parallelism": f"{world} independent (i,j) jobs, no collective"},
+                "roofline": roofline,
+                "detail": {"chunks": info["n_chunks"], "kmers_indexed": kmers, "reads_scanned": info["reads_scanned"],
+                           "shared": stats[0]["shared"], "searched_last_pass": stats[0]["searched"],
+                           "index_kernel_ms": round(idx_ms, 3), "search_kernel_ms": round(srch_ms, 3),
+                           "filter_zero_ms": round(acc["zero_ms"] / steps, 3),
+                           "p_ref_probes": probes,
+                           "reference_model_bytes_per_step": {"index": round(idx_bytes_step), "search": round(srch_bytes_step) if srch_bytes_step else None,
+                                                              "note": "SURVEY 8d's sector model of the REFERENCE's accesses; not what this implementation moves"},
+                           # a job on a search set that was never scanned (warm context): builds the set's query list as well
+                           "first_job_ms": round(first_job_s * 1e3, 3), "first_job_reads_per_s": round(n / first_job_s, 1),
+                           "query_list_bytes": query_list_bytes,
+                           "cold_context_first_job_ms": round(cold_context_first_job_s * 1e3, 3) if cold_context_first_job_s else None,
+                           "upload_and_pack_s": round(upload_s, 3), "upload_second_set_s": round(upload_s - upload_first_s, 3),
+                           "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
+                           "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
+                           "matrix": matrix_detail},
+            }
+            if matrix_detail and "error" not in matrix_detail:
+                # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
+                out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
+                                                               "jobs_s", "imbalance", "predicted_vs_actual_share")}
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(args, b0, b1)
+            print(json.dumps(out), flush=True)
+
     matrix_detail = None
     if not args.no_matrix and args.matrix_sets >= 2:
+        # The extra leg must never cost the headline: if it is not done after BENCH_MATRIX_LIMIT_S (default 900 s; it takes ~20 s
+        # on one GPU, ~60 s for configs[3] on two ranks) every rank gives it up — rank 0 prints the line without it — and leaves.
+        limit = float(os.environ.get("BENCH_MATRIX_LIMIT_S", "900"))
+
+        def bail():
+            progress(ranks, f"matrix leg: not done after {limit:.0f} s; the line goes out without it")
+            try:
+                emit({"error": f"matrix leg not done after {limit:.0f} s (abandoned)"})
+            finally:
+                sys.stdout.flush()
+                if rank == 0:
+                    for w in _WORK_DIRS:
+                        shutil.rmtree(w, ignore_errors=True)
+                os._exit(0)
+
+        watch = threading.Timer(limit, bail)
+        watch.daemon = True
+        watch.start()
         try:
             matrix_detail = matrix_leg(args, ranks)
         except Exception as ex:   # the headline measured above must not be lost with this extra leg
             import traceback
             traceback.print_exc()
             matrix_detail = {"error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            watch.cancel()
 
-    if rank == 0:
-        steps = args.steps
-        ms_per_step = elapsed * 1000.0 / steps
-        value = world * n * steps / elapsed
-        which = {(10_000_000, 100, 32, 2): "BASELINE configs[1]", (20_000_000, 150, 21, 5): "BASELINE configs[4]"}.get((n, L, k, t), "custom size")
-        workload = (f"2 synthetic sets x {n} x {L} bp reads, k={k} t={t}, index set 0 + search set 1 "
-                    f"per GPU ({which}), inputs resident in HBM")
-        if args.skew > 0:
-            workload += f"; {100 * args.skew:g} % of every set's reads low-complexity / repeated (poly-A, tandem repeats, shared 1000-read library)"
-        kmers = info["kmers_indexed"]
-        idx_ms = acc["index_kernel_ms"] / steps
-        srch_ms = acc["search_ms"] / steps
-        roofline = None
-        if ktimes:
-            tr = explicit_traffic(args.traffic) if args.traffic else measured_traffic(workload)
-            table, tr_path, stale = tr if tr else ({}, None, None)
-            step_dev_ms = sum(e["ms_per_step"] for e in ktimes.values())
-            dom = max(ktimes, key=lambda nme: ktimes[nme]["ms_per_step"])
-            e = ktimes[dom]
-
-            def hbm_bytes(nme):
-                x = table.get(nme)
-                return x.get("hbm_bytes_per_launch") if x else None
-
-            tb = hbm_bytes(dom)
-            achieved = tb / (e["avg_launch_ms"] * 1e-3) / 1e9 if tb else None
-            step_bytes, covered = 0.0, True
-            for nme, ee in ktimes.items():
-                x = hbm_bytes(nme)
-                if x is None:
-                    covered = covered and ee["ms_per_step"] < 0.01 * step_dev_ms     # tiny kernels may be missing from the profile
-                else:
-                    step_bytes += x * ee["launches_per_step"]
-            fetch = (table.get(dom) or {}).get("fetch_bytes_per_launch")
-            roofline = {
-                "bound": "hbm", "kernel": dom, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                # as executed: HBM bytes of one launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/) over its live duration
-                "achieved": round(achieved, 1) if achieved else None,
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": tb, "traffic_source": tr_path, "traffic_stale": stale,
-                "avg_launch_ms": round(e["avg_launch_ms"], 4), "launches_per_step": e["launches_per_step"],
-                "time_share": round(e["ms_per_step"] / step_dev_ms, 4),
-                "request_rate": None, "whole_step": None,
-                "kernels": {nme: {"ms_per_step": round(ee["ms_per_step"], 4), "launches_per_step": ee["launches_per_step"],
-                                  "hbm_bytes_per_launch": hbm_bytes(nme),
-                                  "frac": round(hbm_bytes(nme) / (ee["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm_bytes(nme) and ee["avg_launch_ms"] > 0 else None}
-                            for nme, ee in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-                "note": "durations: hipEvents around every launch in untimed extra steps (one index lane, so they add up); "
-                        "bytes: rocprofv3 PMC passes of this workload (gfx950 corrections of MI355X_MICROARCH.md applied by tools/pmc_summary.py)",
-            }
-            if dom == "search_wide_kernel":
-                # ALGORITHMIC bytes of the row pass (SURVEY 8d's "bytes per unit x units", for this kernel's own algorithm):
-                # per read and window that can hold hit J = min(t, 3) of a strand's scan, six rows (planes A, B, C, both
-                # strands) of one bit per chunk filter; rows are filled in groups of 256 chunks
-                J = min(t, 3)
-                windows = max(0, (L - 1 - (t - J) * k) - (k - 1) + 1)
-                groups = -(-info["n_chunks"] // 256)
-                passes = -(-groups * 8 // 512)
-                row_bytes = -(-groups // passes) * 8 * 4
-                alg = n * windows * 6 * row_bytes * passes
-                # this kernel has an algorithmic byte count of its own, so the line's `achieved` / `frac` are that (the
-                # contract's definition); what the counters saw (rows start on 128-byte lines: 1312 of every 1408 bytes are
-                # asked for; the replay's single-word probes; FETCH_SIZE doubled as for every 16-byte-per-lane stream) is kept
-                roofline["as_executed"] = {"achieved": roofline["achieved"], "frac": roofline["frac"], "traffic": tb}
-                roofline["achieved"] = round(alg / (e["ms_per_step"] * 1e-3) / 1e9, 1)
-                roofline["frac"] = round(alg / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                roofline["algorithmic_bytes_per_launch"] = alg // max(1, int(e["launches_per_step"]))
-                roofline["algorithmic_model"] = (f"{n} reads x {windows} windows x 6 rows x {row_bytes} B (one bit per chunk filter, "
-                                                 f"{info['n_chunks']} chunks in groups of 256) x {passes} pass(es)")
-            if fetch and gather_ceiling and dom.startswith(("search", "tq_")) and dom != "search_wide_kernel":   # (gather kernels: one 64-byte sector per request)
-                rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
-                roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),
-                                            "frac": round(rps / gather_ceiling, 4),
-                                            "what": "64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against commet_membench's "
-                                                    "random 4-byte gathers over a filter-sized table, measured in this run"}
-            # what a step cannot avoid moving: both packed sets read once (12 bytes per 32 bases + a triple per read), every
-            # chunk's filter written once and read once (2^(k-1) bytes each way), the tag bits
-            triple_bytes = 12 * (L // 32 + 1)
-            compulsory = (info["reads_indexed"] + n) * triple_bytes + info["n_chunks"] * 2 * (1 << (k - 1)) + n // 8
-            roofline["compulsory_bytes"] = compulsory
-            if step_bytes and covered:
-                roofline["whole_step"] = {"traffic": round(step_bytes), "device_ms": round(step_dev_ms, 3),
-                                          "GBps": round(step_bytes / (step_dev_ms * 1e-3) / 1e9, 1),
-                                          "frac": round(step_bytes / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                roofline["traffic_over_compulsory"] = round(step_bytes / compulsory, 2)
-        # the contract's figure in REFERENCE probes, kept as detail: one request of ours answers several of them
-        idx_bytes_step = info["reads_indexed"] * (L / 4.0) + 4.0 * kmers * 2 * SECTOR
-        srch_bytes_step = info["reads_scanned"] * (L / 4.0 + 1 / 8.0) + probes * SECTOR if probes is not None else None
-        out = {
-            "metric": "reads/sec searched (index_and_search, k=%d)" % k,
-            "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32" if k <= 32 else "u64", "data": "synthetic",
-            "config": {"workload": workload,
-                       "reads_per_set": n, "read_len": L, "k": k, "t": t, "jobs": world,
-                       "parallelism": f"{world} independent (i,j) jobs, no collective"},
-            "roofline": roofline,
-            "detail": {"chunks": info["n_chunks"], "kmers_indexed": kmers, "reads_scanned": info["reads_scanned"],
-                       "shared": stats[0]["shared"], "searched_last_pass": stats[0]["searched"],
-                       "index_kernel_ms": round(idx_ms, 3), "search_kernel_ms": round(srch_ms, 3),
-                       "filter_zero_ms": round(acc["zero_ms"] / steps, 3),
-                       "p_ref_probes": probes,
-                       "reference_model_bytes_per_step": {"index": round(idx_bytes_step), "search": round(srch_bytes_step) if srch_bytes_step else None,
-                                                          "note": "SURVEY 8d's sector model of the REFERENCE's accesses; not what this implementation moves"},
-                       # a job on a search set that was never scanned (warm context): builds the set's query list as well
-                       "first_job_ms": round(first_job_s * 1e3, 3), "first_job_reads_per_s": round(n / first_job_s, 1),
-                       "query_list_bytes": query_list_bytes,
-                       "cold_context_first_job_ms": round(cold_context_first_job_s * 1e3, 3) if cold_context_first_job_s else None,
-                       "upload_and_pack_s": round(upload_s, 3), "upload_second_set_s": round(upload_s - upload_first_s, 3),
-                       "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
-                       "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
-                       "matrix": matrix_detail},
-        }
-        if matrix_detail and "error" not in matrix_detail:
-            # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
-            out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
-                                                           "jobs_s", "imbalance", "predicted_vs_actual_share")}
-        if world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, b0, b1)
-        print(json.dumps(out), flush=True)
+    emit(matrix_detail)
 
     ranks.close()
 
