@@ -96,23 +96,24 @@ def _launch(world, args, cwd, timeout=600, extra_env=None):
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=cwd, timeout=timeout)
 
 
-@pytest.mark.parametrize("world,handover", [(2, "ipc"), (2, "image"), (8, "ipc")])
+@pytest.mark.parametrize("world,handover", [(2, "ipc"), (2, "image"), (8, "ipc"), (2, "default")])
 def test_matrix_driver_host_logic_over_gloo_ranks(tmp_path, world, handover):
     """The N x N driver over `world` processes (gloo; the CPU checker stands in for the GPU engine): every set is parsed
     by exactly one rank, the others take it from its owner — device to device through an exported descriptor ("ipc": the
-    engine's export / import, probed between the ranks first) or as a packed image in the scratch directory ("image":
-    COMMET_MATRIX_IPC=0); outputs equal Commet.py's job sequence run in one process."""
+    engine's export / import, probed between the ranks first: COMMET_MATRIX_IPC=1) or as a packed image in the scratch directory
+    ("image": COMMET_MATRIX_IPC=0, and what the driver does when nothing is said: "default"); outputs equal Commet.py's job
+    sequence run in one process."""
     import json
     import oracle_binding as ob
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden import commet_jobs
     k, t, names, files, bvs = _matrix_case(tmp_path)
     p = _launch(world, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t)], str(tmp_path),
-                extra_env={"COMMET_MATRIX_IPC": "1" if handover == "ipc" else "0"})
+                extra_env={} if handover == "default" else {"COMMET_MATRIX_IPC": "1" if handover == "ipc" else "0"})
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     res = json.load(open(tmp_path / "out" / "result.json"))
     assert res["world"] == world and len(res["per_rank"]) == world
-    assert {r["handover"] for r in res["per_rank"]} == {handover}
+    assert {r["handover"] for r in res["per_rank"]} == {"image" if handover == "default" else handover}
     assert sum(r["sets_parsed"] for r in res["per_rank"]) == len(names)          # one parse per set on the node
     assert sum(r["pairs"] for r in res["per_rank"]) == 10
     assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + world
