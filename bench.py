@@ -7,11 +7,12 @@ resident in HBM: set 0 is indexed chunk by chunk (filter zeroing + index
 kernels), set 1 is searched against every chunk (search kernels), tag bits come
 back to the host.  value = query reads searched per second (whole job).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards as
-independent (i, j) jobs with no data-path collective, so every rank
-runs its own job of the same size on its own GPU -> "weak" scaling; ranks only
-meet at the barriers around the timed region (gloo; the GPU work never touches
-torch) and value = all ranks' reads / the slowest rank's time.
+N > 1 (one rank per GPU; started by torch.distributed.run, or by this script
+itself as plain child processes when no launcher is around it): the path shards
+as independent (i, j) jobs with no data-path collective, so every
+rank runs its own job of the same size on its own GPU -> "weak" scaling; ranks
+only meet at the barriers around the timed region (a TCP store of rank 0; no
+torch in the rank processes) and value = all ranks' reads / the slowest rank's time.
 
 The JSON line also carries
   roofline     — the kernel with the largest measured share of the step's device
@@ -28,9 +29,12 @@ The JSON line also carries
   cpu_baseline — the reference CPU tool (oracle/_ref, kind "reference") or our
                  C restatement (oracle/, kind "port") on a bounded sample of the
                  same synthetic sets: one copy, and one copy per host core.
-  detail.matrix — BASELINE configs[2] (10 sets x 10 M reads, the 10 x 10 matrix)
+  matrix       — BASELINE configs[3] (10 sets x 50 M reads, the 10 x 10 matrix)
                  through commet_amd.matrix split over the N ranks, filter and
-                 load times included (--no-matrix skips it).
+                 load times included — the SAME workload at every N, one GPU
+                 included, so the per-N values are one curve (detail.matrix has
+                 the per-rank profile; detail.matrix_configs2 is configs[2],
+                 10 x 10 M reads, on one GPU; --no-matrix skips both).
 """
 import argparse
 import hashlib
@@ -67,7 +71,8 @@ def parse_args():
     ap.add_argument("--no-matrix", action="store_true", help="skip the configs[2] matrix leg (detail.matrix)")
     ap.add_argument("--matrix-sets", type=int, default=10)
     ap.add_argument("--matrix-reads", type=int, default=None,
-                    help="reads per set of the matrix leg (default: 10 M = configs[2] on one GPU, 50 M = configs[3] on several)")
+                    help="reads per set of the matrix leg (default: 50 M = configs[3] at every N when the host holds the files, "
+                         "plus 10 M = configs[2] on one GPU)")
     ap.add_argument("--skew", type=float, default=0.0,
                     help="fraction of every set's reads replaced by low-complexity / repeated reads (poly-A, tandem repeats, a shared "
                          "1000-read library): the non-uniform data leg, synth.skew_set")
@@ -78,18 +83,12 @@ def parse_args():
 
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process, which has made no HIP
-    call and never will, starts the N ranks through torch.distributed.run as a CHILD process (one rank per GPU,
-    rendezvous on 127.0.0.1), passes the child's output through and leaves with its exit code."""
-    import socket
-    with socket.socket() as sk:                      # a free port for the rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    call and never will, starts the N ranks as plain `python bench.py` CHILD processes (one rank per GPU; RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT in their environment; no torch anywhere: the ranks meet
+    over commet_amd.sharding's TCP store), passes their output through and leaves with the first non-zero exit code."""
+    from commet_amd import sharding
+    return sharding.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                env=dict(os.environ, COMMET_SELF_LAUNCHED="1"))
 
 
 def host_cores():
@@ -251,31 +250,39 @@ def progress(ranks, msg):
         print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
-def matrix_leg(args, ranks):
-    """BASELINE configs[2] through the resident N x N driver, split over the ranks; sets written as FASTA to scratch
-    (each rank generates its share), filter + load + jobs all timed by the driver."""
+def matrix_size(args, ranks, root):
+    """reads per set of the like-for-like matrix leg: BASELINE configs[3] (10 x 50 M reads) at EVERY N, one GPU included, so that the
+    per-N values are one curve; what the host cannot hold as FASTA in the scratch root is cut down (and said so).  Returns (n, note)."""
+    S, L = args.matrix_sets, args.read_len
+    if args.matrix_reads is not None:
+        return args.matrix_reads, None
+    n, note = 50_000_000, None
+    workers_all = min(S, max(1, host_cores() // 2))
+    free = ranks.broadcast_object(host_memory_free(root) if ranks.rank == 0 else None)
+    while free is not None and n > 1_000_000 and matrix_memory_needed(S, n, L, workers_all) * 1.25 > free:
+        note = f"host memory ({free / 2**30:.0f} GiB free) does not hold {S} x {n} reads as FASTA in {root}"
+        n = 10_000_000 if n > 10_000_000 else n // 2
+    if note:
+        note += f": {n} reads per set instead"
+        if ranks.rank == 0:
+            print("bench.py matrix leg: " + note, file=sys.stderr)
+    return n, note
+
+
+def matrix_leg(args, ranks, n, note=None):
+    """The full S x S matrix of S synthetic sets of n reads through the resident N x N driver, split over the ranks; sets written
+    as FASTA to scratch (each rank generates its share), filter + load + jobs all timed by the driver."""
     from commet_amd import matrix, synth
     root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
     # rank 0 makes the work directory (mkdtemp: a fresh name, mode 0700 — /dev/shm is shared with other users)
     work = ranks.broadcast_object(tempfile.mkdtemp(prefix="commet_bench_", dir=root) if ranks.rank == 0 else None)
     _WORK_DIRS.append(work)
     S, L = args.matrix_sets, args.read_len
-    # one GPU: BASELINE configs[2] (10 x 10 M reads); several: configs[3] (10 x 50 M reads, the matrix sharded over the GPUs)
-    n = args.matrix_reads or (10_000_000 if ranks.world == 1 else 50_000_000)
-    workers_all = min(S, max(1, host_cores() // 2))                # generator processes of all ranks together (see below)
-    note = None
-    if args.matrix_reads is None:                                  # the default size must fit the host: never drive the box out of memory
-        free = ranks.broadcast_object(host_memory_free(root) if ranks.rank == 0 else None)
-        while free is not None and n > 1_000_000 and matrix_memory_needed(S, n, L, workers_all) * 1.25 > free:
-            note = f"host memory ({free / 2**30:.0f} GiB free) does not hold {S} x {n} reads as FASTA in {root}"
-            n = 10_000_000 if n > 10_000_000 else n // 2
-        if note:
-            note += f": {n} reads per set instead"
-            if ranks.rank == 0:
-                print("bench.py matrix leg: " + note, file=sys.stderr)
     which = {(10, 10_000_000): "BASELINE configs[2]", (10, 50_000_000): "BASELINE configs[3]"}.get((S, n), "custom size")
     progress(ranks, f"matrix leg: {S} sets x {n} reads ({which}) over {ranks.world} rank(s): writing the FASTA files under {work}")
-    try:
+    saved_scratch = os.environ.get("COMMET_SCRATCH")
+    os.environ["COMMET_SCRATCH"] = work          # the driver's own scratch (descriptors, packed images) inside the work directory:
+    try:                                          # whoever removes `work` removes everything this leg ever wrote
         t0 = time.perf_counter()
         mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
         if mine:
@@ -294,9 +301,14 @@ def matrix_leg(args, ranks):
                          progress=lambda msg: print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] matrix leg, rank {ranks.rank}: {msg}",
                                                     file=sys.stderr, flush=True))
     finally:
+        if saved_scratch is None:
+            os.environ.pop("COMMET_SCRATCH", None)
+        else:
+            os.environ["COMMET_SCRATCH"] = saved_scratch
         ranks.barrier()
         if ranks.rank == 0:
             shutil.rmtree(work, ignore_errors=True)
+        _WORK_DIRS.remove(work)
     progress(ranks, "matrix leg: done")
     if res is None:
         return None
@@ -308,6 +320,7 @@ def matrix_leg(args, ranks):
     out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix ({which}) over {ranks.world} GPU(s): "
                         f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",
                generate_s=round(gen_s, 2), size_note=note,
+               handover=sorted({p.get("handover") for p in per_rank}) if ranks.world > 1 else None,
                # how evenly the static cut of the pairs loaded the ranks: slowest / mean of the ranks' job time (1.0 = even),
                # and what the cut predicted for every rank (its share of the pairs' cost) beside what it took
                imbalance=round(max(busy) / (sum(busy) / len(busy)), 4) if busy and sum(busy) > 0 else None,
@@ -325,17 +338,19 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_STACKS_S"]), repeat=False, file=sys.stderr)
     from commet_amd import sharding
-    ranks = sharding.Ranks(backend="gloo")   # host-side barrier / MAX only; N=1 needs no torch at all
+    ranks = sharding.Ranks()   # host-side barrier / gather / MAX over a TCP store of rank 0: no torch in the rank processes
     world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports {world}", file=sys.stderr)
     if args.rendezvous_only:
         elapsed = sharding.timed_region(ranks, lambda: None, lambda: time.sleep(0.01 * (rank + 1)), args.steps)
         devices = ranks.gather_objects(int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+        torch_in = ranks.gather_objects("torch" in sys.modules)
         if rank == 0:
             print(json.dumps({"metric": "rendezvous only (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(elapsed * 1000.0 / args.steps, 3), "devices": devices,
-                              "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None}), flush=True)
+                              "self_launched": os.environ.get("COMMET_SELF_LAUNCHED") == "1", "ranks_backend": ranks.backend,
+                              "torch_in_ranks": any(torch_in)}), flush=True)
         ranks.close()
         return
 
@@ -422,7 +437,7 @@ def main():
     import threading
     emitted = threading.Event()
 
-    def emit(matrix_detail):
+    def emit(matrix_detail, matrix_c2=None):
         """rank 0: the one JSON line (once)"""
         if rank != 0 or emitted.is_set():
             return
@@ -538,38 +553,56 @@ def main():
                            "upload_and_pack_s": round(upload_s, 3), "upload_second_set_s": round(upload_s - upload_first_s, 3),
                            "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
                            "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
-                           "matrix": matrix_detail},
+                           "matrix": matrix_detail, "matrix_configs2": matrix_c2},
             }
             if matrix_detail and "error" not in matrix_detail:
                 # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
+                # (the same workload at every N — BASELINE configs[3] when the host holds it — so the per-N values are one curve)
                 out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
-                                                               "jobs_s", "imbalance", "predicted_vs_actual_share")}
+                                                               "jobs_s", "set_wait_s", "handover", "imbalance", "predicted_vs_actual_share", "size_note")}
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, b0, b1)
             print(json.dumps(out), flush=True)
 
-    matrix_detail = None
+    matrix_detail, matrix_c2 = None, None
     if not args.no_matrix and args.matrix_sets >= 2:
-        # The extra leg must never cost the headline: if it is not done after BENCH_MATRIX_LIMIT_S (default 900 s; it takes ~20 s
-        # on one GPU, ~60 s for configs[3] on two ranks) every rank gives it up — rank 0 prints the line without it — and leaves.
+        # The extra legs must never cost the headline: if they are not done after BENCH_MATRIX_LIMIT_S (default 900 s; configs[3] takes
+        # ~60 s on one GPU, most of it writing the FASTA files) every rank gives up — rank 0 prints the line without them — ends its
+        # child processes, removes what it wrote and leaves NON-ZERO: a GPU process that had to be abandoned is not a success.
         limit = float(os.environ.get("BENCH_MATRIX_LIMIT_S", "900"))
 
         def bail():
             progress(ranks, f"matrix leg: not done after {limit:.0f} s; the line goes out without it")
             try:
-                emit({"error": f"matrix leg not done after {limit:.0f} s (abandoned)"})
+                emit({"error": f"matrix leg not done after {limit:.0f} s (abandoned)"}, matrix_c2)
             finally:
                 sys.stdout.flush()
-                if rank == 0:
-                    for w in _WORK_DIRS:
-                        shutil.rmtree(w, ignore_errors=True)
-                os._exit(0)
+                try:                                  # filter_reads, generator and canary processes of THIS rank, by their pids
+                    import psutil
+                    for ch in psutil.Process().children(recursive=True):
+                        try:
+                            ch.kill()
+                        except psutil.Error:
+                            pass
+                except Exception:
+                    pass
+                for w in list(_WORK_DIRS):            # (every rank: the directory holds this rank's packed images, too)
+                    shutil.rmtree(w, ignore_errors=True)
+                os._exit(3)
 
         watch = threading.Timer(limit, bail)
         watch.daemon = True
         watch.start()
         try:
-            matrix_detail = matrix_leg(args, ranks)
+            root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
+            n_m, note = matrix_size(args, ranks, root)
+            if world == 1 and args.matrix_reads is None and n_m > 10_000_000:
+                # one GPU: BASELINE configs[2] (10 x 10 M reads) as well, a second object beside the like-for-like one
+                try:
+                    matrix_c2 = matrix_leg(args, ranks, 10_000_000)
+                except Exception as ex:
+                    matrix_c2 = {"error": f"{type(ex).__name__}: {ex}"}
+            matrix_detail = matrix_leg(args, ranks, n_m, note)
         except Exception as ex:   # the headline measured above must not be lost with this extra leg
             import traceback
             traceback.print_exc()
@@ -577,7 +610,7 @@ def main():
         finally:
             watch.cancel()
 
-    emit(matrix_detail)
+    emit(matrix_detail, matrix_c2)
 
     ranks.close()
 

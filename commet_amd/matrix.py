@@ -10,12 +10,14 @@ on sets that stay packed in HBM:
                     J2  index S_i   restricted to T1         search S_ref    -> <G>_in_<S_i>.bv
                     J3  index S_ref restricted to J2's bits  search S_i      -> <F>_in_<S_ref>.bv
 
-One process per GPU (torch.distributed.run).  The path has no exchange step, so ranks share
-nothing but files and three host-side gathers (gloo):
-  * every set is PARSED ONCE on the node: set s by rank s % world, which leaves its packed
-    image (commet_readset_save: the bit-planes as they lie in HBM) in a scratch directory
-    (/dev/shm); the other ranks that need the set load that image — a memcpy and an upload,
-    no parsing;
+One process per GPU.  The path has no exchange step, so ranks share nothing but small files
+and three host-side gathers (sharding.Ranks: a TCP store of rank 0, no torch in the ranks):
+  * every set is PARSED ONCE on the node: set s by rank s % world, which exports the set's
+    device buffers (commet_readset_export: HIP IPC handles, a 264-byte descriptor in a scratch
+    directory); the other ranks that need the set copy it device to device
+    (commet_readset_import: xGMI between GPUs) — no file, no parsing.  Where that is not to be
+    had (the probe or the canary below fail, COMMET_MATRIX_IPC=0) the set travels as a packed
+    image in /dev/shm (commet_readset_save / _load);
   * the row-major list of (ref, i) pairs is cut into contiguous runs of equal cost, one per
     rank: a rank works on few reference sets, builds J1's index of S_ref once for all its
     targets (as Commet.py's J1 does), and loads only the sets its pairs touch;
@@ -26,7 +28,8 @@ step (`filter_reads`, skipped when bvs are given), `OUT/<file>_in_<set>.bv`,
 `OUT/<s>_in_<i>.log`, `matrix_plain.csv`, `matrix_percentage.csv`, `matrix_normalized.csv`.
 
   python -m commet_amd.matrix sets.txt -k 32 -t 2 -o out/            (1 GPU)
-  python -m torch.distributed.run --nproc-per-node 8 -m commet_amd.matrix sets.txt …   (8 GPUs)
+  python -m commet_amd.matrix sets.txt -k 32 -t 2 -o out/ --gpus 8   (8 GPUs: starts its own ranks)
+  python -m torch.distributed.run --nproc-per-node 8 -m commet_amd.matrix sets.txt …   (any launcher that sets RANK / WORLD_SIZE / MASTER_*)
 """
 import argparse
 import os
@@ -34,6 +37,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 import traceback
 
@@ -168,6 +172,11 @@ class HipEngine:
     def import_set(self, blob):
         return self._api.ReadSet.import_(self.ctx, blob)
 
+    def canary_argv(self, scratch, candidates):
+        """the command of the fresh child process that imports the first real set before this process does (ipc_canary.py)"""
+        return [sys.executable, "-m", "commet_amd.ipc_canary", str(self.ctx.device), str(self.ctx.k), str(self.ctx.t), scratch,
+                ",".join(str(c) for c in candidates)]
+
     def same_set(self, a, b):
         """the packed images of two resident sets are the same bytes (the hand-over probe: what came over is what was sent)"""
         d = tempfile.mkdtemp(prefix="commet_probe_", dir=_scratch_root())
@@ -212,7 +221,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     t_start = time.perf_counter()
     own_ranks = ranks is None
     if ranks is None:
-        ranks = sharding.Ranks(backend="gloo")
+        ranks = sharding.Ranks()
     world, rank = ranks.world, ranks.rank
     if out_dir[-1] != "/":
         out_dir += "/"
@@ -297,23 +306,45 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # neighbour and of rank 0; else as a packed image in the scratch directory (0.5 s to write, 0.2 s to read).
     use_ipc = False
 
-    def import_one_at_a_time(blob):
-        """eng.import_set under a lock file of the node: two processes that attach to each other's buffers at the same moment
-        (rank 0 importing a set of rank 1 while rank 1 imports one of rank 0) were seen to block each other for good inside the
-        HIP IPC attach — both stuck in commet_readset_import, 2 x 50 M-read sets, two ranks; one import at a time on the node
-        costs nothing measurable (an import is tens of ms)"""
-        import fcntl
-        with open(os.path.join(scratch, "import.lock"), "a+") as lf:
-            fcntl.flock(lf, fcntl.LOCK_EX)
-            try:
-                return eng.import_set(blob)
-            finally:
-                fcntl.flock(lf, fcntl.LOCK_UN)
+    def import_guarded(blob):
+        """eng.import_set with a deadline: a HIP call that hangs cannot be cancelled from inside the process, so a rank whose
+        import does not return leaves (non-zero; the launcher ends the job) rather than keep its peers waiting for good.
+        COMMET_IPC_LOCK=1 also takes a lock file of the node around the import (one import at a time on the node: a round-3
+        precaution against two processes attaching to each other's buffers at the same moment, never needed without torch)."""
+        def give_up():
+            print(f"commet_amd.matrix, rank {rank}: commet_readset_import did not return within {limit:.0f} s; leaving", file=sys.stderr, flush=True)
+            for s_ in owned:
+                for ext in ("pk", "ipc"):
+                    try:
+                        os.remove(os.path.join(scratch, f"set{s_}.{ext}"))
+                    except OSError:
+                        pass
+            os._exit(4)
 
-    # Opt-in (COMMET_MATRIX_IPC=1) since the end of round 3: with 2 x 5 sets of 50 M reads on two ranks of one device an import
-    # (commet_readset_import of 1.9 GB) did not return within minutes although imports of the same size between two otherwise
-    # idle processes take 12-22 ms (tools/image_bench.py) and the small multi-rank tests pass; the images are slower and safe.
-    if world > 1 and os.environ.get("COMMET_MATRIX_IPC", "0") == "1" and hasattr(eng, "export_set"):
+        limit = float(os.environ.get("COMMET_IPC_IMPORT_LIMIT_S", "120"))
+        watch = threading.Timer(limit, give_up)
+        watch.daemon = True
+        watch.start()
+        try:
+            if os.environ.get("COMMET_IPC_LOCK", "0") == "1":
+                import fcntl
+                with open(os.path.join(scratch, "import.lock"), "a+") as lf:
+                    fcntl.flock(lf, fcntl.LOCK_EX)
+                    try:
+                        return eng.import_set(blob)
+                    finally:
+                        fcntl.flock(lf, fcntl.LOCK_UN)
+            return eng.import_set(blob)
+        finally:
+            watch.cancel()
+
+    # The default since round 4 (COMMET_MATRIX_IPC=0: packed images).  Round 3 had to make it opt-in: an import of a 50 M-read set
+    # did not return when the rank process had imported torch (for the gloo barrier) — two ROCm runtimes in one process.  The ranks
+    # meet over sharding's TCP store now and hold one runtime.  Two nets stay under the large imports, which the probe below (a
+    # four-read set) says nothing about: the first REAL set is imported by a fresh child process first (the canary: killed when it
+    # does not come back, and every rank then asks the owners for packed images), and an import of this process that does not
+    # return within COMMET_IPC_IMPORT_LIMIT_S ends the rank non-zero instead of leaving the job hung.
+    if world > 1 and os.environ.get("COMMET_MATRIX_IPC", "1") != "0" and hasattr(eng, "export_set"):
         probe = blob = None
         try:
             probe = eng.parse_probe()
@@ -328,7 +359,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     if blobs[src] is None:
                         ok = 0
                     else:
-                        got = import_one_at_a_time(blobs[src])    # every rank's probe set holds the same reads:
+                        got = import_guarded(blobs[src])    # every rank's probe set holds the same reads:
                         if hasattr(eng, "same_set") and not eng.same_set(got, probe):   # a copy that arrives damaged counts as no hand-over
                             say("device-to-device hand-over of sets: the probe set did not arrive intact: packed images instead")
                             ok = 0
@@ -343,8 +374,19 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     exported = {}                                                 # sets this rank keeps alive for the others' imports
     loader, loader_stop = None, None
     prof = dict(rank=rank, pairs=len(mine), sets_parsed=0, sets_loaded=0, j1_builds=0, parse_s=0.0, save_s=0.0, load_s=0.0,
-                jobs=0, call_ms=0.0, device_ms=0.0, handover="ipc" if use_ipc else "image",
+                jobs=0, call_ms=0.0, device_ms=0.0, handover="ipc" if use_ipc else "image", backend=getattr(ranks, "backend", None),
+                torch_loaded="torch" in sys.modules,
                 predicted_share=round(sum(pair_cost[c] for c in runs[rank]) / max(sum(pair_cost), 1e-9), 4))   # what the static cut expects of this rank
+    # the canary: of the ranks that take sets from others, the first one starts a fresh child process that imports the first
+    # real set to appear (tests/engines without a child command: no canary)
+    def foreign(r):
+        return sorted({s_ for c in runs[r] for s_ in pairs[c] if s_ % world != r})
+
+    canary_rank = next((r for r in range(world) if foreign(r)), None) if use_ipc else None
+    canary = None
+    if use_ipc and rank == canary_rank and hasattr(eng, "canary_argv") and os.environ.get("COMMET_IPC_CANARY", "1") != "0":
+        canary = subprocess.Popen(eng.canary_argv(scratch, foreign(rank)), stdout=subprocess.DEVNULL)
+    server, serve_stop, stop_ev = None, None, None
     try:
         # ---- residency: parse my sets once, publish their packed images, load the others I need ----------------
         t0 = time.perf_counter()
@@ -390,16 +432,100 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
 
-        def fetch(s):
-            """another rank's set: from its owner's device buffers, or from its packed image"""
+        stop_ev = threading.Event()                               # set when this rank is through (or has failed): ends every wait below
+        hand = dict(ipc=use_ipc, canary=None)
+
+        def wait_file(path, what):
+            """a file another rank publishes (renamed into place: complete or absent): there once its owner has got that far
+            (or never, if that rank died: the launcher then ends this process; the deadline only bounds a stray wait)"""
+            deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
             w0 = time.perf_counter()
-            if use_ipc:
-                with open(os.path.join(scratch, f"set{s}.ipc"), "rb") as fh:
-                    sets[s] = import_one_at_a_time(fh.read())
+            while not os.path.exists(path):
+                if stop_ev.is_set():
+                    return False
+                if time.perf_counter() > deadline:
+                    raise RuntimeError(f"{what} did not appear in {scratch}")
+                time.sleep(0.002)
+            prof["image_wait_s"] = prof.get("image_wait_s", 0.0) + time.perf_counter() - w0
+            return True
+
+        def canary_verdict():
+            """Did the fresh child process of `canary_rank` get the first real set across?  That rank waits for its child (and
+            kills it by its pid when it does not answer in COMMET_IPC_CANARY_S), says so in the scratch directory, the others
+            read it there.  True: this process imports, too."""
+            if hand["canary"] is None:
+                ok_path, fail_path = os.path.join(scratch, "canary.ok"), os.path.join(scratch, "canary.fail")
+                if rank == canary_rank:
+                    verdict = "passed"
+                    if canary is not None:
+                        limit = float(os.environ.get("COMMET_IPC_CANARY_S", "30"))
+                        try:
+                            rc = canary.wait(timeout=limit)
+                            verdict = "passed" if rc == 0 else f"failed (exit code {rc})"
+                        except subprocess.TimeoutExpired:
+                            canary.kill()
+                            try:
+                                canary.wait(timeout=5)
+                            except subprocess.TimeoutExpired:
+                                pass
+                            verdict = f"failed (no answer within {limit:.0f} s: killed)"
+                    path = ok_path if verdict == "passed" else fail_path
+                    with open(path + ".tmp", "w") as fh:
+                        fh.write(verdict)
+                    os.rename(path + ".tmp", path)
+                else:
+                    deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
+                    while not (os.path.exists(ok_path) or os.path.exists(fail_path)):
+                        if stop_ev.is_set() or time.perf_counter() > deadline:
+                            break
+                        time.sleep(0.002)
+                    verdict = "passed" if os.path.exists(ok_path) else (open(fail_path).read() if os.path.exists(fail_path) else "failed (no verdict)")
+                hand["canary"] = verdict
+                prof["ipc_canary"] = verdict
+            return hand["canary"] == "passed"
+
+        def fetch(s):
+            """another rank's set: from its owner's device buffers, or from its packed image; False: this rank is stopping"""
+            ipc_path, pk_path = os.path.join(scratch, f"set{s}.ipc"), os.path.join(scratch, f"set{s}.pk")
+            if hand["ipc"]:
+                if not wait_file(ipc_path, f"the descriptor of set {s}"):
+                    return False
+                if not canary_verdict():                          # (the first set only)
+                    hand["ipc"] = False
+                    prof["handover"] = "image"
+                    note(f"device-to-device hand-over given up (canary {hand['canary']}): packed images from here on")
+            w0 = time.perf_counter()
+            if hand["ipc"]:
+                with open(ipc_path, "rb") as fh:
+                    sets[s] = import_guarded(fh.read())
             else:
-                sets[s] = eng.load(os.path.join(scratch, f"set{s}.pk"))
+                if use_ipc:                                       # the owners published descriptors only: ask for the image
+                    open(os.path.join(scratch, f"set{s}.want.{rank}"), "w").close()
+                w0 = time.perf_counter()
+                if not wait_file(pk_path, f"the packed image of set {s}"):
+                    return False
+                w0 = time.perf_counter()
+                sets[s] = eng.load(pk_path)
             prof["load_s"] += time.perf_counter() - w0
             prof["sets_loaded"] += 1
+            return True
+
+        def serve_images():
+            """the way back: a rank that gave the device-to-device hand-over up asks for `set<s>.pk`; its owner, which keeps
+            every exported set alive, writes it"""
+            served = set()
+            while not serve_stop.wait(0.005):
+                for s_ in list(exported):
+                    if s_ not in served and any(f.startswith(f"set{s_}.want.") for f in os.listdir(scratch)):
+                        w0 = time.perf_counter()
+                        eng.save(exported[s_], os.path.join(scratch, f"set{s_}.pk"))
+                        prof["save_s"] += time.perf_counter() - w0
+                        served.add(s_)
+
+        server, serve_stop = None, threading.Event()
+        if use_ipc and any(s_ in needed_by_others for s_ in owned):
+            server = threading.Thread(target=serve_images, name="commet-image-server", daemon=True)
+            server.start()
 
         def diagonal():
             """reads every set was asked about (its filters' popcount): each set once, by its parser; known to all ranks"""
@@ -415,7 +541,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         if not pipelined:
             for s in needed:
                 if s not in sets:
-                    fetch(s)
+                    fetch(s)                                      # (its owner's descriptor / image is in place behind the barrier)
             filters_done()
             for s in needed:
                 prepare(s)
@@ -426,11 +552,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             # A second host thread makes the sets resident in the order the jobs want them (read sets are made on a stream
             # of their own, include/commet_hip.h) while this one runs the jobs of a reference set as soon as it and its
             # targets are there: the host-bound loading hides behind the device-bound jobs.  One rank: the thread parses
-            # the files, last set first, and ref = N-2, N-3, ... need the sets ref .. N-1.  Several ranks: every rank has
-            # parsed its own sets above and all images are in place behind the barrier; the thread takes the others'.
-            import threading
+            # the files, last set first, and ref = N-2, N-3, ... need the sets ref .. N-1.  Several ranks: the thread parses
+            # this rank's own sets and publishes them, then takes the others' as they appear (no barrier in between).
             ready = [threading.Event() for _ in range(N)]
-            loader_stop = threading.Event()
+            loader_stop = stop_ev
             load_err = []
             load_end = [t0]
             filters_ready = threading.Event()
@@ -451,21 +576,6 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 wanted_by = {s_: sum(1 for r in range(world) if any(s_ in pairs[c] for c in runs[r])) for s_ in owned}
                 own_first = sorted((s_ for s_ in owned if s_ in needed or s_ in needed_by_others), key=lambda s_: (-wanted_by[s_], s_))
 
-            def wait_image(s):
-                """another rank's packed image: there once its owner has parsed the set (or never, if that rank died:
-                the launcher then ends this process; the deadline only bounds a stray wait)"""
-                path = os.path.join(scratch, f"set{s}.ipc" if use_ipc else f"set{s}.pk")
-                deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
-                w0 = time.perf_counter()
-                while not os.path.exists(path):
-                    if loader_stop.is_set():
-                        return False
-                    if time.perf_counter() > deadline:
-                        raise RuntimeError(f"packed image of set {s} did not appear in {scratch}")
-                    time.sleep(0.002)
-                prof["image_wait_s"] = prof.get("image_wait_s", 0.0) + time.perf_counter() - w0
-                return True
-
             def load_all():
                 try:
                     for s in own_first:
@@ -483,10 +593,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             filter_done_for(s)
                             considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
                         else:
-                            if s not in sets:
-                                if not wait_image(s):
-                                    break
-                                fetch(s)
+                            if s not in sets and not fetch(s):
+                                break
                             while not filters_ready.wait(0.05):  # every rank's filter files are written (the job thread says so)
                                 if loader_stop.is_set():
                                     return
@@ -571,7 +679,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 filters_done()
             load_s = load_end[0] - t0
         # ---- matrices on rank 0 -----------------------------------------------------------------------------
-        everyone = ranks.gather_objects((shared, prof))
+        everyone = ranks.gather_objects((shared, prof))     # (every rank is through its jobs: nobody asks for a set any more)
+        if server is not None:
+            serve_stop.set()
+            server.join()
         result = None
         if rank == 0:
             mat = [[0] * N for _ in range(N)]
@@ -609,9 +720,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             eng.release(rs)
         return result
     finally:
+        if stop_ev is not None:
+            stop_ev.set()
         if loader is not None and loader.is_alive():             # (an error in the job thread)
-            loader_stop.set()
             loader.join()
+        if server is not None and server.is_alive():
+            serve_stop.set()
+            server.join()
+        if canary is not None and canary.poll() is None:         # (never asked: this rank failed first)
+            canary.kill()
         if filter_pool is not None:
             filter_pool.shutdown(wait=True, cancel_futures=True)
         eng.close()
@@ -643,7 +760,12 @@ def main(argv=None):
     ap.add_argument("-n", type=int, default=-1)
     ap.add_argument("-e", type=float, default=0)
     ap.add_argument("-m", type=int, default=-1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks to start on this node, one per GPU (ignored under a launcher that has set WORLD_SIZE)")
     a = ap.parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # this process never touches the GPU: it starts the ranks as plain child processes and leaves with their exit code
+        return sharding.spawn_ranks(a.gpus, [sys.executable, "-m", "commet_amd.matrix"] + list(sys.argv[1:] if argv is None else argv))
     try:
         res = run(a.input_file, a.directory, k=a.k, t=a.t, l=a.l, n=a.n, e=a.e, m=a.m, bin_dir=a.bin_dir)
         if res is not None and os.environ.get("COMMET_MATRIX_REPORT"):   # rank 0: times and per-rank profile, as JSON

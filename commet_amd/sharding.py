@@ -9,7 +9,8 @@ for ref < i.  J1(ref) is split per search set so that every (ref, i) pair is one
 independent chain J1(ref,i) -> J2(ref,i) -> J3(ref,i): N(N-1)/2 chains, no
 ordering between chains, only `.bv` bit-vectors flow inside a chain.  Chains
 are dealt to ranks; the only cross-rank operations are a barrier and a MAX
-reduction of the elapsed time (gloo on the host: no data-path collective)."""
+reduction of the elapsed time (on the host, over a small TCP store held by rank 0:
+no data-path collective, and no torch in the rank processes)."""
 import time
 
 
@@ -65,75 +66,399 @@ def assign_pairs_contiguous(cost, world_size):
     return [range(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-class Ranks:
-    """Barrier / MAX-of-elapsed over ranks.  world_size 1 needs no torch at all."""
+# ---- ranks of one job: barrier / gather / MAX / SUM on the host, no torch --------------------------------------
+#
+# The path has no data-path collective; what the ranks of a job tell each other are a few small host
+# objects (who took which pairs, elapsed seconds, a scratch directory's name).  The default backend is a key / value
+# store held by rank 0 on MASTER_ADDR : MASTER_PORT + 1 ... (a launcher such as torch.distributed.run keeps MASTER_PORT
+# itself for its own store) which the ranks reach over TCP: nothing but the standard library is imported, so a rank
+# process holds ONE ROCm runtime — the system's, through libcommet_hip.so — and not a second one from torch's wheel
+# beside it (with both in a process commet_readset_import of a large set did not return).
+# backend="gloo" (or COMMET_RANKS_BACKEND=gloo) keeps the torch.distributed form.
 
-    def __init__(self, backend="gloo"):
+_MAGIC = b"COMMETRZ1"
+_PORT_SPAN = 32
+
+
+def _rdzv_token():
+    import hashlib
+    import os
+    tok = os.environ.get("COMMET_RDZV_TOKEN") or ":".join(os.environ.get(v, "") for v in (
+        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "WORLD_SIZE"))
+    return hashlib.sha256(tok.encode()).digest()
+
+
+def _send_frame(sock, *parts):
+    import struct
+    msg = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+    sock.sendall(struct.pack("<IQ", len(parts), len(msg)) + msg)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("rendezvous connection closed")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_frame(sock):
+    import struct
+    nparts, total = struct.unpack("<IQ", _recv_exact(sock, 12))
+    msg = _recv_exact(sock, total)
+    parts, pos = [], 0
+    for _ in range(nparts):
+        (ln,) = struct.unpack_from("<Q", msg, pos)
+        parts.append(msg[pos + 8:pos + 8 + ln])
+        pos += 8 + ln
+    return parts
+
+
+class _Store:
+    """Rank 0's key / value store: SET, GET (waits for the key), DEL (by prefix), BYE.  Values are opaque bytes.  Every rank
+    connects once; a connection that drops without BYE means that rank died: every waiting and later GET is then answered
+    with an error, so the other ranks fail within seconds instead of at a timeout."""
+
+    def __init__(self, world, token, host, first_port):
+        import socket
+        import threading
+        self.world, self.token = world, token
+        self.kv, self.cv = {}, threading.Condition()
+        self.lost = None
+        self.seen, self.byes = set(), 0
+        self.sock, self.port = None, None
+        err = None
+        for port in range(first_port, first_port + _PORT_SPAN):
+            sk = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                sk.bind((host, port))
+                sk.listen(world + 8)
+                self.sock, self.port = sk, port
+                break
+            except OSError as ex:
+                err = ex
+                sk.close()
+        if self.sock is None:
+            raise RuntimeError(f"rendezvous: no free port in {first_port}..{first_port + _PORT_SPAN - 1} on {host!r}: {err}")
+        self.thread = threading.Thread(target=self._accept, name="commet-rdzv", daemon=True)
+        self.thread.start()
+
+    def _accept(self):
+        import threading
+        while True:
+            try:
+                conn, _ = self.sock.accept()
+            except OSError:
+                return                                           # closed
+            threading.Thread(target=self._serve, args=(conn,), daemon=True).start()
+
+    def _serve(self, conn):
+        import socket
+        import struct
+        rank, said_bye = None, False
+        try:
+            conn.settimeout(5.0)
+            hello = _recv_exact(conn, len(_MAGIC) + 32 + 4)
+            (r,) = struct.unpack("<I", hello[-4:])
+            with self.cv:
+                ok = (hello[:len(_MAGIC)] == _MAGIC and hello[len(_MAGIC):-4] == self.token and r < self.world
+                      and r not in self.seen and self.lost is None)
+                if ok:
+                    self.seen.add(r)
+                    rank = r
+            conn.sendall(b"OK" if ok else b"NO")
+            if not ok:
+                return
+            conn.settimeout(None)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            while True:
+                parts = _recv_frame(conn)
+                op = parts[0]
+                if op == b"SET":
+                    with self.cv:
+                        self.kv[parts[1]] = parts[2]
+                        self.cv.notify_all()
+                    _send_frame(conn, b"OK")
+                elif op == b"GET":
+                    with self.cv:
+                        while parts[1] not in self.kv and self.lost is None:
+                            self.cv.wait()
+                        if parts[1] in self.kv:
+                            _send_frame(conn, b"OK", self.kv[parts[1]])
+                        else:
+                            _send_frame(conn, b"LOST", str(self.lost).encode())
+                elif op == b"DEL":
+                    with self.cv:
+                        for key in [x for x in self.kv if x.startswith(parts[1])]:
+                            del self.kv[key]
+                    _send_frame(conn, b"OK")
+                elif op == b"BYE":
+                    said_bye = True
+                    with self.cv:
+                        self.byes += 1
+                        self.cv.notify_all()
+                    _send_frame(conn, b"OK")
+                    return
+        except (OSError, ConnectionError, struct.error):
+            pass
+        finally:
+            if rank is not None and not said_bye:
+                with self.cv:
+                    if self.lost is None:
+                        self.lost = rank
+                    self.cv.notify_all()
+                try:
+                    self.sock.close()                            # a job that lost a rank takes no new connection
+                except OSError:
+                    pass
+            try:
+                conn.close()
+            except OSError:
+                pass
+
+    def wait_byes(self, seconds):
+        import time
+        deadline = time.monotonic() + seconds
+        with self.cv:
+            while self.byes < self.world and self.lost is None and time.monotonic() < deadline:
+                self.cv.wait(0.1)
+        try:
+            self.sock.close()
+        except OSError:
+            pass
+
+
+class Ranks:
+    """Barrier / gather / MAX / SUM over the ranks of a job (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the
+    environment, as torch.distributed.run and bench.py's own launcher set them).  world_size 1 needs nothing.
+    backend: "tcp" (default: standard library only, see above) or "gloo" (torch.distributed); None reads
+    COMMET_RANKS_BACKEND."""
+
+    def __init__(self, backend=None):
         import os
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = backend or os.environ.get("COMMET_RANKS_BACKEND", "tcp")
+        if self.backend not in ("tcp", "gloo"):
+            raise ValueError(f"unknown ranks backend {self.backend!r} (tcp or gloo)")
+        self.timeout_s = float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))   # a rank that dies must not leave the others waiting for long
         self.dist = None
-        if self.world > 1:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                import datetime
-                # a rank that dies must not leave the others waiting for long (default 30 min)
-                tmo = datetime.timedelta(seconds=float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600")))
-                # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): keep them out of a
-                # caller's result stream (bench.py prints one JSON line there) by lending fd 1 to stderr meanwhile
-                import sys
+        self._sock, self._store, self._seq = None, None, 0
+        if self.world > 1 and self.backend == "gloo":
+            self._init_gloo()
+        elif self.world > 1:
+            self._init_tcp()
+
+    # -- gloo ----------------------------------------------------------------------------------------------------
+    def _init_gloo(self):
+        import os
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            import datetime
+            tmo = datetime.timedelta(seconds=self.timeout_s)
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): keep them out of a
+            # caller's result stream (bench.py prints one JSON line there) by lending fd 1 to stderr meanwhile
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world, timeout=tmo)
+                dist.barrier()          # the connections are made (and announced) at the first collective
+            finally:
                 sys.stdout.flush()
-                saved = os.dup(1)
+                os.dup2(saved, 1)
+                os.close(saved)
+        self.dist = dist
+
+    # -- tcp -----------------------------------------------------------------------------------------------------
+    def _init_tcp(self):
+        import os
+        import socket
+        import struct
+        import threading
+        import time
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        first = int(os.environ.get("MASTER_PORT", "29500")) + 1
+        token = _rdzv_token()
+        self._lock = threading.Lock()
+        if self.rank == 0:
+            local = addr in ("127.0.0.1", "localhost", "::1")
+            self._store = _Store(self.world, token, "127.0.0.1" if local else "", first)
+        deadline = time.monotonic() + self.timeout_s
+        hello = _MAGIC + token + struct.pack("<I", self.rank)
+        ports = [self._store.port] if self._store else list(range(first, first + _PORT_SPAN))
+        host = "127.0.0.1" if self._store else addr
+        while self._sock is None:
+            for port in ports:
+                sk = None
                 try:
-                    os.dup2(2, 1)
-                    dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, timeout=tmo)
-                    dist.barrier()          # the connections are made (and announced) at the first collective
-                finally:
-                    sys.stdout.flush()
-                    os.dup2(saved, 1)
-                    os.close(saved)
-            self.dist = dist
+                    sk = socket.create_connection((host, port), timeout=2.0)
+                    sk.sendall(hello)
+                    if _recv_exact(sk, 2) == b"OK":
+                        sk.settimeout(self.timeout_s)
+                        sk.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._sock = sk
+                        break
+                    sk.close()
+                except (OSError, ConnectionError):
+                    if sk is not None:
+                        sk.close()
+            if self._sock is None:
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f"rendezvous: rank {self.rank} found no store of this job on {host}:{first}..{first + _PORT_SPAN - 1}")
+                time.sleep(0.02)
+        self.barrier()
+
+    def _call(self, *parts):
+        with self._lock:
+            try:
+                _send_frame(self._sock, *parts)
+                rep = _recv_frame(self._sock)
+            except (OSError, ConnectionError) as ex:
+                raise RuntimeError(f"rendezvous: rank {self.rank} lost the store ({type(ex).__name__}: {ex}); a peer has died or "
+                                   f"nothing arrived within {self.timeout_s:.0f} s") from None
+        if rep[0] == b"LOST":
+            raise RuntimeError(f"rendezvous: rank {rep[1].decode()} left the job without saying goodbye")
+        return rep
+
+    def _dumps(self, obj):
+        import hashlib
+        import hmac
+        import pickle
+        body = pickle.dumps(obj, protocol=4)
+        return hmac.new(_rdzv_token(), body, hashlib.sha256).digest() + body
+
+    def _loads(self, blob):
+        import hashlib
+        import hmac
+        import pickle
+        if not hmac.compare_digest(blob[:32], hmac.new(_rdzv_token(), blob[32:], hashlib.sha256).digest()):
+            raise RuntimeError("rendezvous: a value in the store was not written by a rank of this job")
+        return pickle.loads(blob[32:])
+
+    def _gather_tcp(self, obj):
+        seq = self._seq
+        self._seq += 1
+        self._call(b"SET", b"g%d/%d" % (seq, self.rank), self._dumps(obj))
+        out = [self._loads(self._call(b"GET", b"g%d/%d" % (seq, r))[1]) for r in range(self.world)]
+        # whoever is in round `seq` proves that every rank has left round seq - 1 (it has written its value of this round),
+        # i.e. has read everything of round seq - 1... but may still be reading it: round seq - 2 is safe to drop
+        if self.rank == 0 and seq >= 2:
+            self._call(b"DEL", b"g%d/" % (seq - 2))
+        return out
+
+    # -- the operations --------------------------------------------------------------------------------------------
+    def gather_objects(self, obj):
+        if self.world == 1:
+            return [obj]
+        if self.dist is not None:
+            out = [None] * self.world
+            self.dist.all_gather_object(out, obj)
+            return out
+        return self._gather_tcp(obj)
 
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
+        elif self.world > 1:
+            self._gather_tcp(None)
 
     def max_seconds(self, seconds):
-        if self.dist is None:
+        if self.world == 1:
             return float(seconds)
-        import torch
-        t = torch.tensor([float(seconds)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
+        if self.dist is not None:
+            import torch
+            t = torch.tensor([float(seconds)], dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t[0])
+        return max(float(x) for x in self._gather_tcp(float(seconds)))
 
     def sum_int(self, v):
-        if self.dist is None:
+        if self.world == 1:
             return int(v)
-        import torch
-        t = torch.tensor([int(v)], dtype=torch.int64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return int(t[0])
+        if self.dist is not None:
+            import torch
+            t = torch.tensor([int(v)], dtype=torch.int64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            return int(t[0])
+        return sum(int(x) for x in self._gather_tcp(int(v)))
 
     def broadcast_object(self, obj, src=0):
-        if self.dist is None:
+        if self.world == 1:
             return obj
-        box = [obj if self.rank == src else None]
-        self.dist.broadcast_object_list(box, src=src)
-        return box[0]
-
-    def gather_objects(self, obj):
-        if self.dist is None:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
+        if self.dist is not None:
+            box = [obj if self.rank == src else None]
+            self.dist.broadcast_object_list(box, src=src)
+            return box[0]
+        return self._gather_tcp(obj if self.rank == src else None)[src]
 
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
             self.dist = None
+        elif self._sock is not None:
+            self.barrier()
+            try:
+                self._call(b"BYE")
+            except RuntimeError:
+                pass
+            self._sock.close()
+            self._sock = None
+            if self._store is not None:                          # rank 0 stays until every rank has said goodbye
+                self._store.wait_byes(30.0)
+                self._store = None
+
+
+def spawn_ranks(n, argv, env=None):
+    """Starts the n ranks of a job on this node as plain child processes of a parent that never touches the GPU — RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT and a job token in their environment — and waits
+    for them.  A rank that ends non-zero ends the job: the others are terminated (by their process ids) and its code is
+    returned; otherwise 0.  The children inherit stdout / stderr."""
+    import os
+    import secrets
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as sk:                      # a free port (the store takes the ones after it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), COMMET_RDZV_TOKEN=secrets.token_hex(16),
+                LOCAL_WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", "1")
+    procs = [subprocess.Popen(argv, env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    for q in live:                   # the job is over: end the other ranks (exact pids)
+                        q.terminate()
+            time.sleep(0.02)
+    finally:
+        deadline = time.monotonic() + 10.0
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
 
 
 def timed_region(ranks, sync, fn, steps):

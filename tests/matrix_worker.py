@@ -24,6 +24,8 @@ def main():
         os._exit(1)                 # what commet_amd.matrix.main does
     if res is not None:
         res.pop("rank0_profile")
+        for r in res["per_rank"]:
+            r.setdefault("backend", None)
         json.dump(res, open(os.path.join(out, "result.json"), "w"))
 
 

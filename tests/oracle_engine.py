@@ -1,6 +1,6 @@
 """A CPU engine for commet_amd.matrix.run built on the CPU checker (oracle/), so that the multi-rank HOST logic of the
 N x N driver (pair runs, one parse per set, packed images handed between ranks, gathers, failure handling) can run
-under gloo without a GPU.  TEST INFRASTRUCTURE ONLY: the package itself has one engine, HipEngine."""
+under several processes without a GPU.  TEST INFRASTRUCTURE ONLY: the package itself has one engine, HipEngine."""
 import os
 import pickle
 import shutil
@@ -49,6 +49,16 @@ class OracleEngine:
 
     def import_set(self, blob):
         return pickle.loads(blob)
+
+    # the driver's canary (a fresh child process that imports the first real set before a rank does): tests choose its fate
+    canary = os.environ.get("COMMET_TEST_CANARY")     # None: no canary command; "ok" / "fail" / "hang"
+
+    def __getattr__(self, name):
+        if name == "canary_argv" and OracleEngine.canary:
+            import sys
+            code = {"ok": "import sys; sys.exit(0)", "fail": "import sys; sys.exit(1)", "hang": "import time; time.sleep(600)"}[OracleEngine.canary]
+            return lambda scratch, candidates: [sys.executable, "-c", code]
+        raise AttributeError(name)
 
     def file_reads(self, rs):
         return list(rs["counts"])

@@ -1,5 +1,6 @@
-"""The N>1 host logic on CPU: world_size-2 gloo processes share out the pair chains of the
-N x N matrix, meet only at barriers, and agree on the MAX elapsed time."""
+"""The N>1 host logic on CPU: world_size-2 (and 8) processes share out the pair chains of the
+N x N matrix, meet only at barriers, and agree on the MAX elapsed time — over the default
+backend (sharding's TCP store: no torch in a rank process) and over gloo."""
 import json
 import os
 import re
@@ -88,32 +89,57 @@ def _matrix_case(tmp_path):
     return k, t, names, files, bvs
 
 
-def _launch(world, args, cwd, timeout=600, extra_env=None):
-    port = 29500 + (os.getpid() * 7 + world) % 2000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(port)] + args
+def _launch(world, args, cwd, timeout=600, extra_env=None, launcher="torchrun"):
+    """launcher: "torchrun" (the driver's form: python -m torch.distributed.run ...) or "spawn" (sharding.spawn_ranks, what
+    `bench.py --gpus N` and `python -m commet_amd.matrix --gpus N` do themselves: plain child processes)"""
     env = dict(os.environ, OMP_NUM_THREADS="1", COMMET_SCRATCH=str(cwd), COMMET_DIST_TIMEOUT_S="120", **(extra_env or {}))
+    if launcher == "spawn":
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); from commet_amd import sharding; "
+                f"sys.exit(sharding.spawn_ranks({world}, [sys.executable] + {args!r}))")
+        cmd = [sys.executable, "-c", code]
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    else:
+        port = 29500 + (os.getpid() * 7 + world) % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=cwd, timeout=timeout)
 
 
-@pytest.mark.parametrize("world,handover", [(2, "ipc"), (2, "image"), (8, "ipc"), (2, "default")])
-def test_matrix_driver_host_logic_over_gloo_ranks(tmp_path, world, handover):
-    """The N x N driver over `world` processes (gloo; the CPU checker stands in for the GPU engine): every set is parsed
-    by exactly one rank, the others take it from its owner — device to device through an exported descriptor ("ipc": the
-    engine's export / import, probed between the ranks first: COMMET_MATRIX_IPC=1) or as a packed image in the scratch directory
-    ("image": COMMET_MATRIX_IPC=0, and what the driver does when nothing is said: "default"); outputs equal Commet.py's job
-    sequence run in one process."""
+@pytest.mark.parametrize("world,handover,backend,launcher", [
+    (2, "default", "tcp", "torchrun"), (2, "default", "tcp", "spawn"), (8, "default", "tcp", "spawn"), (2, "image", "tcp", "spawn"),
+    (2, "canary-fail", "tcp", "spawn"), (2, "canary-hang", "tcp", "torchrun"), (2, "canary-ok", "tcp", "spawn"),
+    (2, "default", "gloo", "torchrun"), (2, "image", "gloo", "torchrun"), (8, "default", "gloo", "torchrun")])
+def test_matrix_driver_host_logic_over_ranks(tmp_path, world, handover, backend, launcher):
+    """The N x N driver over `world` processes (the CPU checker stands in for the GPU engine): every set is parsed by exactly
+    one rank, the others take it from its owner — device to device through an exported descriptor (the default: the engine's
+    export / import, probed between the ranks first) or as a packed image in the scratch directory (COMMET_MATRIX_IPC=0;
+    and, rank by rank, when the CANARY — the fresh child process that imports the first real set before any rank does —
+    fails or hangs: the importers then ask the owners for images); outputs equal Commet.py's job sequence run in one process.
+    Ranks over the default backend (TCP store of rank 0; no torch in the rank processes) and over gloo, started by
+    torch.distributed.run (the driver's form) and by sharding.spawn_ranks (plain child processes)."""
     import json
     import oracle_binding as ob
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden import commet_jobs
     k, t, names, files, bvs = _matrix_case(tmp_path)
+    env = {"COMMET_RANKS_BACKEND": backend}
+    if handover == "image":
+        env["COMMET_MATRIX_IPC"] = "0"
+    if handover.startswith("canary-"):
+        env.update(COMMET_TEST_CANARY=handover[7:], COMMET_IPC_CANARY_S="3")
     p = _launch(world, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t)], str(tmp_path),
-                extra_env={} if handover == "default" else {"COMMET_MATRIX_IPC": "1" if handover == "ipc" else "0"})
+                extra_env=env, launcher=launcher)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     res = json.load(open(tmp_path / "out" / "result.json"))
     assert res["world"] == world and len(res["per_rank"]) == world
-    assert {r["handover"] for r in res["per_rank"]} == {"image" if handover == "default" else handover}
+    # what every rank ended up with: a rank that takes no set from another never meets the canary's verdict
+    takers = [r for r in res["per_rank"] if r["sets_loaded"] > 0]
+    assert takers
+    assert {r["handover"] for r in takers} == ({"image"} if handover in ("image", "canary-fail", "canary-hang") else {"ipc"})
+    if handover.startswith("canary-"):
+        verdicts = {r.get("ipc_canary") for r in takers}
+        assert len(verdicts) == 1 and next(iter(verdicts)).startswith({"ok": "passed", "fail": "failed (exit code 1)", "hang": "failed (no answer"}[handover[7:]])
+    assert all(r["backend"] == backend and r["torch_loaded"] == (backend == "gloo") for r in res["per_rank"])
     assert sum(r["sets_parsed"] for r in res["per_rank"]) == len(names)          # one parse per set on the node
     assert sum(r["pairs"] for r in res["per_rank"]) == 10
     assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + world
@@ -150,21 +176,58 @@ def test_matrix_driver_host_logic_over_gloo_ranks(tmp_path, world, handover):
     assert checked == 6 * 4          # 6 files, each searched in the 4 other sets
 
 
-def test_matrix_driver_failing_rank_ends_the_group(tmp_path):
+@pytest.mark.parametrize("launcher,backend", [("torchrun", "tcp"), ("spawn", "tcp"), ("torchrun", "gloo")])
+def test_matrix_driver_failing_rank_ends_the_group(tmp_path, launcher, backend):
     """rank 1 raises while parsing: the launcher must come back non-zero within seconds, not after a barrier timeout"""
     import time
     k, t, names, files, bvs = _matrix_case(tmp_path)
     t0 = time.time()
-    p = _launch(2, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t), "1"], str(tmp_path), timeout=300)
+    p = _launch(2, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t), "1"], str(tmp_path), timeout=300,
+                launcher=launcher, extra_env={"COMMET_RANKS_BACKEND": backend})
     assert p.returncode != 0
     assert b"injected failure while parsing" in p.stdout
     assert time.time() - t0 < 90
 
 
+def test_store_tells_the_ranks_when_one_of_them_is_gone(tmp_path):
+    """no launcher to end the group: three ranks started by hand, rank 2 leaves without a word while the others wait at a
+    barrier — the store answers their wait with an error at once (not after COMMET_DIST_TIMEOUT_S)"""
+    import time
+    code = (f"import os, sys; sys.path.insert(0, {ROOT!r}); from commet_amd import sharding\n"
+            "r = sharding.Ranks()\n"
+            "if r.rank == 2: os._exit(0)\n"
+            "try:\n    r.barrier(); r.barrier()\nexcept RuntimeError as ex:\n    print('RANK', r.rank, ex); sys.exit(7)\n")
+    env = dict(os.environ, WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31000 + os.getpid() % 2000), COMMET_DIST_TIMEOUT_S="120")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=100)[0] for p in procs]
+    assert [p.returncode for p in procs] == [7, 7, 0], outs
+    assert "rank 2 left the job" in outs[0]
+    assert "rank 2 left the job" in outs[1] or "lost the store" in outs[1]      # (rank 0, and its store, may be gone first)
+    assert time.time() - t0 < 60
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "spawn"])
+def test_two_ranks_default_backend_has_no_torch(tmp_path, launcher):
+    """the default backend of sharding.Ranks: the same protocol as test_two_ranks_gloo, and `torch` is not in a rank's sys.modules
+    (a rank process that holds torch's ROCm runtime beside the system's was what hung commet_readset_import in round 3)"""
+    p = _launch(2, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "6"], str(tmp_path), timeout=300, launcher=launcher)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    r1 = json.load(open(tmp_path / "rank1.json"))
+    assert r0["backend"] == r1["backend"] == "tcp" and r0["torch_loaded"] is False and r1["torch_loaded"] is False
+    assert sorted(r0["mine"] + r1["mine"]) == list(range(15))
+    assert r0["everyone"] == r1["everyone"] == [r0["mine"], r1["mine"]]
+    assert r0["total_jobs"] == r1["total_jobs"] == 15 * 3 * 2
+    assert r0["elapsed"] == r1["elapsed"] >= 0.19
+    assert r0["first"] == r1["first"] == "from rank 1"
+
+
 def test_two_ranks_gloo(tmp_path):
     port = 29500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "6"]
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "6", "gloo"]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
@@ -175,6 +238,7 @@ def test_two_ranks_gloo(tmp_path):
     assert r0["everyone"] == r1["everyone"] == [r0["mine"], r1["mine"]]
     assert r0["total_jobs"] == r1["total_jobs"] == 15 * 3 * 2            # 3 jobs per chain, 2 steps
     assert r0["elapsed"] == r1["elapsed"] >= 0.19                        # MAX over ranks: rank 1 sleeps 2 x 0.1 s
+    assert r0["backend"] == "gloo" and r0["torch_loaded"] is True and r0["first"] == r1["first"] == "from rank 1"
 
 
 def test_bench_json_contract_fields():
@@ -258,6 +322,7 @@ def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["self_launched"] is True
+    assert out["ranks_backend"] == "tcp" and out["torch_in_ranks"] is False   # plain child processes, no torch in any of them
     assert out["devices"] == [0, 1]                       # one rank per GPU: rank r works on device LOCAL_RANK = r
     assert out["ms_per_step"] >= 20.0                     # MAX over the ranks (rank 1 sleeps 20 ms per step)
 
@@ -269,4 +334,6 @@ def test_bench_under_a_launcher_does_not_launch_again(tmp_path):
                        cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.split("\n") if ln.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    out = json.loads(lines[0])
+    assert len(lines) == 1 and out["n_gpus"] == 2 and out["self_launched"] is False
+    assert out["ranks_backend"] == "tcp" and out["torch_in_ranks"] is False   # the launcher holds torch, the ranks do not

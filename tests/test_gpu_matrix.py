@@ -113,21 +113,32 @@ def test_matrix_driver_matches_oracle_on_synthetic_sets(tmp_path, monkeypatch):
                 assert res["matrix"][a][b] == int(tot)
 
 
-@pytest.mark.parametrize("world,handover", [(2, "ipc"), (4, "ipc"), (2, "image")])
-def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world, handover):
-    """N > 1: `world` processes (torch.distributed.run, gloo) take contiguous runs of the pair list, every set is
-    parsed by one rank only and reaches the others device to device (commet_readset_export / _import: HIP IPC handles of
-    the owner's buffers) or, with COMMET_MATRIX_IPC=0, as a packed image (commet_readset_save / _load); the ranks write
-    their .bv files side by side and rank 0 assembles the matrices.  All ranks use GPU 0 here (COMMET_FORCE_DEVICE);
-    outputs must equal Commet.py's."""
+@pytest.mark.parametrize("world,handover,launcher", [(2, "ipc", "torchrun"), (4, "ipc", "spawn"), (2, "image", "spawn"), (2, "canary-killed", "spawn")])
+def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world, handover, launcher):
+    """N > 1: `world` processes — started by torch.distributed.run (the driver's form) or by `python -m commet_amd.matrix
+    --gpus N` itself (plain child processes); no torch in any rank — take contiguous runs of the pair list, every set is parsed by
+    one rank only and reaches the others device to device (the default: commet_readset_export / _import, HIP IPC handles of the
+    owner's buffers, the first real set through a fresh canary process first) or as a packed image (COMMET_MATRIX_IPC=0:
+    commet_readset_save / _load; "canary-killed": the canary is given no time, so every taker asks the owners for images in
+    mid-run); the ranks write their .bv files side by side and rank 0 assembles the matrices.  All ranks use GPU 0 here
+    (COMMET_FORCE_DEVICE); outputs must equal Commet.py's."""
     import subprocess
     gold = os.path.join(GOLD, "abcde", "commet_py", "five_sets")
     monkeypatch.chdir(abcde)
     open("sets.txt", "w").write(open(os.path.join(gold, "sets.txt")).read())
-    env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT, COMMET_MATRIX_IPC="1" if handover == "ipc" else "0",
-               COMMET_MATRIX_REPORT="report.json")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + (os.getpid() + world) % 300), "-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
+    env = dict(os.environ, COMMET_FORCE_DEVICE="0", PYTHONPATH=ROOT, COMMET_MATRIX_REPORT="report.json")
+    env.pop("COMMET_MATRIX_IPC", None)
+    if handover == "image":
+        env["COMMET_MATRIX_IPC"] = "0"
+    if handover == "canary-killed":
+        env["COMMET_IPC_CANARY_S"] = "0.001"
+    args = ["-m", "commet_amd.matrix", "sets.txt", "-k", "32", "-t", "2", "-o", "out2/"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(29600 + (os.getpid() + world) % 300)] + args
+    else:
+        cmd = [sys.executable] + args + ["--gpus", str(world)]
+        env = {k_: v for k_, v in env.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
     for f in sorted(os.listdir(gold)):
@@ -135,7 +146,14 @@ def test_matrix_driver_ranks_share_the_pairs(abcde, monkeypatch, world, handover
             assert open(os.path.join("out2", f), "rb").read() == open(os.path.join(gold, f), "rb").read(), f
     import json
     rep = json.load(open("report.json"))
-    assert {r["handover"] for r in rep["per_rank"]} == {handover}                   # (the probe between the ranks passed)
+    takers = [r for r in rep["per_rank"] if r["sets_loaded"] > 0]
+    assert takers and {r["handover"] for r in takers} == {"ipc" if handover == "ipc" else "image"}   # (the probe between the ranks passed)
+    if handover == "ipc":
+        assert {r["ipc_canary"] for r in takers} == {"passed"}
+    if handover == "canary-killed":
+        assert all(r["ipc_canary"].startswith("failed (no answer") for r in takers)
+        assert sum(r["save_s"] > 0 for r in rep["per_rank"]) > 0                                    # owners wrote images on request
+    assert all(r["backend"] == "tcp" and r["torch_loaded"] is False for r in rep["per_rank"])
     assert sum(r["sets_parsed"] for r in rep["per_rank"]) == 5 and sum(r["sets_loaded"] for r in rep["per_rank"]) > 0
     os.remove("report.json")
 
