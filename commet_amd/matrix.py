@@ -236,10 +236,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         l = k * t
     # ---- filter step (Commet.py:103-121): one filter_reads per file, dealt over the ranks -------------
     t_filter = time.perf_counter()
+    filter_err = []
     if bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
-        cmds, cmd_set = [], []
+        cmds = []
         for q, (s, j) in enumerate(todo):
             if q % world != rank:
                 continue
@@ -251,29 +252,42 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             cmd += ["-o", bvs[s][j]]
             say("Filtering command: " + " ".join(cmd))
             cmds.append(cmd)
-            cmd_set.append(s)
         # independent processes (each one multi-threaded over its file), a few at a time — and beside the parsing of
-        # the sets below: nothing reads a filter's .bv before the sets are resident
+        # the sets below.  A filter's .bv is written under another name and renamed into place, so the file appears complete
+        # or not at all: whoever needs set s (any rank) waits for ITS files only (`prepare`), not for every filter of the node.
         from concurrent.futures import ThreadPoolExecutor
+        for c in cmds:                                             # what an earlier run left in this directory must not be read as this run's
+            for stale in (c[-1], c[-1] + ".part"):
+                try:
+                    os.remove(stale)
+                except OSError:
+                    pass
+        ranks.barrier()                                            # (every rank's stale files are gone before anybody looks for new ones)
+
+        def run_filter(cmd):
+            subprocess.run(cmd[:-1] + [cmd[-1] + ".part"], check=True, stdout=subprocess.DEVNULL)
+            os.rename(cmd[-1] + ".part", cmd[-1])
+
         filter_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("COMMET_FILTER_JOBS", "3")))
         # (the sets are loaded last set first, see below: so are their filters)
-        filter_jobs = [filter_pool.submit(subprocess.run, c, check=True, stdout=subprocess.DEVNULL) for c in reversed(cmds)]
+        filter_jobs = [filter_pool.submit(run_filter, c) for c in reversed(cmds)]
         filter_end = [t_filter]
-        for j in filter_jobs:                                      # when the last of them was done
-            j.add_done_callback(lambda _f: filter_end.__setitem__(0, max(filter_end[0], time.perf_counter())))
-        filter_set = list(reversed(cmd_set))
+
+        def filter_over(f):
+            filter_end[0] = max(filter_end[0], time.perf_counter())   # when the last of them was done
+            if not f.cancelled() and f.exception() is not None:
+                filter_err.append(f.exception())                   # whoever waits for a set (here) is told at once
+
+        for j in filter_jobs:
+            j.add_done_callback(filter_over)
+        filtered_here = True
     else:
-        filter_pool, filter_jobs, filter_set = None, [], []
+        filter_pool, filter_jobs = None, []
+        filtered_here = False
     filter_s = 0.0
 
-    def filter_done_for(s):
-        """set s's filter files are written (single rank: this process started them all)"""
-        for j, fs in zip(filter_jobs, filter_set):
-            if fs == s:
-                j.result()
-
     def filters_done():
-        """every rank's filter files are written (raises what a filter_reads process raised)"""
+        """this rank's filter processes are through (raises what a filter_reads process raised)"""
         nonlocal filter_s
         if filter_pool is not None:
             try:
@@ -282,7 +296,6 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             finally:
                 filter_pool.shutdown(wait=True)
             filter_s = (filter_end[0] if filter_jobs else time.perf_counter()) - t_filter
-            ranks.barrier()
 
     # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
     pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
@@ -421,30 +434,39 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 if s in needed or s in needed_by_others:
                     parse_own(s)
             ranks.barrier()                                      # every image is in place
-        counts, sel, considered_mine = {}, {}, {}
+        counts, sel, considered = {}, {}, {}
 
         def prepare(s):
-            """set s is resident and filtered: its per-file read counts and its input selection"""
+            """set s is resident; once its filter files are there (written by whichever rank filtered them): its per-file read
+            counts, its input selection, the number of reads it was asked about (the matrix's diagonal)"""
             counts[s] = eng.file_reads(sets[s])
+            if filtered_here:
+                for b in bvs[s]:
+                    if not wait_file(b, f"the filter of set {s}", where=os.path.dirname(b)):
+                        return False
             parts = [read_bv(b) for b in bvs[s]]
+            considered[s] = sum(popcount(b, nb) for nb, b in parts)
             for (nb, _), c, f in zip(parts, counts[s], files[s]):
                 if nb != c:
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
+            return True
 
         stop_ev = threading.Event()                               # set when this rank is through (or has failed): ends every wait below
         hand = dict(ipc=use_ipc, canary=None)
 
-        def wait_file(path, what):
+        def wait_file(path, what, where=None):
             """a file another rank publishes (renamed into place: complete or absent): there once its owner has got that far
             (or never, if that rank died: the launcher then ends this process; the deadline only bounds a stray wait)"""
             deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
             w0 = time.perf_counter()
             while not os.path.exists(path):
+                if filter_err:
+                    raise filter_err[0]
                 if stop_ev.is_set():
                     return False
                 if time.perf_counter() > deadline:
-                    raise RuntimeError(f"{what} did not appear in {scratch}")
+                    raise RuntimeError(f"{what} did not appear in {where or scratch}")
                 time.sleep(0.002)
             prof["image_wait_s"] = prof.get("image_wait_s", 0.0) + time.perf_counter() - w0
             return True
@@ -527,25 +549,13 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             server = threading.Thread(target=serve_images, name="commet-image-server", daemon=True)
             server.start()
 
-        def diagonal():
-            """reads every set was asked about (its filters' popcount): each set once, by its parser; known to all ranks"""
-            for s in range(N):
-                if s % world == rank:
-                    considered_mine[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
-            got = {}
-            for d in ranks.gather_objects(considered_mine):
-                got.update(d)
-            return [got[s] for s in range(N)]
-
         refs = sorted({p[0] for p in mine}, reverse=pipelined)    # pipelined: last reference set first
         if not pipelined:
             for s in needed:
                 if s not in sets:
                     fetch(s)                                      # (its owner's descriptor / image is in place behind the barrier)
-            filters_done()
             for s in needed:
                 prepare(s)
-            considered = diagonal()
             load_s = time.perf_counter() - t0
             say(f"loaded {N} sets in {load_s:.2f} s (rank 0: {prof['sets_parsed']} parsed, {prof['sets_loaded']} from packed images)")
         else:
@@ -558,10 +568,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             loader_stop = stop_ev
             load_err = []
             load_end = [t0]
-            filters_ready = threading.Event()
             if solo:
                 order = list(range(N - 1, -1, -1))
-                considered = [0] * N
                 own_first = []
             else:
                 order = []
@@ -590,15 +598,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             sets[s] = eng.parse(files[s])
                             prof["parse_s"] += time.perf_counter() - w0
                             prof["sets_parsed"] += 1
-                            filter_done_for(s)
-                            considered[s] = sum(popcount(b, nb) for nb, b in (read_bv(p) for p in bvs[s]))
-                        else:
-                            if s not in sets and not fetch(s):
-                                break
-                            while not filters_ready.wait(0.05):  # every rank's filter files are written (the job thread says so)
-                                if loader_stop.is_set():
-                                    return
-                        prepare(s)
+                        elif s not in sets and not fetch(s):
+                            break
+                        if not prepare(s):
+                            break
                         ready[s].set()
                         note(f"set {s} resident")
                 except BaseException as ex:          # handed to the job thread, which is waiting for a set
@@ -610,22 +613,14 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
             loader = threading.Thread(target=load_all, name="commet-set-loader", daemon=True)
             loader.start()
-            if not solo:
-                # the collectives stay on this thread: the filters of all ranks (they ran beside the parsing), the diagonal
-                try:
-                    filters_done()
-                    considered = diagonal()
-                    filters_ready.set()
-                except BaseException:
-                    loader_stop.set()
-                    raise
-
         set_wait = [0.0]
 
         def wait_for(s):
             if loader is not None:
                 w0 = time.perf_counter()
-                ready[s].wait()
+                while not ready[s].wait(0.05):
+                    if filter_err:                               # a filter_reads process of this rank failed
+                        raise filter_err[0]
                 set_wait[0] += time.perf_counter() - w0
                 if load_err:
                     raise load_err[0]
@@ -675,24 +670,26 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             for s in order:                                      # (one rank: a set no pair needs is still loaded and counted)
                 wait_for(s)
             loader.join()
-            if solo:
-                filters_done()
             load_s = load_end[0] - t0
+        filters_done()                                           # (this rank's filter processes: what one of them raised is raised here)
         # ---- matrices on rank 0 -----------------------------------------------------------------------------
-        everyone = ranks.gather_objects((shared, prof))     # (every rank is through its jobs: nobody asks for a set any more)
+        everyone = ranks.gather_objects((shared, prof, considered))   # (every rank is through its jobs: nobody asks for a set any more)
         if server is not None:
             serve_stop.set()
             server.join()
         result = None
         if rank == 0:
             mat = [[0] * N for _ in range(N)]
-            for d, _ in everyone:
+            diag = {}
+            for d, _, cons in everyone:
+                diag.update(cons)                                # (every set is in some rank's pairs)
                 for (a, b), v in d.items():
                     mat[a][b] = v
+            considered_all = [diag[s] for s in range(N)]
             for s in range(N):
-                mat[s][s] = considered[s]
-            write_matrices(out_dir, names, considered, mat)
-            result = dict(names=names, considered=considered, matrix=mat)
+                mat[s][s] = considered_all[s]
+            write_matrices(out_dir, names, considered_all, mat)
+            result = dict(names=names, considered=considered_all, matrix=mat)
             say("All Commet work is done")
             say("\t Output csv matrices are in:")
             for f in ("matrix_plain.csv", "matrix_percentage.csv", "matrix_normalized.csv"):
@@ -707,7 +704,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             result.update(filter_s=slowest_filter, load_s=slowest_load, filter_overlaps_load=filter_pool is not None,
                           load_overlaps_jobs=pipelined, set_wait_s=prof.get("set_wait_s", 0.0), jobs_s=slowest, total_s=total_s,
                           reads_searched=total_searched, world=world, rank0_profile=prof,
-                          per_rank=[p for _, p in everyone],
+                          per_rank=[p for _, p, _c in everyone],
                           reads_per_s=total_searched / slowest if slowest > 0 else 0.0,
                           reads_per_s_incl_load_and_filter=total_searched / total_s if total_s > 0 else 0.0)
             say(f"{total_searched} reads searched in {slowest:.3f} s of jobs on {world} GPU(s): {result['reads_per_s'] / 1e6:.1f} M reads/s "

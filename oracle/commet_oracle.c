@@ -182,6 +182,11 @@ uint64_t ok_max_kmer(int k)
     return (uint64_t) (1000000000.0 / pow(2, 33 - k));
 }
 
+/* Test hook (no counterpart in the reference): the chunk size of the next ok_index_and_search calls, so that the
+ * checker can be chunked like a library context whose `max_kmer` option is set (many chunks from small sets). */
+static uint64_t g_max_kmer_override = 0;
+void ok_set_max_kmer(uint64_t max_kmer) { g_max_kmer_override = max_kmer; }
+
 /* ======================================================================== */
 /* per-read bodies of index_reads / search_reads                            */
 /* ======================================================================== */
@@ -827,7 +832,7 @@ int ok_index_and_search(const char *index_cfg, const char *search_cfg,
                         ok_set_result *results, int cap, int *n_results,
                         uint64_t *n_chunks, uint64_t *kmers_indexed, int quiet)
 {
-    uint64_t max_kmer = ok_max_kmer(k);
+    uint64_t max_kmer = g_max_kmer_override ? g_max_kmer_override : ok_max_kmer(k);
     ensure_dir(log_dir);
     ensure_dir(out_dir);
 

@@ -60,6 +60,10 @@ int       ok_bloom_is_found(ok_bloom *f, const ok_hash *h); /* bloom_filter.h:12
 /* max_kmer = (unsigned long)(1e9 / 2^(33-k))  (src/index_and_search.cpp:73,146) */
 uint64_t ok_max_kmer(int k);
 
+/* Test hook, no counterpart in the reference: k-mers per chunk of the following ok_index_and_search calls (0: the
+ * reference's constant again) — the twin of the library option `max_kmer`, so that both sides chunk alike. */
+void ok_set_max_kmer(uint64_t max_kmer);
+
 /* ---- batch forms of the two kernels (what the HIP path is compared with) - */
 /* Feeds every complete k-mer of the reads whose select bit is 1 (select ==
  * NULL: all reads) — the body of the while loop of index_reads.h:49-61 without

@@ -41,6 +41,8 @@ def load():
         lib.ok_bloom_free.argtypes = [C.POINTER(OkBloom)]
         lib.ok_max_kmer.restype = C.c_uint64
         lib.ok_max_kmer.argtypes = [C.c_int]
+        lib.ok_set_max_kmer.restype = None
+        lib.ok_set_max_kmer.argtypes = [C.c_uint64]
         lib.ok_index_batch.restype = C.c_uint64
         lib.ok_index_batch.argtypes = [C.POINTER(OkBloom), C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         lib.ok_search_batch.restype = C.c_uint64
@@ -130,15 +132,18 @@ def max_kmer(k):
     return int(load().ok_max_kmer(k))
 
 
-def index_and_search(index_cfg, search_cfg, out_dir, log_dir, k, t):
-    """Runs the restated tool in-process. Returns (rc, results, n_chunks, kmers)."""
+def index_and_search(index_cfg, search_cfg, out_dir, log_dir, k, t, max_kmer=0):
+    """Runs the restated tool in-process. Returns (rc, results, n_chunks, kmers).  max_kmer != 0: k-mers per chunk (the
+    twin of the library's test hook `max_kmer`; 0 = the reference's constant)."""
     lib = load()
+    lib.ok_set_max_kmer(int(max_kmer))
     res = (OkSetResult * 64)()
     n = C.c_int(0)
     chunks = C.c_uint64(0)
     kmers = C.c_uint64(0)
     rc = lib.ok_index_and_search(index_cfg.encode(), search_cfg.encode(), out_dir.encode(), log_dir.encode(), k, t,
                                  res, 64, C.byref(n), C.byref(chunks), C.byref(kmers), 1)
+    lib.ok_set_max_kmer(0)
     out = [dict(name=res[i].search_name.decode(), indexed=int(res[i].indexed), searched=int(res[i].searched),
                 shared=int(res[i].shared), probes=int(res[i].probes)) for i in range(n.value)]
     return rc, out, int(chunks.value), int(kmers.value)

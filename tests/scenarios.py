@@ -86,13 +86,14 @@ def run_tool(tool, scn, out, log, extra_env=None, extra_args=()):
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 
-def run_oracle(scn, out, log):
-    """the CPU checker in-process (paths resolved against the scenario dir)"""
+def run_oracle(scn, out, log, max_kmer=0):
+    """the CPU checker in-process (paths resolved against the scenario dir); max_kmer != 0: chunked like a library context
+    with that `max_kmer` option"""
     import oracle_binding as ob
     cwd = os.getcwd()
     os.chdir(scn.dir)
     try:
-        return ob.index_and_search(scn.index_cfg, scn.search_cfg, out, log, scn.k, scn.t)
+        return ob.index_and_search(scn.index_cfg, scn.search_cfg, out, log, scn.k, scn.t, max_kmer=max_kmer)
     finally:
         os.chdir(cwd)
 

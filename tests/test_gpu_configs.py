@@ -461,3 +461,157 @@ def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
         assert np.array_equal(tags[0], found), name
         assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum())), name
         assert (stats[0]["shared"] > 1500) == (kernel == "search_sliced_kernel"), (name, stats[0]["shared"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[4] AS STATED: k = 21, t = 5, 2 x 20 M x 150 bp reads -> ~10 400 chunk filters of 1 MiB, auto mode
+# ---------------------------------------------------------------------------------------------------------------
+def test_c5_full_size_sample_matches_cpu_checker(tmp_path):
+    """BASELINE configs[4] at full size, on the code path a user gets (auto mode: the probe, then one pass of
+    search_wide_kernel over the rows of ALL chunk filters — the 64-lane, two-pieces-per-lane instantiation).  The CPU
+    checker builds every one of the ~10 400 chunk filters (index_reads.h:49-61 with the reference's max_kmer = 244 140 and
+    the dropped look-ahead reads) in worker processes and runs search_reads (search_reads.h:45-83) of a 10 000-read sample
+    of the query set against each of them; a read's tag is the OR over the chunks (index_and_search.cpp:255-277).  Beside
+    the sample: the log numbers' size-independent relations at full size."""
+    import commet_amd
+    from commet_amd import synth
+    from concurrent.futures import ThreadPoolExecutor
+    k, t, L, n = 21, 5, 150, 20_000_000
+    b0, o0 = synth.synth_set(0, n, L)
+    b1, o1 = synth.synth_set(1, n, L)
+    rng = np.random.default_rng(21)
+    smp = _sample(rng, n, 4000, 6000)
+    sb = np.ascontiguousarray(b1.reshape(n, L)[smp]).reshape(-1)
+    with commet_amd.Context(k=k, t=t) as ctx, ThreadPoolExecutor(1) as cpu:
+        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
+        del o0, o1
+        kc = irs.kmer_counts()
+        chunks = oracle_pool.chunks_from_counts(kc, ob.max_kmer(k))
+        assert ob.max_kmer(k) == 244_140 and 10_000 < len(chunks) < 10_800
+        # the CPU replay runs beside the GPU job
+        replay = cpu.submit(oracle_pool.search_sample_over_chunks, str(tmp_path), "c5full", b0, L, chunks, k, t, sb,
+                            first_chunk=True, sample_len=L)
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        times = ctx.kernel_times()
+        found_cpu, fed, first = replay.result()
+    assert info["n_chunks"] == len(chunks)
+    assert times["search_wide_kernel"][0] == 1 and times["search_sliced_kernel"][0] == 1      # the probe, then ONE wide pass
+    assert fed == [int(kc[a:e].sum()) for a, e in chunks] and info["kmers_indexed"] == sum(fed)
+    found = util.bools_from_bits(tags[0], n)
+    assert np.array_equal(found[smp], found_cpu)
+    assert found_cpu[:4000].sum() > 2000                                   # the sample does contain shared reads ...
+    assert len(np.unique(first[first >= 0])) > 1500                        # ... first found in chunk filters all over the job
+    # log numbers at full size: indexed = every read but the dropped look-ahead ones; shared = the tags' bit count;
+    # searched = the reads the LAST chunk's pass still scans = all but those found before it
+    assert stats[0]["indexed"] == sum(e - a for a, e in chunks) == n - (len(chunks) - 1) - (0 if chunks[-1][1] == n else 1)
+    assert stats[0]["shared"] == int(found.sum())
+    assert n - stats[0]["shared"] <= stats[0]["searched"] <= n
+    last_only = int((first == len(chunks) - 1).sum())                      # sample reads that only the last chunk finds: rare
+    assert stats[0]["searched"] - (n - stats[0]["shared"]) <= max(1, last_only) * (n // len(smp)) * 4 + 4000
+    assert found[: n // 4].mean() > 0.5 and found[n // 4:].mean() < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[3] AS STATED, through the N x N driver: 10 sets x 50 M reads, all 99 jobs' worth on one GPU
+# ---------------------------------------------------------------------------------------------------------------
+C4_N, C4_L, C4_SETS, C4_PAIR = 50_000_000, 100, 10, (2, 6)
+
+
+def _big_scratch(tmp_path_factory, need_bytes):
+    """a directory for `need_bytes` of FASTA files: /dev/shm when it (and the host's memory) holds them with room to spare"""
+    import shutil
+    import tempfile
+    try:
+        free_shm = shutil.disk_usage("/dev/shm").free
+        avail = next(int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:"))
+        if os.access("/dev/shm", os.W_OK) and free_shm > need_bytes * 1.2 and avail > need_bytes + (110 << 30):
+            return tempfile.mkdtemp(prefix="commet_c4m_", dir="/dev/shm"), True
+    except Exception:
+        pass
+    return str(tmp_path_factory.mktemp("c4m")), False
+
+
+@pytest.fixture(scope="module")
+def c4m(tmp_path_factory):
+    """matrix.run on BASELINE configs[3] (the run `bench.py` times as its matrix leg), once for the module; the two sets of
+    the pair that is replayed on the CPU checker are generated here, where their bases are needed"""
+    import multiprocessing as mp
+    import shutil
+    from commet_amd import build, matrix, synth
+    build.build_lib()
+    build.build_tools()
+    d, in_shm = _big_scratch(tmp_path_factory, C4_SETS * C4_N * (C4_L + 12))
+    keep = {}
+    try:
+        with open(os.path.join(d, "sets.txt"), "w") as fh:
+            for s in range(C4_SETS):
+                fh.write(f"S{s}: {d}/set{s}.fa\n")
+        with mp.get_context("spawn").Pool(4) as pool:                       # (a 50 M-read set is ~8 GB of generator state per worker)
+            pending = pool.map_async(util.gen_set_fasta, [(s, C4_N, C4_L, os.path.join(d, f"set{s}.fa")) for s in range(C4_SETS)
+                                                           if s not in C4_PAIR], chunksize=1)
+            for s in C4_PAIR:
+                keep[s], _ = synth.synth_set(s, C4_N, C4_L)
+                synth.write_fasta_fast(os.path.join(d, f"set{s}.fa"), keep[s], C4_N, C4_L)
+            pending.get()
+        res = matrix.run(os.path.join(d, "sets.txt"), os.path.join(d, "out") + "/", k=32, t=2, verbose=False)
+        for s in range(C4_SETS):                                            # 56 GB back before the CPU replays start
+            os.remove(os.path.join(d, f"set{s}.fa"))
+        yield dict(dir=d, res=res, bases=keep)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_c4_matrix_as_the_driver_runs_it(c4m, tmp_path):
+    """The 10 x 50 M matrix as commet_amd.matrix produces it on one GPU — J1 of a reference set built once and shared by its
+    targets (7 chunk filters per pass, search_group8_kernel), J2 / J3 on selection lists, 24 GB of packed sets resident, the
+    sets loaded beside the jobs — against the CPU checker: one pair chain replayed on 20 000-read samples FROM THE DRIVER'S OWN
+    .bv FILES (J2's and J3's outputs; J1's tags, which the driver never writes, recomputed through the API and then proved
+    by J2's replay, whose index selection they are), plus the matrix's invariants."""
+    import commet_amd
+    from concurrent.futures import ThreadPoolExecutor
+    res, N = c4m["res"], C4_SETS
+    m, considered = res["matrix"], res["considered"]
+    n, L, k, t = C4_N, C4_L, 32, 2
+    assert considered == [n] * N and res["world"] == 1
+    assert res["reads_searched"] == 3 * n * N * (N - 1) // 2
+    for i in range(N):
+        for j in range(N):
+            if i != j:
+                assert 0.50 * n / 4 < m[i][j] < 1.05 * n / 4, (i, j, m[i][j])
+    out = os.path.join(c4m["dir"], "out")
+    assert sum(1 for f in os.listdir(out) if "_in_" in f and f.endswith(".bv")) == N * (N - 1)
+    ref, i = C4_PAIR
+    b_ref, b_i = c4m["bases"][ref], c4m["bases"][i]
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        rs_ref = commet_amd.ReadSet.from_files(ctx, [(b_ref, offs)])
+        rs_i = commet_amd.ReadSet.from_files(ctx, [(b_i, offs)])
+        kc_ref, kc_i = rs_ref.kmer_counts(), rs_i.kmer_counts()
+        tags1, st1, inf1 = ctx.index_and_search(rs_ref, [rs_i])          # J1(ref, i) on its own
+    del offs
+    T1 = util.bools_from_bits(tags1[0], n)
+    _, n2, bits2 = util.read_bv(os.path.join(out, f"set{ref}.fa_in_S{i}.bv"))      # J2: S_ref in (S_i restricted to T1)
+    _, n3, bits3 = util.read_bv(os.path.join(out, f"set{i}.fa_in_S{ref}.bv"))      # J3: S_i in (S_ref restricted to T2)
+    T2, T3 = util.bools_from_bits(bits2, n2), util.bools_from_bits(bits3, n3)
+    assert n2 == n3 == n and inf1["n_chunks"] == 7
+    assert T3.sum() == m[i][ref] and T2.sum() == m[ref][i]
+    for (a, b) in [(0, 9), (9, 0), (5, 4)]:
+        _, nn, bits = util.read_bv(os.path.join(out, f"set{a}.fa_in_S{b}.bv"))
+        assert nn == n and int(util.bools_from_bits(bits, nn).sum()) == m[a][b]
+    rng = np.random.default_rng(13)
+    smp_i, smp_ref = _sample(rng, n, 6000, 14000), _sample(rng, n, 6000, 14000)
+    sb_i = np.ascontiguousarray(b_i.reshape(n, L)[smp_i]).reshape(-1)
+    sb_ref = np.ascontiguousarray(b_ref.reshape(n, L)[smp_ref]).reshape(-1)
+    scratch = str(tmp_path)
+    with ThreadPoolExecutor(3) as pool:   # 7 + 2 + 2 chunk filters, each built by a worker process of its own
+        r1 = pool.submit(_replay, scratch, "m1", b_ref, L, None, kc_ref, k, t, sb_i)
+        r2 = pool.submit(_replay, scratch, "m2", b_i, L, T1, kc_i, k, t, sb_ref)      # index set restricted to J1's result
+        r3 = pool.submit(_replay, scratch, "m3", b_ref, L, T2, kc_ref, k, t, sb_i)
+        (f1, nch1), (f2, nch2), (f3, nch3) = r1.result(), r2.result(), r3.result()
+    assert (nch1, nch2, nch3) == (7, 2, 2)
+    assert np.array_equal(T1[smp_i], f1)
+    assert np.array_equal(T2[smp_ref], f2)           # the driver's J2 output (and with it the T1 it really used)
+    assert np.array_equal(T3[smp_i], f3)             # the driver's J3 output
+    assert f1.sum() > 4000 and f2.sum() > 4000 and f3.sum() > 4000

@@ -136,8 +136,9 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
     import commet_amd as commet
     k = [25, 26, 28, 30, 32, 33, 34, 32][seed % 8]          # 33, 34: 64-bit keys (tq_*<uint64_t>)
     scn = Scenario(str(tmp_path / "scn"), 900 + seed, k=k, n_scale=[1.0, 6.0, 20.0][seed % 3])
+    max_kmer = [0, 3000, 900][(seed // 8) % 3]              # more chunks from small sets (test hook; the CPU checker is chunked alike)
     out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
-    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o)
+    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o, max_kmer=max_kmer)
     assert rc == 0
     with commet.Context(k=scn.k, t=scn.t) as ctx:
         irs, isel = _load_set(commet, ctx, scn.sets[scn.index_name], scn.dir)
@@ -147,7 +148,7 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
             srs.append(r)
             ssel.append(s)
         ctx.set_option("tiled_search", 2)
-        ctx.set_option("max_kmer", [0, 3000, 900][(seed // 8) % 3])          # more chunks from small sets (test hook)
+        ctx.set_option("max_kmer", max_kmer)
         ctx.set_option("chunk_group", [2, 1, 3][(seed // 3) % 3])
         got = ctx.index_and_search(irs, srs, isel, ssel)
         ctx.set_option("tiled_search", 1)
@@ -155,18 +156,18 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
         for a, b in zip(got[0], ref[0]):
             assert np.array_equal(a, b)
         assert [(s["indexed"], s["searched"], s["shared"]) for s in got[1]] == [(s["indexed"], s["searched"], s["shared"]) for s in ref[1]]
-        if [0, 3000, 900][(seed // 8) % 3] == 0:                              # the reference's own chunk size: the CPU checker's bits
-            tags, stats, info = got
-            assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
-            by_name = {r["name"]: r for r in res}
-            for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
-                o = by_name[nme]
-                assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
-                pos = 0
-                for fa, _, reads, _ in scn.sets[nme]:
-                    _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
-                    assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
-                    pos += n
+        # every seed against the CPU checker's bits and log numbers (chunked with the same constant)
+        tags, stats, info = got
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        by_name = {r["name"]: r for r in res}
+        for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
+            o = by_name[nme]
+            assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
+            pos = 0
+            for fa, _, reads, _ in scn.sets[nme]:
+                _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
+                pos += n
 
 
 @pytest.mark.parametrize("k,t,chunk_group", [(20, 2, 4), (24, 3, 2), (33, 2, 4), (16, 2, 1)])
