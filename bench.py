@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("-k", type=int, default=32)
     ap.add_argument("-t", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads per set of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also run the reference CPU tool ONCE on the whole job (both full sets, one core; 10-15 minutes at configs[1]) and "
+                         "compare its .bv bytes and log line with the GPU's: cpu_baseline.full_job (off by default: the driver's run stays short)")
     ap.add_argument("--no-probe-count", action="store_true", help="skip the extra (untimed) P_ref counting step")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the extra (untimed) per-kernel timing steps")
     ap.add_argument("--kt-steps", type=int, default=3, help="untimed steps of the per-kernel timing leg")
@@ -139,6 +142,53 @@ def matrix_memory_needed(n_sets, n_reads, read_len, workers):
     return int(fasta + images + workers * n_reads * read_len * 2.5 + (2 << 30))
 
 
+def cpu_full_job(args, b0, b1, gpu_tags, gpu_stats):
+    """--cpu-full: the reference tool (oracle/_ref, else our C restatement) on the WHOLE job, one copy on one core
+    (index_and_search.cpp:252-300: its own clock() around index_reads / search_reads), its .bv bytes and its
+    [indexed, searched, shared] line compared with the GPU's."""
+    import numpy as np
+    from commet_amd import synth
+    n, L = args.reads, args.read_len
+    work = tempfile.mkdtemp(prefix="commet_cpufull_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    try:
+        synth.write_fasta_fast(os.path.join(work, "s0.fa"), b0, n, L)
+        synth.write_fasta_fast(os.path.join(work, "s1.fa"), b1, n, L)
+        open(os.path.join(work, "i.txt"), "w").write(f"s0:{work}/s0.fa\n")
+        open(os.path.join(work, "s.txt"), "w").write(f"s1:{work}/s1.fa\n")
+        ref = os.path.join(ROOT, "oracle", "_ref", "index_and_search")
+        if os.path.exists(ref):
+            kind, tool = "reference", ref
+        else:
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_build/oracle_cli"], check=True)
+            kind, tool = "port", os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+        print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] --cpu-full: {kind} tool on 2 x {n} reads, one core (minutes)", file=sys.stderr, flush=True)
+        t0 = time.time()
+        pr = subprocess.Popen([tool, "-i", os.path.join(work, "i.txt"), "-s", os.path.join(work, "s.txt"), "-o", "out", "-l", "log",
+                               "-k", str(args.k), "-t", str(args.t)], cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        while pr.poll() is None:                      # a line a minute: a long silent run looks hung to whoever watches
+            try:
+                pr.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] --cpu-full: running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+        wall = time.time() - t0
+        if pr.returncode != 0:
+            return {"error": f"the CPU tool left with code {pr.returncode}"}
+        lines = open(os.path.join(work, "log", "s1_in_s0.log")).read().split("\n")
+        hot = float(lines[0].split()[2]) + float(lines[1].split()[2]) if kind == "reference" else wall
+        nums = [int(x) for x in re.findall(r"\d+", lines[3])]
+        data = open(os.path.join(work, "out", "s1.fa_in_s0.bv"), "rb").read()
+        body = data[data.index(b"\n", data.index(b"#")) + 1:]
+        cpu_bits = np.frombuffer(body[: n // 8 + 1], dtype=np.uint8)
+        same = bool(np.array_equal(cpu_bits, np.asarray(gpu_tags[: n // 8 + 1], dtype=np.uint8)))
+        return {"kind": kind, "cores": 1, "reads_per_s": round(n / hot, 1), "index_s": float(lines[0].split()[2]) if kind == "reference" else None,
+                "search_s": float(lines[1].split()[2]) if kind == "reference" else None, "wall_s": round(wall, 1),
+                "log_line": lines[3], "bv_bytes_equal_gpu": same,
+                "log_numbers_equal_gpu": nums == [gpu_stats["indexed"], gpu_stats["searched"], gpu_stats["shared"]],
+                "what": f"the whole job (2 x {n} reads, k={args.k} t={args.t}) on one host core; .bv of the search set byte-compared with the GPU's tags"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cpu_baseline(args, b0, b1):
     """Times the reference CPU path on the first `cpu_sample` reads of both sets (rank 0, N=1 only): one copy alone,
     then one independent copy per host core (P = 1 and P = all, P stated)."""
@@ -198,11 +248,12 @@ def cpu_baseline(args, b0, b1):
 def source_hash():
     """hash of the device-code sources: a traffic.json taken from another version of the kernels is marked stale"""
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "commet_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for sub in ("", "capi"):                      # the kernels and the launch / dispatch code (csrc/host is the HIP-free host side)
+        d = os.path.join(ROOT, "commet_amd", "csrc", sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".hpp")):
+                h.update((sub + "/" + f).encode())
+                h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -394,7 +445,7 @@ def main():
         tags, stats, info = ctx.index_and_search(irs, [qrs])
         for f in acc:
             acc[f] += info[f]
-        last["stats"], last["info"] = stats, info
+        last["stats"], last["info"], last["tags"] = stats, info, tags
 
     progress(ranks, f"sets resident ({n} reads each), {args.warmup} warm-up step(s) done; timing {args.steps} step(s)")
     elapsed = sharding.timed_region(ranks, ctx.synchronize, step, args.steps)
@@ -562,6 +613,12 @@ def main():
                                                                "jobs_s", "set_wait_s", "handover", "imbalance", "predicted_vs_actual_share", "size_note")}
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, b0, b1)
+                if args.cpu_full and out["cpu_baseline"] is not None:
+                    out["cpu_baseline"]["full_job"] = cpu_full_job(args, b0, b1, last["tags"][0], stats[0])
+                    fj = out["cpu_baseline"]["full_job"]
+                    if "error" not in fj:
+                        out["cpu_baseline"]["sample"] += (f"; the WHOLE job once on one core (--cpu-full): {fj['reads_per_s']:.0f} reads/s "
+                                                          f"(index {fj['index_s']} s + search {fj['search_s']} s), .bv bytes equal the GPU's: {fj['bv_bytes_equal_gpu']}")
             print(json.dumps(out), flush=True)
 
     matrix_detail, matrix_c2 = None, None

@@ -43,7 +43,7 @@ def _sources(*dirs, exts=(".hip", ".hpp", ".h", ".cpp")):
 
 def build_lib(force=False):
     """libcommet_hip.so: kernels + C ABI, cross-compiled for gfx950."""
-    srcs = _sources(CSRC, os.path.join(CSRC, "host"), os.path.join(ROOT, "include"))   # capi.hip includes host/fasta_source.hpp
+    srcs = _sources(CSRC, os.path.join(CSRC, "capi"), os.path.join(CSRC, "host"), os.path.join(ROOT, "include"))   # capi.hip includes capi/*.hpp and host/*.hpp
     if force or _newer(LIB, srcs):
         _run([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
               "-o", LIB, os.path.join(CSRC, "capi.hip"), "-lz"])

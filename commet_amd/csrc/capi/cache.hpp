@@ -1,0 +1,126 @@
+// capi/cache.hpp — device memory under pressure: the query lists cached with resident sets (accounted, least recently used first), allocations that retry after giving lists back, scatter workspaces picked from several candidates; the cache entry points of the ABI
+// (a part of the one translation unit capi.hip: included there, in order, after the kernels and state.hpp)
+#pragma once
+
+namespace {
+// drops one set's query list (caller holds ql_mu); hipFree waits for the kernels that read it
+void drop_query_list(commet_ctx *c, const commet_readset *rs)
+{
+    if (!rs->ql.built && !rs->ql.bytes) return;
+    c->ql_bytes -= std::min(c->ql_bytes, rs->ql.bytes);
+    rs->ql.release();
+    ++c->ql_evictions;
+}
+
+// gives cached query lists back until at most `target` bytes of them are left: least recently used first, never a list
+// of the running job unless `even_in_job` (the job thread itself is out of memory and holds no list between build and
+// launch).  Returns the bytes released.  Caller holds ql_mu.
+uint64_t shrink_query_lists(commet_ctx *c, uint64_t target, bool even_in_job)
+{
+    uint64_t freed = 0;
+    while (c->ql_bytes > target) {
+        const commet_readset *victim = nullptr;
+        for (const commet_readset *rs : c->sets)
+            if (rs->ql.built && (even_in_job || !rs->in_job) && (!victim || rs->ql.last_use < victim->ql.last_use)) victim = rs;
+        if (!victim) break;
+        freed += victim->ql.bytes;
+        drop_query_list(c, victim);
+    }
+    return freed;
+}
+
+// hipMalloc that gives the cached query lists back and tries once more when the device is out of memory
+hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void) hipGetLastError();
+    uint64_t freed;
+    {
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        freed = shrink_query_lists(c, 0, job_thread);
+    }
+    if (!freed) return e;
+    e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) (void) hipGetLastError();
+    return e;
+}
+
+// A buffer of several GB that kernels sweep as a whole — the scatter workspaces: 2^17 output streams all over it — is as fast as
+// hipMalloc happened to back it: one allocation in three streams ~20 % faster than the others (fills of 5.8 GB at 5.4 against
+// 4.5 TB/s, scatter1 4.2 against 5.0 ms per configs[1] step), the draw is made once per allocation, a fill shows it as well as
+// the kernels do, and most of the box-to-box spread of the whole step was this.  So: allocate `candidates`
+// buffers, touch each, time a second fill of each, keep the fastest and free the rest.  Costs a few ms per candidate, once per
+// workspace (the first job of a context, or the first one with larger chunks).
+hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stream, int candidates, const char *what)
+{
+    *p = nullptr;
+    const int n = std::max(1, std::min(candidates, 8));
+    void *cand[8] = {nullptr};
+    float ms[8] = {0};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (n > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return hipErrorUnknown;
+    int got = 0;
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < n; ++i) {
+        err = dev_alloc(c, &cand[i], bytes, true);
+        if (err != hipSuccess) break;                        // (the candidates before this one are still candidates)
+        ++got;
+        // first touch here, not inside the first scatter launch (measured: 15.6 ms instead of 2.5 ms for that one launch)
+        err = hipMemsetAsync(cand[i], 0, bytes, stream);
+        if (err == hipSuccess && n > 1) {
+            (void) hipEventRecord(e0, stream);
+            err = hipMemsetAsync(cand[i], 0, bytes, stream);
+            (void) hipEventRecord(e1, stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(stream);
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms[i], e0, e1);
+        }
+        if (err != hipSuccess) break;
+    }
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    if (got == 0) return err == hipSuccess ? hipErrorOutOfMemory : err;
+    int best = 0;
+    for (int i = 1; i < got; ++i)
+        if (ms[i] > 0 && (ms[best] <= 0 || ms[i] < ms[best])) best = i;
+    if (c->ws_verbose) {
+        fprintf(stderr, "commet: %s, %.2f GB, %d candidate(s), fill ms:", what, bytes / 1e9, got);
+        for (int i = 0; i < got; ++i) fprintf(stderr, " %.3f%s", ms[i], i == best ? "*" : "");
+        fprintf(stderr, "\n");
+    }
+    for (int i = 0; i < got; ++i)
+        if (i != best) (void) hipFree(cand[i]);
+    *p = cand[best];
+    (void) hipGetLastError();                               // (a failed extra candidate is not an error of the caller)
+    return hipSuccess;
+}
+}  // namespace
+
+extern "C" {
+
+uint64_t commet_readset_cache_bytes(const commet_readset *rs)
+{
+    std::lock_guard<std::mutex> lk(rs->ctx->ql_mu);
+    return rs->ql.built ? rs->ql.bytes : 0;
+}
+
+void commet_readset_drop_cache(commet_readset *rs)
+{
+    commet_ctx *c = rs->ctx;
+    (void) hipSetDevice(c->device);
+    std::lock_guard<std::mutex> lk(c->ql_mu);
+    if (rs->in_job) return;                              // (never under a running job)
+    drop_query_list(c, rs);
+    rs->ql.failed = false;                               // a list that did not fit once may fit now
+}
+
+int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions)
+{
+    std::lock_guard<std::mutex> lk(c->ql_mu);
+    if (bytes) *bytes = c->ql_bytes;
+    if (budget_bytes) *budget_bytes = c->ql_budget;
+    if (evictions) *evictions = c->ql_evictions;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+// capi/index_dispatch.hpp — which index construction runs for a chunk (atomic kernel or bucketed build, index_part.hpp) and its launches; commet_filter_reset
+// (a part of the one translation unit capi.hip: included there, in order, after the kernels and state.hpp)
+#pragma once
+
+extern "C" {
+
+/* ---- kernels -------------------------------------------------------------- */
+
+int commet_filter_reset(commet_ctx *c)
+{
+    HIP_OK(hipSetDevice(c->device));
+    KScope ks(c, "filter_memset", c->stream);
+    HIP_OK(hipMemsetAsync(c->slot_ptr(c->cur_slot), 0, c->filter_bytes, c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// uploads a host bit array (n/8+1 bytes) into a device bitmap of bitmap_words(n) words
+int upload_bits(commet_ctx *c, uint64_t *d_bits, const uint8_t *h_bits, uint64_t n)
+{
+    HIP_OK(hipMemsetAsync(d_bits, 0, bitmap_words(n) * 8, c->stream));
+    HIP_OK(hipMemcpyAsync(d_bits, h_bits, bitmap_bytes_host(n), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int launch_index_atomic(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                        unsigned long long *d_fed)
+{
+    if (count == 0) return 0;
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks >= (1ull << 24)) return fail("index launch too large (>= 2^32 reads in one chunk)");
+    KScope ks(c, "index_kernel", c->stream);
+    if (c->k <= 32)
+        COMMET_LAUNCH(index_kernel<uint32_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, first, count, d_sel, d_fed);
+    else
+        COMMET_LAUNCH(index_kernel<uint64_t>, dim3((unsigned) blocks), dim3(256), 0, c->stream, rs->view(), c->view(),
+                           c->k, first, count, d_sel, d_fed);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+bool partition_eligible(const commet_ctx *c, const commet_readset *rs)
+{
+    return c->k >= 20 && c->k <= 34 && (uint64_t) rs->max_kcnt * 4 <= S1_KEYS &&
+           ((uint64_t) rs->max_len + 7) / 8 <= S1_ITEMS;
+}
+
+// Bucketed construction of the filter for one chunk (index_part.hpp).  The
+// filter must have been zeroed on the stream before.  kmers = exact number of
+// complete k-mers of the selected reads of [first, first+count).
+// d_ids != nullptr (fixed-length sets only): the chunk's selected reads are ids[pos_first .. pos_first + pos_count) (sel_ids_kernel);
+// hist and scatter1 then take the arithmetic item path over that list instead of planning rounds over the bitmap
+int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                             uint64_t kmers, bool additive, bool zero_fill, int lane = 0, const uint32_t *d_ids = nullptr,
+                             uint64_t pos_first = 0, uint64_t pos_count = 0)
+{
+    if (count == 0 || kmers == 0) return 0;
+    if (d_ids && rs->uniform_len != 0 && !c->part_no_uni && pos_count) first = pos_first, count = pos_count, d_sel = nullptr;
+    else d_ids = nullptr;
+    commet_ctx::PartWs &ws = c->part[lane];
+    hipStream_t stream = lane ? c->aux_stream : c->stream;
+    uint32_t *const slot = c->slot_ptr(c->cur_slot);
+    PartGeom g = make_geom(c->k);
+    g.xcd_swizzle = c->s2_swizzle;
+    g.packed = c->part_packed;
+    if (c->part_b1 > 0 && c->part_b1 < g.nb_bits && c->part_b1 <= 8 && g.nb_bits - c->part_b1 <= 9) {
+        g.b1 = c->part_b1;
+        g.b2 = g.nb_bits - g.b1;
+        g.nb1 = 1u << g.b1;
+    }
+    if (g.b2 == 0) g.packed = 0;   // single level: scatter1 writes the final buckets itself, as plain keys
+    const uint64_t total = 4 * kmers;
+    if (ws.nb != g.nb) {
+        (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off); (void) hipFree(ws.goff);
+        (void) hipFree(ws.cur2);
+        ws.hist = ws.wl = nullptr; ws.off = ws.goff = nullptr; ws.cur2 = nullptr;
+        HIP_OK(dev_alloc(c, (void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.off, (g.nb + 1) * sizeof(uint64_t), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.goff, (g.nb + 1) * sizeof(uint64_t), true));
+        if (!ws.blockcnt) HIP_OK(dev_alloc(c, (void **) &ws.blockcnt, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(uint32_t), true));
+        if (!ws.blockoff) HIP_OK(dev_alloc(c, (void **) &ws.blockoff, (size_t) S1_GRID_MAX * MAX_L1 * sizeof(unsigned long long), true));
+        HIP_OK(dev_alloc(c, (void **) &ws.cur2, g.nb * sizeof(unsigned long long), true));
+        ws.nb = g.nb;
+    }
+    if (ws.cap_keys < total) {
+        HIP_OK(hipStreamSynchronize(stream));
+        (void) hipFree(ws.bufA); (void) hipFree(ws.bufB);
+        ws.bufA = ws.bufB = nullptr;
+        ws.cap_keys = 0;
+        const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
+        // (touched there, too: a first touch inside the first scatter launch cost 15.6 instead of 2.5 ms)
+        HIP_OK(alloc_fastest(c, (void **) &ws.bufA, cap * sizeof(uint32_t), stream, c->ws_candidates, lane ? "scatter workspace A (lane 1)" : "scatter workspace A"));
+        HIP_OK(alloc_fastest(c, (void **) &ws.bufB, cap * sizeof(uint32_t), stream, c->ws_candidates, lane ? "scatter workspace B (lane 1)" : "scatter workspace B"));
+        ws.cap_keys = cap;
+    }
+    const bool wide = c->k > 32;
+    // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
+    const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;   // (d_ids: positions in the list of selected reads)
+    HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
+    // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
+    const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
+    {
+        const unsigned grid = (grid1 + 1) / 2;
+        const bool full = g.nb <= HIST_MAX_BUCKETS;
+        // 32-bit keys (k <= 32): at most 2^15 buckets, the LDS histogram always covers them all (FULL); 64-bit keys: never.
+        // Only those four instantiations exist (tests/test_gpu_zz_dispatch_coverage.py checks that each is reached).
+        if (full == wide) return fail("internal error: histogram geometry (k = %d, %u buckets)", c->k, g.nb);
+        const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true, false> : (const void *) part_hist_kernel<uint64_t, false, false>)
+                              : (uni ? (const void *) part_hist_kernel<uint32_t, true, true> : (const void *) part_hist_kernel<uint32_t, false, true>);
+        for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
+            const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
+            const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
+            HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            ReadsView rv = rs->view();
+            const uint32_t *kc = rs->d_kcnt;
+            uint32_t *hist = ws.hist, *bcnt = ws.blockcnt;
+            uint32_t nblk = grid1;
+            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt, &d_ids};
+            KScope ks(c, "part_hist_kernel", stream);
+            note_launch(fn);
+            HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
+        }
+    }
+    {
+        const bool lds_hist = (size_t) g.nb * 4 <= (128u << 10);   // stage the histogram in LDS (coalesced loads) when it fits
+        const size_t lds = lds_hist ? ((size_t) g.nb + g.nb / 32 + 1) * 4 : 0;   // (padded: see the kernel)
+        if (lds) HIP_OK(hipFuncSetAttribute((const void *) part_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        KScope ks(c, "part_scan_kernel", stream);
+        COMMET_LAUNCH(part_scan_kernel, dim3(1), dim3(1024), lds, stream, ws.hist, g, zero_fill ? 1 : 0, ws.off,
+                           ws.cur2, ws.wl, ws.goff, lds_hist ? 1 : 0);
+    }
+    HIP_OK(hipGetLastError());
+    {
+        KScope ks(c, "part_blockoff_kernel", stream);
+        COMMET_LAUNCH(part_blockoff_kernel, dim3(g.nb1), dim3(512), 0, stream, ws.blockcnt, ws.off, g, grid1,
+                           ws.blockoff);
+    }
+    HIP_OK(hipGetLastError());
+    // scatter 1 (straight into the final buckets when there is a single level)
+    uint32_t *level1_out = g.b2 ? ws.bufA : ws.bufB;
+    {
+        const void *fn = wide ? (uni ? (const void *) part_scatter1_kernel<uint64_t, true> : (const void *) part_scatter1_kernel<uint64_t, false>)
+                              : (uni ? (const void *) part_scatter1_kernel<uint32_t, true> : (const void *) part_scatter1_kernel<uint32_t, false>);
+        ReadsView rv = rs->view();
+        const uint32_t *kc = rs->d_kcnt;
+        const unsigned long long *boff = ws.blockoff;
+        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out, &d_ids};
+        KScope ks(c, "part_scatter1_kernel", stream);
+        note_launch(fn);
+        HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
+    }
+    if (COMMET_ABLATE & 31) return 0;   // ablation builds only: scatter1 left garbage in bufA, nothing downstream may consume it
+    if (g.b2) {
+        const uint64_t grid = (total + S2_KEYS - 1) / S2_KEYS;
+        if (grid >= (1ull << 24)) return fail("scatter launch too large");
+        {
+            KScope ks(c, (g.packed && (1u << g.b2) <= S2P_MAX_SUB) ? "part_scatter2_packed_kernel" : "part_scatter2_kernel", stream);
+            if (g.packed && (1u << g.b2) <= S2P_MAX_SUB)
+                COMMET_LAUNCH(part_scatter2_packed_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, (uint2 *) ws.bufB,
+                                   ws.off, g, ws.cur2, total);
+            else
+                COMMET_LAUNCH(part_scatter2_kernel, dim3((unsigned) grid), dim3(S2_NT), 0, stream, ws.bufA, ws.bufB,
+                                   ws.off, g, ws.cur2, total);
+        }
+        HIP_OK(hipGetLastError());
+    }
+    if (COMMET_ABLATE) return 0;   // ablation builds only: bufB holds garbage
+    {
+        const uint64_t grid = (uint64_t) g.nb + total / BUILD_CAP + 1;
+        if (grid >= (1ull << 24)) return fail("build launch too large");
+        if (zero_fill) {   // no memset happened: clear the tiles that several workgroups OR into
+            KScope ks(c, "part_zero_split_kernel", stream);
+            COMMET_LAUNCH(part_zero_split_kernel, dim3(g.nb), dim3(256), 0, stream, ws.wl, g, slot);
+            HIP_OK(hipGetLastError());
+        }
+        HIP_OK(hipFuncSetAttribute((const void *) part_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int) (TILE_WORDS * sizeof(uint32_t))));
+        {
+            KScope ks(c, "part_build_kernel", stream);
+            COMMET_LAUNCH(part_build_kernel, dim3((unsigned) grid), dim3(BUILD_NT), TILE_WORDS * sizeof(uint32_t), stream,
+                               ws.bufB, g.packed ? ws.goff : ws.off, ws.wl, g, slot, additive ? 1 : 0, ws.cur2);
+        }
+        HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+// whether a launch of `kmers` complete k-mers takes the bucketed construction
+bool would_partition(const commet_ctx *c, const commet_readset *rs, uint64_t kmers)
+{
+    if (kmers == ~0ull || kmers == 0) return false;
+    if (c->index_mode == 2) return partition_eligible(c, rs);
+    if (c->index_mode == 0) return partition_eligible(c, rs) && kmers >= c->part_min_kmers;
+    return false;
+}
+
+// kmers: exact complete-k-mer count of the launch when known (enables the bucketed path), else ~0.
+// fresh_filter: the filter holds nothing yet; filter_zeroed: the caller has zeroed it (if not, a bucketed build
+// zero-fills what it does not set; the atomic kernel always needs a zeroed filter).
+int launch_index(commet_ctx *c, const commet_readset *rs, uint64_t first, uint64_t count, const uint64_t *d_sel,
+                 unsigned long long *d_fed, uint64_t kmers = ~0ull, bool fresh_filter = false, bool filter_zeroed = true,
+                 int lane = 0, const uint32_t *d_ids = nullptr, uint64_t pos_first = 0, uint64_t pos_count = 0)
+{
+    if (c->index_mode == 2) {
+        if (!partition_eligible(c, rs)) return fail("bucketed index construction needs 20 <= k <= 34 and reads of at most %u k-mers", S1_KEYS / 4);
+        if (kmers == ~0ull) return fail("bucketed index construction needs the k-mer count of the launch");
+    }
+    if (!would_partition(c, rs, kmers)) {
+        if (!filter_zeroed) return fail("internal error: atomic index launch on a filter that was not zeroed");
+        return launch_index_atomic(c, rs, first, count, d_sel, d_fed);
+    }
+    if (d_fed) {
+        // the count is known exactly on the host
+        const unsigned long long v = kmers;
+        HIP_OK(hipMemcpyAsync(d_fed, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return launch_index_partitioned(c, rs, first, count, d_sel, kmers, !fresh_filter, fresh_filter && !filter_zeroed, lane, d_ids, pos_first,
+                                    pos_count);
+}
+
+}  // namespace

@@ -1,0 +1,303 @@
+// capi/state.hpp — what every part of the C-ABI implementation shares: error reporting, launch bookkeeping, the context and
+// read-set objects behind the opaque handles of include/commet_hip.h, the per-launch timing scope.
+// (a part of the one translation unit capi.hip: included there first, after the kernel headers)
+#pragma once
+
+using namespace commet;
+
+namespace {
+
+thread_local std::string g_err;
+
+// Every kernel launch of the library notes its entry point here (the host-side handle hipLaunchKernel takes): the
+// test-suite resolves the addresses against the library's symbol table and checks that every instantiation compiled
+// into it was reached by a parity test (commet_launched_kernels, tests/test_gpu_zz_dispatch_coverage.py).
+std::mutex g_launch_mu;
+std::set<const void *> g_launched;
+inline void note_launch(const void *entry)
+{
+    // (the sliced / wide regimes issue thousands of launches per job, from two host threads: only an entry point this thread has
+    // not noted lately takes the lock)
+    thread_local const void *recent[16] = {nullptr};
+    thread_local unsigned next = 0;
+    for (const void *r : recent)
+        if (r == entry) return;
+    recent[next++ & 15u] = entry;
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    g_launched.insert(entry);
+}
+// a call site notes its kernel once (a template's call site: once per instantiation)
+#define COMMET_LAUNCH(kernel, ...)                                   \
+    do {                                                              \
+        static std::atomic<bool> noted_{false};                       \
+        if (!noted_.load(std::memory_order_relaxed)) {                \
+            note_launch((const void *) (kernel));                     \
+            noted_.store(true, std::memory_order_relaxed);            \
+        }                                                             \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                      \
+    } while (0)
+
+int fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define HIP_OK_NULL(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);           \
+            return nullptr;                                                                            \
+        }                                                                                              \
+    } while (0)
+
+inline uint64_t bitmap_words(uint64_t n) { return n / 64 + 1; }
+inline uint64_t bitmap_bytes_host(uint64_t n) { return n / 8 + 1; }   // boolean_vector.h:130
+
+constexpr uint64_t STAGE_BASES = 64ull << 20;
+constexpr uint64_t STAGE_READS = 1ull << 20;
+constexpr int      N_COUNTERS = 8;
+
+}  // namespace
+
+struct commet_ctx {
+    int device = 0;
+    int k = 0, t = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *filter = nullptr;       // 4 planes, contiguous
+    uint64_t plane_words = 0;
+    uint64_t filter_bytes = 0;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;   // pinned
+    hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    bool have_index_ev = false, have_search_ev = false;
+    bool count_probes = false;
+    int index_mode = 0;               // 0 auto, 1 atomic kernel, 2 bucketed construction
+    int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
+    int part_packed = 1;              // option: final buckets as groups of three 19-bit keys in 8 bytes (index_part.hpp)
+    int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
+    int s2_swizzle = 128;             // scatter2 slab order: number of interleaved slab ranges (index_part.hpp), 0 = dispatch order
+    uint64_t part_min_kmers = 8ull << 20;
+    // workspaces of the bucketed construction (index_part.hpp): two, so that the chunks of a group can be built on two
+    // streams at once (the compute-bound hist / scatter1 of one chunk overlap the HBM-bound scatter2 / build of another)
+    struct PartWs {
+        uint32_t *bufA = nullptr, *bufB = nullptr;
+        uint64_t cap_keys = 0;
+        uint32_t *hist = nullptr, *wl = nullptr;
+        uint64_t *off = nullptr, *goff = nullptr;   // bucket offsets in keys / in 8-byte groups (packed final level)
+        unsigned long long *cur2 = nullptr, *blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
+        uint32_t *blockcnt = nullptr;                              // keys per [scatter1 workgroup][coarse bucket]
+        uint32_t nb = 0;
+        void release()
+        {
+            (void) hipFree(bufA); (void) hipFree(bufB); (void) hipFree(hist); (void) hipFree(wl); (void) hipFree(off); (void) hipFree(goff);
+            (void) hipFree(cur2); (void) hipFree(blockoff); (void) hipFree(blockcnt);
+            *this = PartWs();
+        }
+    } part[2];
+    unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
+    uint32_t *d_ids = nullptr, *d_idblk = nullptr;   // read numbers of the index selection of the running job, in order (sel_ids_kernel)
+    uint64_t ids_cap = 0, idblk_cap = 0;
+    unsigned long long *d_plansum = nullptr;  // per-block k-mer sums of a selection (host planner input)
+    uint64_t plansum_cap = 0;
+    uint64_t jobcnt_cap = 0;
+    hipStream_t aux_stream = nullptr;         // second lane of a chunk group's index phase
+    hipStream_t load_stream = nullptr;        // everything that makes a read set (uploads, k-mer counts): a set may be loaded by one
+                                              // host thread while another runs jobs on sets that are complete
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
+    int ws_candidates = 4;                    // option / COMMET_WS_CANDIDATES: scatter workspaces allocated per buffer, the fastest kept (alloc_fastest)
+    bool ws_verbose = false;                  // COMMET_WS_VERBOSE: the candidates' fill times on stderr
+
+    int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)
+    int cur_slot = 0;                 // slot the index / search launch helpers work on
+    uint32_t *il_a = nullptr;         // interleaved A planes of a chunk group
+    int il_stride = 0;
+    // option "kernel_timing": a hipEvent pair around every kernel launch of commet_index_and_search, on the stream the
+    // kernel is launched on; per-kernel totals are read with commet_kernel_times (bench.py's roofline leg)
+    struct KernelClock {
+        struct Rec { const char *name; hipEvent_t a, b; };
+        bool on = false;
+        std::vector<Rec> open;                         // launches of the current call
+        std::vector<hipEvent_t> spare;                 // events kept for the next call
+        std::vector<std::string> names;                // totals, in first-seen order
+        std::vector<uint64_t> launches;
+        std::vector<double> total_ms;
+        hipEvent_t get()
+        {
+            hipEvent_t e = nullptr;
+            if (!spare.empty()) e = spare.back(), spare.pop_back();
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        }
+        void collect()                                  // after the stream has been synchronised
+        {
+            for (Rec &r : open) {
+                float ms = 0;
+                if (r.a && r.b && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                    size_t i = 0;
+                    while (i < names.size() && names[i] != r.name) ++i;
+                    if (i == names.size()) names.push_back(r.name), launches.push_back(0), total_ms.push_back(0);
+                    launches[i] += 1;
+                    total_ms[i] += ms;
+                }
+                if (r.a) spare.push_back(r.a);
+                if (r.b) spare.push_back(r.b);
+            }
+            open.clear();
+        }
+        void reset() { names.clear(), launches.clear(), total_ms.clear(); }
+        void release()
+        {
+            collect();
+            for (hipEvent_t e : spare) (void) hipEventDestroy(e);
+            spare.clear();
+        }
+    } kclock;
+    // the many-small-chunks regime (slice_search.hpp): staging bit-planes, bit-sliced tables, chunk descriptors
+    uint32_t *slice_stage = nullptr, *slice_tables = nullptr;
+    SliceChunk *d_slice_chunks = nullptr;
+    uint64_t slice_stage_words = 0, slice_table_words = 0, slice_chunks_cap = 0;
+    uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
+    uint64_t qres_cap = 0;
+    int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
+    // environment knobs of A/B runs, read ONCE in commet_create (nothing on the launch path calls getenv)
+    int tq_sbits = 0;                 // COMMET_TQ_SBITS: log2 bits per address slice of the query list (0 = TQ_SBITS)
+    int tq_parts = 1;                 // COMMET_TQ_PARTS / option "tq_parts": runs of pieces whose replay overlaps the next run's probe.  Off:
+                                      // measured on configs[1] 19.76 ms per step in one part, 21.8 / 23.2 / 24.6 / 25.3 in 2 / 3 / 4 / 6 (the
+                                      // replay of one part and the probe of the next contend for the same memory system, r03_parts_*.json)
+    unsigned tq_wpx = 64;             // COMMET_TQ_WPX: probe workgroups per XCD (a multiple of the 32 CUs of an XCD keeps the sweep even;
+                                      // measured: 32 or 64 (1 or 2 per CU) 2.3-2.6 ms, 128: 3.7, 256: 4.8)
+    bool stage_reads = true;          // COMMET_NO_STAGE_READS: search_group_kernel without the LDS copy of the lanes' reads
+    bool job_verbose = false;         // COMMET_JOB_VERBOSE: host-side phase times of every commet_index_and_search call on stderr
+    bool ingest_verbose = false;      // COMMET_INGEST_VERBOSE
+    int slice_mode = 0;               // option: 0 auto, 1 never, 2 whenever k allows it
+    int slice_gw = 0;                 // option: words per bit-sliced entry (32 chunks each); 0 = by the number of chunks
+    int slice_wide = 0;               // option: wide rows (all chunk filters side by side, slice_search.hpp): 0 auto (more than 256 chunks), 1 never, 2 whenever the regime applies
+    uint32_t wide_cap_words = 0;      // option "slice_wide_words": at most this many words per row (tests: several passes); 0 = the budget decides
+    uint32_t *wide_tables = nullptr;
+    uint64_t wide_table_words = 0;
+    uint64_t max_kmer_test = 0;       // option "max_kmer": chunk size override for tests (0 = the reference's constant)
+    int chunk_group = 8;              // option: chunks searched per pass (1 = one pass per chunk; more than 4 only where group8_ok)
+    // pinned / device staging buffers of the parallel host ingest, kept for the next read set (hipHostMalloc is slow)
+    struct IngestBuf {
+        uint32_t *h_planes = nullptr;
+        uint64_t *h_goff = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<IngestBuf> ingest_pool;
+
+    // Derived data cached with the read sets (the tiled search's query lists, ~6 bytes per first-hit window: several times
+    // the packed set itself) is accounted here and given back under pressure: least recently used lists first when the
+    // budget is exceeded, every list that is not part of the running job when a device allocation fails.
+    std::mutex ql_mu;                                 // guards the registry and every query list of the context
+    std::vector<commet_readset *> sets;               // read sets alive on this context
+    uint64_t ql_bytes = 0, ql_budget = 64ull << 30, ql_clock = 0, ql_evictions = 0;
+    uint64_t ql_max_list = 4ull << 30;                // auto mode: sets whose list (8 bytes per first-hit window, estimated) is larger keep the gather kernels
+
+    uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
+    FilterView view() const
+    {
+        uint32_t *base = slot_ptr(cur_slot);
+        FilterView f;
+        f.a = base;
+        f.b = base + plane_words;
+        f.c = base + 2 * plane_words;
+        f.d = base + 3 * plane_words;
+        return f;
+    }
+};
+
+struct commet_readset {
+    commet_ctx *ctx = nullptr;
+    uint64_t max_reads = 0, max_bases = 0;
+    uint64_t n_reads = 0, n_bases = 0;
+    uint32_t *d_planes = nullptr;
+    uint64_t *d_goff = nullptr;
+    uint32_t *d_kcnt = nullptr;
+    uint32_t *d_lenmm = nullptr;
+    uint64_t *d_sel = nullptr, *d_tags = nullptr, *d_found = nullptr;   // bitmaps, bitmap_words(max_reads)
+    struct Stage {
+        uint8_t *h_bases = nullptr;
+        uint64_t *h_offs = nullptr;
+        uint8_t *d_bases = nullptr;
+        uint64_t *d_offs = nullptr;
+        hipEvent_t done = nullptr;
+        bool inflight = false;
+    } st[2];
+    int cur = 0;
+    bool acquired = false;
+    uint64_t stage_bases = 0, stage_reads = 0;
+    std::vector<FileSpan> files;
+    std::vector<uint64_t> empty_reads;
+    mutable std::vector<uint32_t> h_kcnt;      // host copy of d_kcnt, made on first use (host_counts)
+    mutable std::vector<uint64_t> h_kprefix;   // prefix sums of h_kcnt (fast chunk planning)
+    mutable bool have_host_counts = false;
+    uint32_t uniform_len = 0;
+    uint32_t max_kcnt = 0;
+    uint32_t max_len = 0, min_len = 0;
+    // query list of the tiled search (tile_search.hpp): the set's lane-a addresses sorted by address slice, made on first use
+    struct QueryList {
+        unsigned long long *d_tile_off = nullptr;
+        uint32_t *d_qaddr = nullptr, *d_tstart = nullptr;
+        uint16_t *d_qwho = nullptr, *d_tlen = nullptr;
+        uint64_t n_records = 0;
+        uint32_t n_slices = 0, n_pieces = 0;
+        int sbits = 0;
+        bool built = false, failed = false;
+        uint64_t bytes = 0, last_use = 0;           // HBM held; the context's ql_clock at the last scan that used the list
+        void release()
+        {
+            (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho); (void) hipFree(d_tstart); (void) hipFree(d_tlen);
+            *this = QueryList();
+        }
+    };
+    mutable QueryList ql;
+    mutable bool in_job = false;                    // part of the commet_index_and_search call that is running: its list stays
+    bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
+    uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;
+    bool finalized = false;
+
+    ReadsView view() const
+    {
+        ReadsView v;
+        v.planes = d_planes;
+        v.goff = d_goff;
+        v.uniform_len = uniform_len;
+        v.n = n_reads;
+        return v;
+    }
+};
+
+namespace {
+// times one kernel launch when option "kernel_timing" is on (no-op otherwise)
+struct KScope {
+    commet_ctx::KernelClock &kc;
+    hipStream_t stream;
+    size_t idx = ~(size_t) 0;
+    KScope(commet_ctx *c, const char *name, hipStream_t s) : kc(c->kclock), stream(s)
+    {
+        if (!kc.on) return;
+        commet_ctx::KernelClock::Rec r{name, kc.get(), kc.get()};
+        if (r.a) (void) hipEventRecord(r.a, stream);
+        idx = kc.open.size();
+        kc.open.push_back(r);
+    }
+    ~KScope()
+    {
+        if (idx != ~(size_t) 0 && kc.open[idx].b) (void) hipEventRecord(kc.open[idx].b, stream);
+    }
+};
+}  // namespace

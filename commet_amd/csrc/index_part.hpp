@@ -89,7 +89,7 @@ inline PartGeom make_geom(int k)
     // coarse buckets wherever the packed scatter2 still takes the rest (b2 <= 8): k = 32 is 7 + 8 (was 8 + 7: scatter1 -0.55 … -0.9 ms
     // per step, scatter2 +0.15 … +0.5)
     g.b1 = g.nb_bits <= 8 ? g.nb_bits : (g.nb_bits + 1) / 2;
-    if (g.b1 > 7 && g.nb_bits - 7 <= 8) g.b1 = 7;
+    if (g.nb_bits > 8 && g.b1 > 7 && g.nb_bits - 7 <= 8) g.b1 = 7;   // (two-level geometries only: k = 25 keeps its single level of 2^8 buckets)
     if (g.b1 > 8) g.b1 = 8;
     g.b2 = g.nb_bits - g.b1;
     g.nb = 1u << g.nb_bits;
