@@ -351,13 +351,17 @@ def matrix_leg(args, ranks, n, note=None):
         res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False,
                          progress=lambda msg: print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] matrix leg, rank {ranks.rank}: {msg}",
                                                     file=sys.stderr, flush=True))
+    except BaseException as ex:
+        ranks.abort(f"{type(ex).__name__}: {ex}")      # (the other ranks' waits end with an error naming this one; no-op on one rank)
+        raise
     finally:
         if saved_scratch is None:
             os.environ.pop("COMMET_SCRATCH", None)
         else:
             os.environ["COMMET_SCRATCH"] = saved_scratch
-        ranks.barrier()
-        if ranks.rank == 0:
+        if not ranks.failed:
+            ranks.barrier()
+        if ranks.rank == 0 or ranks.failed:             # (a failed job: whoever gets here removes what is left)
             shutil.rmtree(work, ignore_errors=True)
         _WORK_DIRS.remove(work)
     progress(ranks, "matrix leg: done")

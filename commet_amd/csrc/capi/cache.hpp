@@ -55,15 +55,27 @@ hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
 hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stream, int candidates, const char *what)
 {
     *p = nullptr;
-    const int n = std::max(1, std::min(candidates, 8));
+    int n = std::max(1, std::min(candidates, 8));
+    {   // never more candidates than the device holds with room to spare (several processes may share it)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const size_t spare = (size_t) 16 << 30;
+            n = (int) std::max<size_t>(1, std::min<size_t>((size_t) n, fr > spare ? (fr - spare) / std::max<size_t>(bytes, 1) : 1));
+        }
+    }
     void *cand[8] = {nullptr};
     float ms[8] = {0};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (n > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return hipErrorUnknown;
     int got = 0;
     hipError_t err = hipSuccess;
+    double alloc_ms[8] = {0}, free_ms = 0;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int i = 0; i < n; ++i) {
-        err = dev_alloc(c, &cand[i], bytes, true);
+        const double a0 = now_ms();
+        // (only the first candidate may take memory back from the cached query lists: the others are optional)
+        err = i == 0 ? dev_alloc(c, &cand[i], bytes, true) : hipMalloc(&cand[i], bytes);
+        alloc_ms[i] = now_ms() - a0;
         if (err != hipSuccess) break;                        // (the candidates before this one are still candidates)
         ++got;
         // first touch here, not inside the first scatter launch (measured: 15.6 ms instead of 2.5 ms for that one launch)
@@ -83,13 +95,17 @@ hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stre
     int best = 0;
     for (int i = 1; i < got; ++i)
         if (ms[i] > 0 && (ms[best] <= 0 || ms[i] < ms[best])) best = i;
+    const double f0 = now_ms();
+    for (int i = 0; i < got; ++i)
+        if (i != best) (void) hipFree(cand[i]);
+    free_ms = now_ms() - f0;
     if (c->ws_verbose) {
         fprintf(stderr, "commet: %s, %.2f GB, %d candidate(s), fill ms:", what, bytes / 1e9, got);
         for (int i = 0; i < got; ++i) fprintf(stderr, " %.3f%s", ms[i], i == best ? "*" : "");
-        fprintf(stderr, "\n");
+        fprintf(stderr, "; hipMalloc ms:");
+        for (int i = 0; i < got; ++i) fprintf(stderr, " %.1f", alloc_ms[i]);
+        fprintf(stderr, "; hipFree of the others %.1f ms\n", free_ms);
     }
-    for (int i = 0; i < got; ++i)
-        if (i != best) (void) hipFree(cand[i]);
     *p = cand[best];
     (void) hipGetLastError();                               // (a failed extra candidate is not an error of the caller)
     return hipSuccess;

@@ -12,7 +12,8 @@ on sets that stay packed in HBM:
 
 One process per GPU.  The path has no exchange step, so ranks share nothing but small files
 and three host-side gathers (sharding.Ranks: a TCP store of rank 0, no torch in the ranks):
-  * every set is PARSED ONCE on the node: set s by rank s % world, which exports the set's
+  * every set is PARSED ONCE on the node (set s by rank s % world; left-over sets by the ranks with
+    the cheapest pairs), by a rank which exports the set's
     device buffers (commet_readset_export: HIP IPC handles, a 264-byte descriptor in a scratch
     directory); the other ranks that need the set copy it device to device
     (commet_readset_import: xGMI between GPUs) — no file, no parsing.  Where that is not to be
@@ -297,14 +298,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 filter_pool.shutdown(wait=True)
             filter_s = (filter_end[0] if filter_jobs else time.perf_counter()) - t_filter
 
-    # ---- who does what: pairs in contiguous runs of equal cost, sets parsed by rank s % world -----------
+    # ---- who does what: pairs in contiguous runs of equal cost, every set parsed by one rank (sharding.assign_owners) ----
     pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
     size = [float(sum(os.path.getsize(f) for f in fl)) for fl in files]   # cost proxy known before any parsing
     pair_cost = [size[a] + size[b] for a, b in pairs]
     runs = sharding.assign_pairs_contiguous(pair_cost, world)
     mine = [pairs[c] for c in runs[rank]]
     needed = sorted({s for p in mine for s in p})
-    owned = [s for s in range(N) if s % world == rank]
+    owner = sharding.assign_owners(N, world, [sum(pair_cost[c] for c in runs[r]) for r in range(world)])
+    owned = [s for s in range(N) if owner[s] == rank]
     needed_by_others = {s for r in range(world) if r != rank for c in runs[r] for s in pairs[c]}
 
     scratch = None
@@ -393,7 +395,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # the canary: of the ranks that take sets from others, the first one starts a fresh child process that imports the first
     # real set to appear (tests/engines without a child command: no canary)
     def foreign(r):
-        return sorted({s_ for c in runs[r] for s_ in pairs[c] if s_ % world != r})
+        return sorted({s_ for c in runs[r] for s_ in pairs[c] if owner[s_] != r})
 
     canary_rank = next((r for r in range(world) if foreign(r)), None) if use_ipc else None
     canary = None
@@ -460,11 +462,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             (or never, if that rank died: the launcher then ends this process; the deadline only bounds a stray wait)"""
             deadline = time.perf_counter() + float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))
             w0 = time.perf_counter()
+            polls = 0
             while not os.path.exists(path):
                 if filter_err:
                     raise filter_err[0]
                 if stop_ev.is_set():
                     return False
+                polls += 1
+                if polls % 128 == 0 and hasattr(ranks, "check"):   # (every quarter of a second: has the rank that is to publish it given up?)
+                    ranks.check()
                 if time.perf_counter() > deadline:
                     raise RuntimeError(f"{what} did not appear in {where or scratch}")
                 time.sleep(0.002)
@@ -636,31 +642,40 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
         t_jobs = time.perf_counter()
         for ref in refs:
-            targets = [i for (r, i) in mine if r == ref]
-            for s_need in [ref] + targets:                       # (pipelined: resident by now, or nearly)
-                wait_for(s_need)
-            w0 = time.perf_counter()
-            tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
-            prof["j1_builds"] += 1
-            reads_searched += sum(considered[i] for i in targets)
-            _acc(inf1)
-            for i, T1 in zip(targets, tags1):
-                # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
-                tags2, st2, inf2 = eng.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
-                T2 = tags2[0]
-                _acc(inf2)
-                for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
-                    write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-                _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
-                shared[(ref, i)] = st2[0]["shared"]
-                # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
-                tags3, st3, inf3 = eng.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
-                _acc(inf3)
-                for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
-                    write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
-                _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
-                shared[(i, ref)] = st3[0]["shared"]
-                reads_searched += considered[ref] + considered[i]
+            wait_for(ref)
+            pending = [i for (r, i) in mine if r == ref]
+            while pending:
+                # J1 of `ref` against the targets that are resident by now — all of them as a rule; at the start of a run with several
+                # ranks whichever have arrived, the others in a second call (one more index build of S_ref instead of an idle GPU)
+                targets = [i for i in pending if loader is None or ready[i].is_set()]
+                if not targets:
+                    wait_for(pending[0])
+                    continue
+                pending = [i for i in pending if i not in targets]
+                for s_need in targets:
+                    wait_for(s_need)                             # (resident: raises what the loader raised, if it did)
+                w0 = time.perf_counter()
+                tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
+                prof["j1_builds"] += 1
+                reads_searched += sum(considered[i] for i in targets)
+                _acc(inf1)
+                for i, T1 in zip(targets, tags1):
+                    # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
+                    tags2, st2, inf2 = eng.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
+                    T2 = tags2[0]
+                    _acc(inf2)
+                    for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
+                        write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
+                    _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
+                    shared[(ref, i)] = st2[0]["shared"]
+                    # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
+                    tags3, st3, inf3 = eng.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
+                    _acc(inf3)
+                    for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
+                        write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
+                    _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
+                    shared[(i, ref)] = st3[0]["shared"]
+                    reads_searched += considered[ref] + considered[i]
             note(f"jobs of set {ref} done ({prof['jobs']} so far)")
         eng.synchronize()
         jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
@@ -716,6 +731,12 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         for rs in sets.values():
             eng.release(rs)
         return result
+    except BaseException as ex:
+        # with several ranks: tell the others at once (their waits end with an error naming this rank) instead of leaving them in a
+        # gather until the timeout
+        if world > 1 and hasattr(ranks, "abort"):
+            ranks.abort(f"{type(ex).__name__}: {ex}")
+        raise
     finally:
         if stop_ev is not None:
             stop_ev.set()
@@ -731,7 +752,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         eng.close()
         if scratch is not None:
             # rank 0 removes the scratch directory once everybody is through; a failing rank removes its own images
-            if sys.exc_info()[0] is None:
+            if sys.exc_info()[0] is None and not getattr(ranks, "failed", False):
                 ranks.barrier()
                 if rank == 0:
                     shutil.rmtree(scratch, ignore_errors=True)

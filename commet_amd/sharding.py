@@ -66,6 +66,19 @@ def assign_pairs_contiguous(cost, world_size):
     return [range(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
+def assign_owners(n_sets, world_size, rank_cost):
+    """Which rank parses which set (every set is parsed once on the node): set s by rank s % world_size for the first
+    world_size * (n_sets // world_size) sets; the sets left over — the ranks that take them parse one set more than the
+    others — go to the ranks whose pairs cost least (rank_cost[r], ties to the lower rank), one each."""
+    owner = [s % world_size for s in range(n_sets)]
+    full = world_size * (n_sets // world_size)
+    if n_sets >= world_size:
+        by_slack = sorted(range(world_size), key=lambda r: (rank_cost[r], r))
+        for j, s in enumerate(range(full, n_sets)):
+            owner[s] = by_slack[j % world_size]
+    return owner
+
+
 # ---- ranks of one job: barrier / gather / MAX / SUM on the host, no torch --------------------------------------
 #
 # The path has no data-path collective (SURVEY 8e); what the ranks of a job tell each other are a few small host
@@ -195,6 +208,19 @@ class _Store:
                         for key in [x for x in self.kv if x.startswith(parts[1])]:
                             del self.kv[key]
                     _send_frame(conn, b"OK")
+                elif op == b"CHK":                               # is the job still whole?
+                    with self.cv:
+                        lost = self.lost
+                    if lost is None:
+                        _send_frame(conn, b"OK")
+                    else:
+                        _send_frame(conn, b"LOST", str(lost).encode())
+                elif op == b"ABORT":                             # a rank gives the job up: every wait ends with an error, now and later
+                    with self.cv:
+                        if self.lost is None:
+                            self.lost = f"{rank} (gave up: {parts[1].decode(errors='replace')})"
+                        self.cv.notify_all()
+                    _send_frame(conn, b"OK")
                 elif op == b"BYE":
                     said_bye = True
                     with self.cv:
@@ -221,9 +247,9 @@ class _Store:
 
     def wait_byes(self, seconds):
         import time
-        deadline = time.monotonic() + seconds
+        deadline = time.monotonic() + (seconds if self.lost is None else min(seconds, 3.0))   # (a failed job: the others are told, then out)
         with self.cv:
-            while self.byes < self.world and self.lost is None and time.monotonic() < deadline:
+            while self.byes < self.world and time.monotonic() < deadline:
                 self.cv.wait(0.1)
         try:
             self.sock.close()
@@ -247,6 +273,7 @@ class Ranks:
             raise ValueError(f"unknown ranks backend {self.backend!r} (tcp or gloo)")
         self.timeout_s = float(os.environ.get("COMMET_DIST_TIMEOUT_S", "600"))   # a rank that dies must not leave the others waiting for long
         self.dist = None
+        self.failed = False                              # a rank of the job has given up (or vanished): no collective will complete any more
         self._sock, self._store, self._seq = None, None, 0
         if self.world > 1 and self.backend == "gloo":
             self._init_gloo()
@@ -320,11 +347,31 @@ class Ranks:
                 _send_frame(self._sock, *parts)
                 rep = _recv_frame(self._sock)
             except (OSError, ConnectionError) as ex:
+                self.failed = True
                 raise RuntimeError(f"rendezvous: rank {self.rank} lost the store ({type(ex).__name__}: {ex}); a peer has died or "
                                    f"nothing arrived within {self.timeout_s:.0f} s") from None
         if rep[0] == b"LOST":
-            raise RuntimeError(f"rendezvous: rank {rep[1].decode()} left the job without saying goodbye")
+            self.failed = True
+            who = rep[1].decode()
+            raise RuntimeError(f"rendezvous: rank {who}" + ("" if "gave up" in who else " left the job without saying goodbye"))
         return rep
+
+    def check(self):
+        """Raises if a rank of the job has given up or vanished (for waits that do not go through the store: files another rank
+        is to publish).  Cheap; any thread."""
+        if self._sock is not None:
+            self._call(b"CHK")
+
+    def abort(self, reason):
+        """This rank gives the job up (it raised): the other ranks' waits, now and later, end with an error naming it — nobody is left
+        in a barrier until a timeout.  gloo has no such thing: there a failing rank leaves the process (matrix.main) and the launcher
+        ends the group."""
+        self.failed = True
+        if self._sock is not None:
+            try:
+                self._call(b"ABORT", str(reason)[:500].encode())
+            except RuntimeError:
+                pass
 
     def _dumps(self, obj):
         import hashlib
@@ -403,8 +450,9 @@ class Ranks:
             self.dist.destroy_process_group()
             self.dist = None
         elif self._sock is not None:
-            self.barrier()
             try:
+                if not self.failed:
+                    self.barrier()
                 self._call(b"BYE")
             except RuntimeError:
                 pass

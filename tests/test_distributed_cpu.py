@@ -39,6 +39,20 @@ def test_assignment_is_a_partition_and_balanced(world):
     assert max(loads) - min(loads) <= max(cost)
 
 
+@pytest.mark.parametrize("n,world", [(10, 1), (10, 2), (10, 4), (10, 8), (5, 8), (3, 2), (16, 8), (17, 8)])
+def test_every_set_has_one_owner_and_left_over_sets_go_to_the_cheapest_ranks(n, world):
+    pairs = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
+    runs = sharding.assign_pairs_contiguous([2.0] * len(pairs), world)
+    cost = [2.0 * len(r) for r in runs]
+    owner = sharding.assign_owners(n, world, cost)
+    assert len(owner) == n and all(0 <= o < world for o in owner)
+    per = [owner.count(r) for r in range(world)]
+    assert max(per) - min(per) <= 1                                   # nobody parses two sets more than anybody else
+    extra = [r for r in range(world) if per[r] == max(per)] if max(per) != min(per) else []
+    if extra and n >= world:
+        assert max(cost[r] for r in extra) <= min(cost[r] for r in range(world) if r not in extra) + 2.0 or len(set(cost)) == 1
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
 def test_contiguous_runs_partition_the_pairs(world):
     n = 10
@@ -142,7 +156,7 @@ def test_matrix_driver_host_logic_over_ranks(tmp_path, world, handover, backend,
     assert all(r["backend"] == backend and r["torch_loaded"] == (backend == "gloo") for r in res["per_rank"])
     assert sum(r["sets_parsed"] for r in res["per_rank"]) == len(names)          # one parse per set on the node
     assert sum(r["pairs"] for r in res["per_rank"]) == 10
-    assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + world
+    assert sum(r["j1_builds"] for r in res["per_rank"]) <= 4 + 2 * world          # (a rank may split its first J1 by the sets that have arrived)
     # the static cut: every rank's predicted share of the pairs' cost is within one pair of the mean, and they add up
     shares = [r["predicted_share"] for r in res["per_rank"]]
     sizes = [sum(os.path.getsize(tmp_path / f) for f in fl) for fl in files]
@@ -189,14 +203,28 @@ def test_matrix_driver_failing_rank_ends_the_group(tmp_path, launcher, backend):
     assert time.time() - t0 < 90
 
 
+def test_a_rank_that_raises_tells_the_others(tmp_path):
+    """rank 1 raises inside matrix.run and its caller CATCHES (as bench.py's matrix leg does): matrix.run has told the store, so
+    rank 0 — three sets into its own work, or waiting in a gather — gets an error naming rank 1 within seconds, not a timeout"""
+    import time
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    t0 = time.time()
+    p = _launch(2, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t), "1"], str(tmp_path), timeout=300,
+                launcher="spawn", extra_env={"COMMET_TEST_SOFT_FAIL": "1"})
+    out = p.stdout.decode()
+    assert p.returncode == 5, out[-2000:]
+    assert "injected failure while parsing" in out and "rank 1 (gave up: RuntimeError: injected failure while parsing)" in out
+    assert time.time() - t0 < 60
+
+
 def test_store_tells_the_ranks_when_one_of_them_is_gone(tmp_path):
     """no launcher to end the group: three ranks started by hand, rank 2 leaves without a word while the others wait at a
     barrier — the store answers their wait with an error at once (not after COMMET_DIST_TIMEOUT_S)"""
     import time
     code = (f"import os, sys; sys.path.insert(0, {ROOT!r}); from commet_amd import sharding\n"
-            "r = sharding.Ranks()\n"
-            "if r.rank == 2: os._exit(0)\n"
-            "try:\n    r.barrier(); r.barrier()\nexcept RuntimeError as ex:\n    print('RANK', r.rank, ex); sys.exit(7)\n")
+            "me = int(os.environ['RANK'])\n"
+            "try:\n    r = sharding.Ranks()\n    if me == 2: os._exit(0)\n    r.barrier(); r.barrier()\n"
+            "except RuntimeError as ex:\n    print('RANK', me, ex); sys.exit(7)\n")
     env = dict(os.environ, WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31000 + os.getpid() % 2000), COMMET_DIST_TIMEOUT_S="120")
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
