@@ -566,12 +566,26 @@ def main():
                     roofline["algorithmic_bytes_per_launch"] = alg // max(1, int(e["launches_per_step"]))
                     roofline["algorithmic_model"] = (f"{n} reads x {windows} windows x 6 rows x {row_bytes} B (one bit per chunk filter, "
                                                      f"{info['n_chunks']} chunks in groups of 256) x {passes} pass(es)")
+                def request_rate(nme):
+                    """a gather kernel priced in 64-byte memory requests that miss L2 (FETCH_SIZE / 64) against the random-gather ceiling of this run"""
+                    fx, ee = (table.get(nme) or {}).get("fetch_bytes_per_launch"), ktimes.get(nme)
+                    if not (fx and ee and gather_ceiling):
+                        return None
+                    rps = fx / SECTOR / (ee["avg_launch_ms"] * 1e-3)
+                    return {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling), "frac": round(rps / gather_ceiling, 4)}
+
                 if fetch and gather_ceiling and dom.startswith(("search", "tq_")) and dom != "search_wide_kernel":   # (gather kernels: one 64-byte sector per request)
-                    rps = fetch / SECTOR / (e["avg_launch_ms"] * 1e-3)
-                    roofline["request_rate"] = {"requests_per_s": round(rps), "ceiling_per_s": round(gather_ceiling),
-                                                "frac": round(rps / gather_ceiling, 4),
-                                                "what": "64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against commet_membench's "
-                                                        "random 4-byte gathers over a filter-sized table, measured in this run"}
+                    roofline["request_rate"] = dict(request_rate(dom), what="64-byte memory requests of the kernel (FETCH_SIZE / 64) per second against "
+                                                    "commet_membench's random 4-byte gathers over a filter-sized table, measured in this run")
+                # both kernels of a tiled scan: the replay's requests miss L2 (that ceiling applies); the probe's gathers are served
+                # FROM L2 slice by slice, so it is priced in query-list records per second as well (what its HBM requests are: streams)
+                sk = {nme: request_rate(nme) for nme in ktimes if nme.startswith(("search_", "tq_probe", "tq_replay")) and nme != "search_wide_kernel"}
+                if "tq_probe_kernel" in ktimes and query_list_bytes:
+                    recs = query_list_bytes // 6                                    # 4-byte address + 2-byte owner per first-hit window
+                    pk = ktimes["tq_probe_kernel"]
+                    sk["tq_probe_kernel"] = dict(sk.get("tq_probe_kernel") or {}, l2_gathers_per_s=round(recs * pk["launches_per_step"] / (pk["ms_per_step"] * 1e-3)),
+                                                 records=recs)
+                roofline["search_kernels_request_rate"] = {nme: v for nme, v in sk.items() if v}
                 # what a step cannot avoid moving: both packed sets read once (12 bytes per 32 bases + a triple per read), every
                 # chunk's filter written once and read once (2^(k-1) bytes each way), the tag bits
                 triple_bytes = 12 * (L // 32 + 1)

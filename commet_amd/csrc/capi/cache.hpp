@@ -29,7 +29,10 @@ uint64_t shrink_query_lists(commet_ctx *c, uint64_t target, bool even_in_job)
     return freed;
 }
 
-// hipMalloc that gives the cached query lists back and tries once more when the device is out of memory
+void trim_ws_pool(commet_ctx *c);
+
+// hipMalloc that gives the cached query lists (and workspace candidates still waiting in the pool) back and tries once more when
+// the device is out of memory
 hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
 {
     hipError_t e = hipMalloc(p, bytes);
@@ -37,8 +40,13 @@ hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
     (void) hipGetLastError();
     uint64_t freed;
     {
+        std::lock_guard<std::mutex> lk(c->ws_pool_mu);
+        freed = c->ws_pool.size();
+    }
+    trim_ws_pool(c);
+    {
         std::lock_guard<std::mutex> lk(c->ql_mu);
-        freed = shrink_query_lists(c, 0, job_thread);
+        freed += shrink_query_lists(c, 0, job_thread);
     }
     if (!freed) return e;
     e = hipMalloc(p, bytes);
@@ -49,12 +57,36 @@ hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
 // A buffer of several GB that kernels sweep as a whole — the scatter workspaces: 2^17 output streams all over it — is as fast as
 // hipMalloc happened to back it: one allocation in three streams ~20 % faster than the others (fills of 5.8 GB at 5.4 against
 // 4.5 TB/s, scatter1 4.2 against 5.0 ms per configs[1] step), the draw is made once per allocation, a fill shows it as well as
-// the kernels do, and most of the box-to-box spread of the whole step was this.  So: allocate `candidates`
-// buffers, touch each, time a second fill of each, keep the fastest and free the rest.  Costs a few ms per candidate, once per
-// workspace (the first job of a context, or the first one with larger chunks).
+// the kernels do, and most of the box-to-box spread of the whole step was this.  So the first workspace of a
+// context is picked from `candidates` buffers: each touched, a second fill of each timed, the fastest kept.  The others are NOT
+// freed at once: they wait in the context's pool, and the workspaces asked for next — the same job's other buffer, the second
+// index lane's two — take the fastest one left that is large enough.  Four candidates thus serve the four buffers of a two-lane
+// context with no allocation beyond the four it needs anyway; what is left in the pool is freed when the job ends.  (Freeing tens
+// of GB and allocating again is not free on this driver: a hipMalloc of 8.5 GB now and then blocks for 1-2 s when the process has
+// just given that much back — measured with 4 candidates PER buffer, 12 of 16 freed at once — so churn is what to avoid.)
+void trim_ws_pool(commet_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(c->ws_pool_mu);
+    for (auto &b : c->ws_pool) (void) hipFree(b.ptr);
+    c->ws_pool.clear();
+}
+
 hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stream, int candidates, const char *what)
 {
     *p = nullptr;
+    {   // a timed buffer left over from an earlier pick: the fastest that fits (and is not absurdly larger)
+        std::lock_guard<std::mutex> lk(c->ws_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int) c->ws_pool.size(); ++i)
+            if (c->ws_pool[i].bytes >= bytes && c->ws_pool[i].bytes <= 2 * bytes + (64u << 20) && (best < 0 || c->ws_pool[i].ms < c->ws_pool[best].ms)) best = i;
+        if (best >= 0) {
+            *p = c->ws_pool[best].ptr;
+            if (c->ws_verbose)
+                fprintf(stderr, "commet: %s, %.2f GB: from the pool (fill %.3f ms, %zu left)\n", what, bytes / 1e9, c->ws_pool[best].ms, c->ws_pool.size() - 1);
+            c->ws_pool.erase(c->ws_pool.begin() + best);
+            return hipSuccess;
+        }
+    }
     int n = std::max(1, std::min(candidates, 8));
     {   // never more candidates than the device holds with room to spare (several processes may share it)
         size_t fr = 0, tot = 0;
@@ -69,7 +101,7 @@ hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stre
     if (n > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return hipErrorUnknown;
     int got = 0;
     hipError_t err = hipSuccess;
-    double alloc_ms[8] = {0}, free_ms = 0;
+    double alloc_ms[8] = {0};
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int i = 0; i < n; ++i) {
         const double a0 = now_ms();
@@ -95,16 +127,17 @@ hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stre
     int best = 0;
     for (int i = 1; i < got; ++i)
         if (ms[i] > 0 && (ms[best] <= 0 || ms[i] < ms[best])) best = i;
-    const double f0 = now_ms();
-    for (int i = 0; i < got; ++i)
-        if (i != best) (void) hipFree(cand[i]);
-    free_ms = now_ms() - f0;
+    {
+        std::lock_guard<std::mutex> lk(c->ws_pool_mu);
+        for (int i = 0; i < got; ++i)
+            if (i != best) c->ws_pool.push_back({cand[i], bytes, ms[i]});
+    }
     if (c->ws_verbose) {
         fprintf(stderr, "commet: %s, %.2f GB, %d candidate(s), fill ms:", what, bytes / 1e9, got);
         for (int i = 0; i < got; ++i) fprintf(stderr, " %.3f%s", ms[i], i == best ? "*" : "");
         fprintf(stderr, "; hipMalloc ms:");
         for (int i = 0; i < got; ++i) fprintf(stderr, " %.1f", alloc_ms[i]);
-        fprintf(stderr, "; hipFree of the others %.1f ms\n", free_ms);
+        fprintf(stderr, "; the others wait in the pool\n");
     }
     *p = cand[best];
     (void) hipGetLastError();                               // (a failed extra candidate is not an error of the caller)

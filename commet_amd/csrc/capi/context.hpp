@@ -108,6 +108,7 @@ void commet_destroy(commet_ctx *c)
     (void) hipFree(c->d_idblk);
     c->part[0].release();
     c->part[1].release();
+    trim_ws_pool(c);
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
     if (c->load_stream) (void) hipStreamSynchronize(c->load_stream), (void) hipStreamDestroy(c->load_stream);
     if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);

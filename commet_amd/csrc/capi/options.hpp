@@ -93,6 +93,7 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
             w.bufA = w.bufB = nullptr;
             w.cap_keys = 0;
         }
+        trim_ws_pool(c);
         return 0;
     }
     if (!strcmp(name, "part_packed")) {

@@ -248,8 +248,10 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) {
             // reads sorted per round in LDS: as many as keep rpr * (first-hit windows per read) within TQ_FILL_CAP records
             const int64_t fhw = std::max<int64_t>(1, (int64_t) rs->max_len - (int64_t) t * c->k + 1);
-            uint32_t rpr = TQ_PIECE;
-            while (rpr > 1 && (uint64_t) rpr * (uint64_t) fhw > TQ_FILL_CAP) rpr /= 2;
+            // (even rounds: 256 reads x 37 windows = 9 472 records are two rounds of 128 reads, not 166 + 90)
+            const uint32_t rounds = (uint32_t) (((uint64_t) TQ_PIECE * (uint64_t) fhw + TQ_FILL_CAP - 1) / TQ_FILL_CAP);
+            uint32_t rpr = (TQ_PIECE + rounds - 1) / rounds;
+            while (rpr > 1 && (uint64_t) rpr * (uint64_t) fhw > TQ_FILL_CAP) --rpr;
             const size_t lds_fill = ((size_t) 4 * ql.n_slices + 2 * TQ_FILL_CAP) * 4;
             e = hipFuncSetAttribute(c->k <= 32 ? (const void *) tq_fill_kernel<uint32_t> : (const void *) tq_fill_kernel<uint64_t>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
@@ -257,10 +259,10 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
                 KScope ks(c, "tq_fill_kernel", c->stream);
                 if (c->k <= 32)
                     COMMET_LAUNCH(tq_fill_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
-                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tstart, ql.d_qaddr, ql.d_qwho);
                 else
                     COMMET_LAUNCH(tq_fill_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
-                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tile_off, ql.d_qaddr, ql.d_qwho);
+                                  ql.n_slices, ql.n_pieces, rpr, ql.d_tstart, ql.d_qaddr, ql.d_qwho);
                 e = hipGetLastError();
             }
         }

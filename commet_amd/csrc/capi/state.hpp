@@ -118,7 +118,10 @@ struct commet_ctx {
                                               // host thread while another runs jobs on sets that are complete
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
-    int ws_candidates = 4;                    // option / COMMET_WS_CANDIDATES: scatter workspaces allocated per buffer, the fastest kept (alloc_fastest)
+    int ws_candidates = 4;                    // option / COMMET_WS_CANDIDATES: buffers allocated and timed when a scatter workspace is first needed (alloc_fastest)
+    struct WsCand { void *ptr; size_t bytes; float ms; };
+    std::vector<WsCand> ws_pool;              // timed candidates not (yet) chosen: the next workspaces take the fastest that fits; freed when the job ends
+    std::mutex ws_pool_mu;
     bool ws_verbose = false;                  // COMMET_WS_VERBOSE: the candidates' fill times on stderr
 
     int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)

@@ -182,25 +182,27 @@ __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long
     tlen[i] = (uint16_t) (e - a);
 }
 
-// writes the records of piece blockIdx.x into its tiles (tile_off = the scanned counts).  The records of `rpr` reads at a
-// time are sorted by slice in LDS (counting sort) and every tile's share leaves as one run of consecutive lanes: written
-// record by record straight from the window loop, each 4-byte store reached HBM on its own (18.7 GB written for 3 GB of
-// records, 11 ms per 10 M-read set).
+// writes the records of piece blockIdx.x into its tiles.  The records of `rpr` reads at a time are sorted by slice in LDS
+// (counting sort) and leave as ONE flat sequence: thread j takes sorted records j, j + 256, ...; a record carries its slice, the
+// slice's place in the list (tstart, the piece-major copy of the tile bounds: one coalesced load per workgroup) and what earlier
+// rounds wrote sit in LDS.  History: written record by record straight from the window loop, each 4-byte store reached HBM on its
+// own (18.7 GB written for 3 GB of records, 11 ms per 10 M-read set); sorted in LDS but written slice by slice — a wave per slice,
+// each with a dependent 8-byte load of its tile's start and ~24 of 64 lanes busy — 5.6 ms.
 constexpr uint32_t TQ_FILL_CAP = 6144;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
 template <typename W>
 __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
-                                                      uint32_t rpr, const unsigned long long *__restrict__ tile_off,
+                                                      uint32_t rpr, const uint32_t *__restrict__ tstart,
                                                       uint32_t *__restrict__ qaddr, uint16_t *__restrict__ qwho)
 {
     static_assert(TQ_PIECE <= 256 && TQ_MAX_WIN <= 128, "qwho packs the read in 8 bits and the window in 7");
     extern __shared__ uint32_t fl[];
-    uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *done = fill + n_slices;   // n_slices each
-    uint32_t *rec_a = done + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
+    uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *dstb = fill + n_slices;   // n_slices each
+    uint32_t *rec_a = dstb + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
     __shared__ uint32_t wsum[16];
-    for (uint32_t i = threadIdx.x; i < n_slices; i += 256) done[i] = 0;
+    // where this piece's share of every slice starts (n_slices <= 1024 consecutive words)
+    for (uint32_t i = threadIdx.x; i < n_slices; i += 256) dstb[i] = tstart[(uint64_t) blockIdx.x * n_slices + i];
     const uint64_t r0 = (uint64_t) blockIdx.x * TQ_PIECE;
     const uint32_t smask = (1u << sbits) - 1u;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t rr = 0; rr < TQ_PIECE; rr += rpr) {
         for (uint32_t i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0, fill[i] = 0;
         __syncthreads();
@@ -214,20 +216,19 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
                 const uint32_t s = (uint32_t) (addr >> sbits);
                 const uint32_t at = base[s] + atomicAdd(&fill[s], 1u);
                 rec_a[at] = ((uint32_t) addr & smask) | (selfp ? 0x80000000u : 0u);
-                rec_w[at] = i | (win << 8);
+                rec_w[at] = i | (win << 8) | (s << 15);                  // read (8 bits) | window (7) | slice (<= 10)
             });
         __syncthreads();
-        for (uint32_t s = wave; s < n_slices; s += 4) {
-            const uint32_t n = cnt[s];
-            if (!n) continue;
-            const unsigned long long dst = tile_off[(uint64_t) s * n_pieces + blockIdx.x] + done[s];
-            for (uint32_t j = lane; j < n; j += 64) {
-                qaddr[dst + j] = rec_a[base[s] + j];
-                qwho[dst + j] = (uint16_t) rec_w[base[s] + j];
-            }
-            if (lane == 0) done[s] += n;
+        const uint32_t total = base[n_slices - 1] + cnt[n_slices - 1];
+        for (uint32_t j = threadIdx.x; j < total; j += 256) {
+            const uint32_t w = rec_w[j], s = w >> 15;
+            const uint32_t dst = dstb[s] + (j - base[s]);
+            qaddr[dst] = rec_a[j];
+            qwho[dst] = (uint16_t) (w & 0x7FFFu);
         }
         __syncthreads();
+        for (uint32_t s = threadIdx.x; s < n_slices; s += 256) dstb[s] += cnt[s];
+        // (the zeroing of cnt / fill at the top of the next round touches other arrays; its barrier orders these updates, too)
     }
 }
 

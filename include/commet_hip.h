@@ -201,8 +201,10 @@ int commet_index_and_search(commet_ctx *ctx,
  *   index_mode (0/1/2)   0 auto, 1 atomic-OR kernel, 2 bucketed (LDS-tile) construction
  *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
- *   ws_candidates (1..8) scatter workspaces allocated per buffer when a workspace is (re)allocated; each is filled once, timed,
- *                        the fastest kept, the others freed (default 4; how a multi-GB buffer is backed decides how fast
+ *   ws_candidates (1..8) buffers allocated and timed (one fill each) when a scatter workspace is first needed: the fastest becomes
+ *                        that workspace, the others serve the workspaces asked for next (the job's second buffer, the second
+ *                        index lane) fastest first, and what is left is freed when the job ends (default 4 = the four buffers
+ *                        of a two-lane context: no allocation beyond those; how a multi-GB buffer is backed decides how fast
  *                        kernels sweep it, and that is drawn per allocation)
  *   drop_workspaces      frees the scatter workspaces (the next bucketed index build allocates them again)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
