@@ -74,15 +74,23 @@ void trim_ws_pool(commet_ctx *c)
 hipError_t alloc_fastest(commet_ctx *c, void **p, size_t bytes, hipStream_t stream, int candidates, const char *what)
 {
     *p = nullptr;
-    {   // a timed buffer left over from an earlier pick: the fastest that fits (and is not absurdly larger)
+    {   // a timed buffer left over from an earlier pick: the fastest that fits.  A much larger one (the second lane's chunk is often a
+        // third of the first's) is taken, too, while the device has memory to spare: keeping it costs nothing then, freeing it is churn
+        size_t fr = 0, tot = 0;
+        const bool roomy = hipMemGetInfo(&fr, &tot) == hipSuccess && fr > ((size_t) 64 << 30);
         std::lock_guard<std::mutex> lk(c->ws_pool_mu);
         int best = -1;
-        for (int i = 0; i < (int) c->ws_pool.size(); ++i)
-            if (c->ws_pool[i].bytes >= bytes && c->ws_pool[i].bytes <= 2 * bytes + (64u << 20) && (best < 0 || c->ws_pool[i].ms < c->ws_pool[best].ms)) best = i;
+        for (int i = 0; i < (int) c->ws_pool.size(); ++i) {
+            const auto &b = c->ws_pool[i];
+            if (b.bytes < bytes || (!roomy && b.bytes > 2 * bytes + (64u << 20))) continue;
+            // (fill times of buffers of different sizes compare per byte)
+            if (best < 0 || b.ms / (double) b.bytes < c->ws_pool[best].ms / (double) c->ws_pool[best].bytes) best = i;
+        }
         if (best >= 0) {
             *p = c->ws_pool[best].ptr;
             if (c->ws_verbose)
-                fprintf(stderr, "commet: %s, %.2f GB: from the pool (fill %.3f ms, %zu left)\n", what, bytes / 1e9, c->ws_pool[best].ms, c->ws_pool.size() - 1);
+                fprintf(stderr, "commet: %s, %.2f GB: from the pool (%.2f GB, fill %.3f ms, %zu left)\n", what, bytes / 1e9, c->ws_pool[best].bytes / 1e9,
+                        c->ws_pool[best].ms, c->ws_pool.size() - 1);
             c->ws_pool.erase(c->ws_pool.begin() + best);
             return hipSuccess;
         }
