@@ -320,7 +320,7 @@ def matrix_size(args, ranks, root):
     return n, note
 
 
-def matrix_leg(args, ranks, n, note=None):
+def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
     """The full S x S matrix of S synthetic sets of n reads through the resident N x N driver, split over the ranks; sets written
     as FASTA to scratch (each rank generates its share), filter + load + jobs all timed by the driver."""
     from commet_amd import matrix, synth
@@ -349,6 +349,7 @@ def matrix_leg(args, ranks, n, note=None):
         gen_s = time.perf_counter() - t0
         progress(ranks, f"matrix leg: files written in {gen_s:.1f} s; filter + load + jobs")
         res = matrix.run(os.path.join(work, "sets.txt"), os.path.join(work, "out") + "/", k=args.k, t=args.t, ranks=ranks, verbose=False,
+                         fatal_hook=fatal_hook,
                          progress=lambda msg: print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] matrix leg, rank {ranks.rank}: {msg}",
                                                     file=sys.stderr, flush=True))
     except BaseException as ex:
@@ -677,7 +678,8 @@ def main():
                     matrix_c2 = matrix_leg(args, ranks, 10_000_000)
                 except Exception as ex:
                     matrix_c2 = {"error": f"{type(ex).__name__}: {ex}"}
-            matrix_detail = matrix_leg(args, ranks, n_m, note)
+            # (a rank whose import of another rank's set hangs ends itself from a watchdog thread: rank 0 prints the line first)
+            matrix_detail = matrix_leg(args, ranks, n_m, note, fatal_hook=lambda msg: (emit({"error": msg}, matrix_c2), sys.stdout.flush()))
         except Exception as ex:   # the headline measured above must not be lost with this extra leg
             import traceback
             traceback.print_exc()

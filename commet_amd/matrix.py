@@ -216,9 +216,11 @@ def _scratch_root():
 
 
 def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ranks=None, verbose=True,
-        engine_factory=None, progress=None):
+        engine_factory=None, progress=None, fatal_hook=None):
     """progress: optional callable(str), called on every rank at the stages of the run (a caller that keeps stdout for itself —
-    bench.py — shows a long run is alive with it)"""
+    bench.py — shows a long run is alive with it).
+    fatal_hook: optional callable(str), called from a watchdog thread right before this process is ended with os._exit because a
+    HIP call of it does not return (an import of another rank's set): the caller's last chance to say what it has to say"""
     t_start = time.perf_counter()
     own_ranks = ranks is None
     if ranks is None:
@@ -327,7 +329,13 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         COMMET_IPC_LOCK=1 also takes a lock file of the node around the import (one import at a time on the node: a round-3
         precaution against two processes attaching to each other's buffers at the same moment, never needed without torch)."""
         def give_up():
-            print(f"commet_amd.matrix, rank {rank}: commet_readset_import did not return within {limit:.0f} s; leaving", file=sys.stderr, flush=True)
+            msg = f"commet_amd.matrix, rank {rank}: commet_readset_import did not return within {limit:.0f} s; leaving"
+            print(msg, file=sys.stderr, flush=True)
+            if fatal_hook is not None:
+                try:
+                    fatal_hook(msg)
+                except Exception:
+                    pass
             for s_ in owned:
                 for ext in ("pk", "ipc"):
                     try:

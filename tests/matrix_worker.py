@@ -17,7 +17,8 @@ def main():
     if len(sys.argv) > 5:
         OracleEngine.fail_on_rank = int(sys.argv[5])
     try:
-        res = matrix.run(sets, out, k=k, t=t, verbose=False, engine_factory=OracleEngine)
+        res = matrix.run(sets, out, k=k, t=t, verbose=False, engine_factory=OracleEngine,
+                         fatal_hook=lambda msg: open(os.path.join(out, f"last_words_rank{os.environ.get('RANK', '0')}.txt"), "w").write(msg))
     except BaseException:
         traceback.print_exc()
         sys.stderr.flush()

@@ -48,6 +48,9 @@ class OracleEngine:
         return pickle.dumps(rs)
 
     def import_set(self, blob):
+        if os.environ.get("COMMET_TEST_IMPORT_HANG") == str(self.rank) and pickle.loads(blob)["files"]:   # (not the probe set)
+            import time
+            time.sleep(600)                      # a HIP call that never returns
         return pickle.loads(blob)
 
     # the driver's canary (a fresh child process that imports the first real set before a rank does): tests choose its fate

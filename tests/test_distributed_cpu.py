@@ -217,6 +217,22 @@ def test_a_rank_that_raises_tells_the_others(tmp_path):
     assert time.time() - t0 < 60
 
 
+def test_an_import_that_never_returns_ends_the_rank_after_its_last_words(tmp_path):
+    """rank 0's import of another rank's set hangs (a HIP call cannot be cancelled): after COMMET_IPC_IMPORT_LIMIT_S the rank's
+    watchdog calls the caller's fatal_hook (bench.py prints its headline there) and ends the process with code 4; the launcher
+    ends the job"""
+    import time
+    k, t, names, files, bvs = _matrix_case(tmp_path)
+    t0 = time.time()
+    p = _launch(2, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", "out/", str(k), str(t)], str(tmp_path), timeout=300,
+                launcher="spawn", extra_env={"COMMET_TEST_IMPORT_HANG": "0", "COMMET_IPC_IMPORT_LIMIT_S": "2"})
+    out = p.stdout.decode()
+    assert p.returncode == 4, out[-2000:]
+    assert "commet_readset_import did not return within 2 s" in out
+    assert "did not return" in open(tmp_path / "out" / "last_words_rank0.txt").read()
+    assert time.time() - t0 < 60
+
+
 def test_store_tells_the_ranks_when_one_of_them_is_gone(tmp_path):
     """no launcher to end the group: three ranks started by hand, rank 2 leaves without a word while the others wait at a
     barrier — the store answers their wait with an error at once (not after COMMET_DIST_TIMEOUT_S)"""
