@@ -248,7 +248,7 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) {
             // reads sorted per round in LDS: as many as keep rpr * (first-hit windows per read) within TQ_FILL_CAP records
             const int64_t fhw = std::max<int64_t>(1, (int64_t) rs->max_len - (int64_t) t * c->k + 1);
-            // (even rounds: 256 reads x 37 windows = 9 472 records are two rounds of 128 reads, not 166 + 90)
+            // (even rounds: e.g. 256 reads x 87 windows = 22 272 records are three rounds of 86 reads)
             const uint32_t rounds = (uint32_t) (((uint64_t) TQ_PIECE * (uint64_t) fhw + TQ_FILL_CAP - 1) / TQ_FILL_CAP);
             uint32_t rpr = (TQ_PIECE + rounds - 1) / rounds;
             while (rpr > 1 && (uint64_t) rpr * (uint64_t) fhw > TQ_FILL_CAP) --rpr;

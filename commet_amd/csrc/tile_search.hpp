@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long
 // slice's place in the list (tstart, the piece-major copy of the tile bounds: one coalesced load per workgroup) and what earlier
 // rounds wrote sit in LDS.  History: written record by record straight from the window loop, each 4-byte store reached HBM on its
 // own (18.7 GB written for 3 GB of records, 11 ms per 10 M-read set); sorted in LDS but written slice by slice — a wave per slice,
-// each with a dependent 8-byte load of its tile's start and ~24 of 64 lanes busy — 5.6 ms.
-constexpr uint32_t TQ_FILL_CAP = 6144;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
+// each with a dependent 8-byte load of its tile's start and ~24 of 64 lanes busy — 5.6 ms; flat, two rounds per piece 2.5 ms.
+#ifndef COMMET_TQ_FILL_CAP
+#define COMMET_TQ_FILL_CAP 9600   // a whole piece of 100-bp reads at k = 32, t = 2 (256 x 37 records) in ONE round: 1.94 ms per 10 M-read set against 2.59 with 6144 (two rounds of 128 reads) and 2.58 with 4800; 81 KB of LDS, two workgroups per CU
+#endif
+constexpr uint32_t TQ_FILL_CAP = COMMET_TQ_FILL_CAP;    // records sorted per round: rpr * (first-hit windows per read) <= TQ_FILL_CAP
 template <typename W>
 __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t, int sbits, uint32_t n_slices, uint32_t n_pieces,
                                                       uint32_t rpr, const uint32_t *__restrict__ tstart,
