@@ -5,11 +5,13 @@ holds reads.  The rank waits for this process with a deadline and kills it when 
 itself first.  Round 3 saw that call hang for good on sets of 50 M reads (never on small ones, which is why the probe set of
 the ranks is not enough) in processes that held torch's own ROCm runtime beside the system's.
 
-  python -m commet_amd.ipc_canary <device> <k> <t> <scratch dir> <set numbers, comma separated>
+  python commet_amd/ipc_canary.py <device> <k> <t> <scratch dir> <set numbers, comma separated>
 """
 import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # started by path from any working directory
 
 
 def main(argv):

@@ -175,7 +175,8 @@ class HipEngine:
 
     def canary_argv(self, scratch, candidates):
         """the command of the fresh child process that imports the first real set before this process does (ipc_canary.py)"""
-        return [sys.executable, "-m", "commet_amd.ipc_canary", str(self.ctx.device), str(self.ctx.k), str(self.ctx.t), scratch,
+        # (by path, not `-m`: the child's working directory need not be one from which the package can be imported)
+        return [sys.executable, os.path.join(HERE, "ipc_canary.py"), str(self.ctx.device), str(self.ctx.k), str(self.ctx.t), scratch,
                 ",".join(str(c) for c in candidates)]
 
     def same_set(self, a, b):
