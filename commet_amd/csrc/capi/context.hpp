@@ -39,6 +39,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (const char *e = getenv("COMMET_TQ_SBITS")) c->tq_sbits = atoi(e);
     if (const char *e = getenv("COMMET_TQ_WPX")) c->tq_wpx = (unsigned) std::max(1, atoi(e));
     if (const char *e = getenv("COMMET_TQ_PARTS")) c->tq_parts = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = getenv("COMMET_LANE_STAGGER")) c->lane_stagger = atoi(e) != 0;
     if (const char *e = getenv("COMMET_WS_CANDIDATES")) c->ws_candidates = std::max(1, std::min(8, atoi(e)));
     c->ws_verbose = getenv("COMMET_WS_VERBOSE") != nullptr;
     c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
@@ -74,6 +75,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->load_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream);
     if (e != hipSuccess) {
@@ -111,6 +113,7 @@ void commet_destroy(commet_ctx *c)
     trim_ws_pool(c);
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
     if (c->load_stream) (void) hipStreamSynchronize(c->load_stream), (void) hipStreamDestroy(c->load_stream);
+    if (c->ev_stagger) (void) hipEventDestroy(c->ev_stagger);
     if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void) hipEventDestroy(c->ev_join);
     if (c->d_counters) (void) hipFree(c->d_counters);

@@ -63,6 +63,10 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     else d_ids = nullptr;
     commet_ctx::PartWs &ws = c->part[lane];
     hipStream_t stream = lane ? c->aux_stream : c->stream;
+    if (lane == 1 && c->stagger_armed) {   // (see behind scatter1 below)
+        HIP_OK(hipStreamWaitEvent(stream, c->ev_stagger, 0));
+        c->stagger_armed = false;
+    }
     uint32_t *const slot = c->slot_ptr(c->cur_slot);
     PartGeom g = make_geom(c->k);
     g.xcd_swizzle = c->s2_swizzle;
@@ -153,6 +157,14 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         KScope ks(c, "part_scatter1_kernel", stream);
         note_launch(fn);
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));
+    }
+    // Two lanes, staggered: the chunk on the second lane starts when this one's scatter1 is through, so that its hist and
+    // scatter1 (VALU, LDS atomics, a write pattern) run beside this chunk's scatter2 and build (HBM streams) instead of beside
+    // the same phases of this chunk.  Four boxes, configs[1], per step: -0.36, -0.25, 0.0 and +0.04 ms (the slower the box's
+    // draw, the more); a 2 x 50 M-read pair 169.4 -> 168.1 ms.  Staggering behind hist instead: +0.5 ms.
+    if (c->lane_stagger && lane == 0 && c->ev_stagger) {
+        HIP_OK(hipEventRecord(c->ev_stagger, stream));
+        c->stagger_armed = true;
     }
     if (COMMET_ABLATE & 31) return 0;   // ablation builds only: scatter1 left garbage in bufA, nothing downstream may consume it
     if (g.b2) {

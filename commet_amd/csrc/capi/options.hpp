@@ -80,6 +80,10 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->index_lanes = (int) value;
         return 0;
     }
+    if (!strcmp(name, "lane_stagger")) {      // 1 = the second index lane's chunk starts behind the first lane's scatter1 (default), 0 = both at once
+        c->lane_stagger = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "ws_candidates")) {     // scatter workspaces allocated per buffer, the fastest kept (1 = take the first); applies to
         if (value < 1 || value > 8) return fail("ws_candidates must be in [1, 8]");   // workspaces allocated from now on
         c->ws_candidates = (int) value;

@@ -118,6 +118,9 @@ struct commet_ctx {
                                               // host thread while another runs jobs on sets that are complete
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int index_lanes = 2;                      // option: 1 = build the chunks of a group one after the other
+    int lane_stagger = 1;                     // option / COMMET_LANE_STAGGER: the second lane's chunk starts behind the first lane's scatter1 (index_dispatch.hpp)
+    bool stagger_armed = false;
+    hipEvent_t ev_stagger = nullptr;
     int ws_candidates = 4;                    // option / COMMET_WS_CANDIDATES: buffers allocated and timed when a scatter workspace is first needed (alloc_fastest)
     struct WsCand { void *ptr; size_t bytes; float ms; };
     std::vector<WsCand> ws_pool;              // timed candidates not (yet) chosen: the next workspaces take the fastest that fits; freed when the job ends

@@ -201,6 +201,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *   index_mode (0/1/2)   0 auto, 1 atomic-OR kernel, 2 bucketed (LDS-tile) construction
  *   part_min_kmers       auto mode: chunks with fewer k-mers take the atomic kernel
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
+ *   lane_stagger (0/1)   two lanes: the second lane's chunk starts when the first lane's scatter1 is through (default 1), so that
+ *                        its VALU-bound phases run beside the first chunk's HBM-bound ones; 0 = both chunks start together
  *   ws_candidates (1..8) buffers allocated and timed (one fill each) when a scatter workspace is first needed: the fastest becomes
  *                        that workspace, the others serve the workspaces asked for next (the job's second buffer, the second
  *                        index lane) fastest first, and what is left is freed when the job ends (default 4 = the four buffers
