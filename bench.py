@@ -458,19 +458,22 @@ def main():
     stats, info = last["stats"], last["info"]
 
     # the first job on a SET also builds what is cached with the set (the tiled search's query list): not part of the
-    # steady-state `value`, reported beside it — the list is dropped, then one more job is timed (warm context)
-    # (twice, the faster one counts: a hipMalloc of the list's 2 GB right after the hipFree of the old one now and then blocks for
-    # 50-150 ms on this driver — an allocator artefact of dropping and rebuilding, which no real first job does)
+    # steady-state `value`, reported beside it (warm context) —
+    # measured on a FRESH copy of the search set (made outside the clock), twice, the faster one counts: dropping the resident
+    # set's list and building it again would time the allocator instead — a hipMalloc of the list's 2 GB right after the
+    # hipFree of the old one blocks for 50-150 ms now and then on this driver, which no real first job meets
     query_list_bytes = qrs.cache_bytes
-    first_job_s = None
+    first_job_s, fresh_sets = None, []
     for _ in range(2):
-        qrs.drop_cache()
+        fresh_sets.append(commet_amd.ReadSet.from_files(ctx, [(b1, o1)]))      # (both stay alive until both are timed: nothing is freed in between)
         ctx.synchronize()
         t_c = time.perf_counter()
-        ctx.index_and_search(irs, [qrs])
+        ctx.index_and_search(irs, [fresh_sets[-1]])
         ctx.synchronize()
         dt = time.perf_counter() - t_c
         first_job_s = dt if first_job_s is None else min(first_job_s, dt)
+    for fs in fresh_sets:
+        fs.close()
 
     # ---- untimed extras (rank 0): P_ref, per-kernel times, the random-gather ceiling ---------------------------
     probes, ktimes, gather_ceiling = None, None, None
