@@ -76,6 +76,8 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->load_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->list_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(c->filter, 0, c->filter_bytes, c->stream);
     if (e != hipSuccess) {
@@ -114,6 +116,9 @@ void commet_destroy(commet_ctx *c)
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
     if (c->load_stream) (void) hipStreamSynchronize(c->load_stream), (void) hipStreamDestroy(c->load_stream);
     if (c->ev_stagger) (void) hipEventDestroy(c->ev_stagger);
+    if (c->list_stream) (void) hipStreamSynchronize(c->list_stream), (void) hipStreamDestroy(c->list_stream);
+    if (c->ev_list) (void) hipEventDestroy(c->ev_list);
+    (void) hipFree(c->d_ql_totals);
     if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void) hipEventDestroy(c->ev_join);
     if (c->d_counters) (void) hipFree(c->d_counters);

@@ -198,6 +198,11 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
     ql.n_pieces = (uint32_t) ((rs->n_reads + TQ_PIECE - 1) / TQ_PIECE);
     const uint64_t entries = (uint64_t) ql.n_slices * ql.n_pieces;
     const uint32_t nb = (uint32_t) ((entries + 4095) / 4096);
+    // The list is built on a stream of its own: at this point the job's index kernels are queued on the main streams, and the
+    // list's kernels (VALU and LDS work on the SEARCH set) run beside them instead of behind them; the main stream waits for the
+    // list before the probe (ev_list).  Nothing here may synchronise the device: the scan's block totals live in a scratch
+    // buffer kept with the context (a hipFree would wait for the index build).
+    hipStream_t ls = c->list_stream;
     unsigned long long *d_totals = nullptr;
     // (the caller holds ql_mu: on an allocation failure here the other sets' lists are given back directly)
     auto alloc = [&](void **ptr, size_t bytes) -> hipError_t {
@@ -210,29 +215,35 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         return ae;
     };
     hipError_t e = alloc((void **) &ql.d_tile_off, (entries + 1) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = alloc((void **) &d_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess && c->ql_totals_cap < (uint64_t) nb + 1) {
+        (void) hipFree(c->d_ql_totals);                     // (grows a few times in a context's life)
+        c->d_ql_totals = nullptr, c->ql_totals_cap = 0;
+        e = alloc((void **) &c->d_ql_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
+        if (e == hipSuccess) c->ql_totals_cap = (uint64_t) nb + 1;
+    }
+    d_totals = c->d_ql_totals;
     if (e == hipSuccess) {
         const int t = t_eff(c, rs);
         const size_t lds = (size_t) ql.n_slices * 4;
         {
-            KScope ks(c, "tq_count_kernel", c->stream);
+            KScope ks(c, "tq_count_kernel", ls);
             if (c->k <= 32)
-                COMMET_LAUNCH(tq_count_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                COMMET_LAUNCH(tq_count_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds, ls, rs->view(), c->k, t, ql.sbits, ql.n_slices,
                               ql.n_pieces, ql.d_tile_off);
             else
-                COMMET_LAUNCH(tq_count_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds, c->stream, rs->view(), c->k, t, ql.sbits, ql.n_slices,
+                COMMET_LAUNCH(tq_count_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds, ls, rs->view(), c->k, t, ql.sbits, ql.n_slices,
                               ql.n_pieces, ql.d_tile_off);
         }
         {
-            KScope ks(c, "tq_scan_kernels", c->stream);
-            COMMET_LAUNCH(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals);
-            COMMET_LAUNCH(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, c->stream, d_totals, nb, d_totals + nb);
-            COMMET_LAUNCH(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, ql.d_tile_off, entries, d_totals, d_totals + nb);
+            KScope ks(c, "tq_scan_kernels", ls);
+            COMMET_LAUNCH(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, ls, ql.d_tile_off, entries, d_totals);
+            COMMET_LAUNCH(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, ls, d_totals, nb, d_totals + nb);
+            COMMET_LAUNCH(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, ls, ql.d_tile_off, entries, d_totals, d_totals + nb);
         }
         e = hipGetLastError();
         unsigned long long total = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_totals + nb, sizeof total, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_totals + nb, sizeof total, hipMemcpyDeviceToHost, ls);
+        if (e == hipSuccess) e = hipStreamSynchronize(ls);
         ql.n_records = total;
         if (e == hipSuccess && total >= (1ull << 32)) e = hipErrorOutOfMemory;   // tstart is 32 bits (tiled_ok keeps such sets out; before any large allocation)
         if (e == hipSuccess) e = alloc((void **) &ql.d_qaddr, std::max<uint64_t>(total, 1) * 4);
@@ -240,8 +251,8 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
         if (e == hipSuccess) e = alloc((void **) &ql.d_tstart, std::max<uint64_t>(entries, 1) * 4);
         if (e == hipSuccess) e = alloc((void **) &ql.d_tlen, std::max<uint64_t>(entries, 1) * 2);
         if (e == hipSuccess) {
-            KScope ks(c, "tq_bounds_kernel", c->stream);
-            COMMET_LAUNCH(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, c->stream, ql.d_tile_off, ql.n_slices,
+            KScope ks(c, "tq_bounds_kernel", ls);
+            COMMET_LAUNCH(tq_bounds_kernel, dim3((unsigned) ((entries + 255) / 256)), dim3(256), 0, ls, ql.d_tile_off, ql.n_slices,
                                ql.n_pieces, ql.d_tstart, ql.d_tlen);
             e = hipGetLastError();
         }
@@ -256,18 +267,19 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
             e = hipFuncSetAttribute(c->k <= 32 ? (const void *) tq_fill_kernel<uint32_t> : (const void *) tq_fill_kernel<uint64_t>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fill);
             if (e == hipSuccess) {
-                KScope ks(c, "tq_fill_kernel", c->stream);
+                KScope ks(c, "tq_fill_kernel", ls);
                 if (c->k <= 32)
-                    COMMET_LAUNCH(tq_fill_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                    COMMET_LAUNCH(tq_fill_kernel<uint32_t>, dim3(ql.n_pieces), dim3(256), lds_fill, ls, rs->view(), c->k, t, ql.sbits,
                                   ql.n_slices, ql.n_pieces, rpr, ql.d_tstart, ql.d_qaddr, ql.d_qwho);
                 else
-                    COMMET_LAUNCH(tq_fill_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds_fill, c->stream, rs->view(), c->k, t, ql.sbits,
+                    COMMET_LAUNCH(tq_fill_kernel<uint64_t>, dim3(ql.n_pieces), dim3(256), lds_fill, ls, rs->view(), c->k, t, ql.sbits,
                                   ql.n_slices, ql.n_pieces, rpr, ql.d_tstart, ql.d_qaddr, ql.d_qwho);
                 e = hipGetLastError();
             }
         }
     }
-    (void) hipFree(d_totals);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_list, ls);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_list, 0);   // whatever the caller queues next (the probe) finds the list complete
     if (e != hipSuccess) {   // no room for the list (or a launch failed): this set keeps the gather kernels
         (void) hipGetLastError();
         ql.release();

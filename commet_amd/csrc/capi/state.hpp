@@ -176,6 +176,10 @@ struct commet_ctx {
     uint32_t *slice_stage = nullptr, *slice_tables = nullptr;
     SliceChunk *d_slice_chunks = nullptr;
     uint64_t slice_stage_words = 0, slice_table_words = 0, slice_chunks_cap = 0;
+    hipStream_t list_stream = nullptr;        // query lists are built here, beside the job's index kernels (build_query_list)
+    hipEvent_t ev_list = nullptr;
+    unsigned long long *d_ql_totals = nullptr;   // scratch of the list build's scan, kept (no hipFree on the job path)
+    uint64_t ql_totals_cap = 0;
     uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
     uint64_t qres_cap = 0;
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
