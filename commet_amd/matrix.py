@@ -238,15 +238,26 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
     if l < k * t and l != 0:                                      # Commet.py:509-513 (l stays 0 by default)
         l = k * t
-    # ---- filter step (Commet.py:103-121): one filter_reads per file, dealt over the ranks -------------
+    # ---- who does what: pairs in contiguous runs of equal cost, every set parsed by one rank (sharding.assign_owners) ----
+    pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
+    size = [float(sum(os.path.getsize(f) for f in fl)) for fl in files]   # cost proxy known before any parsing
+    pair_cost = [size[a] + size[b] for a, b in pairs]
+    runs = sharding.assign_pairs_contiguous(pair_cost, world)
+    mine = [pairs[c] for c in runs[rank]]
+    needed = sorted({s for p in mine for s in p})
+    owner = sharding.assign_owners(N, world, [sum(pair_cost[c] for c in runs[r]) for r in range(world)])
+    owned = [s for s in range(N) if owner[s] == rank]
+    needed_by_others = {s for r in range(world) if r != rank for c in runs[r] for s in pairs[c]}
+
+    # ---- filter step (Commet.py:103-121): one filter_reads per file, run by the rank that parses the set ---------
     t_filter = time.perf_counter()
     filter_err = []
     if bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
         cmds = []
-        for q, (s, j) in enumerate(todo):
-            if q % world != rank:
+        for s, j in todo:
+            if owner[s] != rank:                                   # (the set's parser filters its files, too: one producer per set)
                 continue
             cmd = [os.path.join(bin_dir, "filter_reads"), files[s][j], "-l", str(l), "-e", str(e)]
             if n >= 0:
@@ -300,17 +311,6 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             finally:
                 filter_pool.shutdown(wait=True)
             filter_s = (filter_end[0] if filter_jobs else time.perf_counter()) - t_filter
-
-    # ---- who does what: pairs in contiguous runs of equal cost, every set parsed by one rank (sharding.assign_owners) ----
-    pairs = [(ref, i) for ref in range(N - 1) for i in range(ref + 1, N)]
-    size = [float(sum(os.path.getsize(f) for f in fl)) for fl in files]   # cost proxy known before any parsing
-    pair_cost = [size[a] + size[b] for a, b in pairs]
-    runs = sharding.assign_pairs_contiguous(pair_cost, world)
-    mine = [pairs[c] for c in runs[rank]]
-    needed = sorted({s for p in mine for s in p})
-    owner = sharding.assign_owners(N, world, [sum(pair_cost[c] for c in runs[r]) for r in range(world)])
-    owned = [s for s in range(N) if owner[s] == rank]
-    needed_by_others = {s for r in range(world) if r != rank for c in runs[r] for s in pairs[c]}
 
     scratch = None
     if world > 1:
