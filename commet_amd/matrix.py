@@ -83,6 +83,21 @@ def write_bv(path, comment, n, bits):
         fh.write(np.ascontiguousarray(bits[:n // 8 + 1], dtype=np.uint8).tobytes())
 
 
+def default_filter_bv(path, read_file, n):
+    """What `filter_reads <read_file> -l 0 -e 0 -o <path>` writes (filter_reads.cpp:160-176, boolean_vector.h:148-164, 302-346): with the
+    default options no read can be removed, so the vector is all ones over the file's n reads (padding bits cleared) behind the tool's
+    comment block — written from the parser's record count instead of a second pass over the file.  Returns the bits."""
+    bits = np.full(n // 8 + 1, 0xFF, dtype=np.uint8)
+    bits[-1] = (1 << (n & 7)) - 1                                   # bits n .. of the last byte (all of it when n % 8 == 0) are padding
+    i = read_file.rfind("/")
+    comment = ("----------------\nReference file\n  " + (read_file[i + 1:] if i > 0 else read_file) + "\nFilter Options\n"
+               "  min read size     : 0\n  max number of N   : infinite\n  min shannon index : 0\n")
+    if path is not None:
+        write_bv(path + ".part", comment, n, bits)
+        os.rename(path + ".part", path)
+    return bits
+
+
 def popcount(bits, n):
     return int(np.unpackbits(bits[:n // 8 + 1], bitorder="little")[:n].sum())
 
@@ -252,7 +267,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # ---- filter step (Commet.py:103-121): one filter_reads per file, run by the rank that parses the set ---------
     t_filter = time.perf_counter()
     filter_err = []
-    if bvs is None:
+    # Commet.py's default options (-l 0 -e 0, no -n, no -m) remove no read: the filter vectors are then all ones over each file's
+    # reads and are written from the parser's record counts by the set's owner (default_filter_bv: the tool's bytes, tested), every
+    # rank derives the same selection from the counts of the set it holds — no second pass over the files, nothing to wait for.
+    # COMMET_MATRIX_FILTER_TOOL=1 runs filter_reads all the same.
+    synth_filters = bvs is None and l == 0 and e == 0 and n < 0 and m < 0 and os.environ.get("COMMET_MATRIX_FILTER_TOOL", "0") != "1"
+    if synth_filters:
+        bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
+        filter_pool, filter_jobs, filtered_here = None, [], False
+    elif bvs is None:
         bvs = [[out_dir + os.path.basename(f) + ".bv" for f in fl] for fl in files]
         todo = [(s, j) for s in range(N) for j in range(len(files[s]))]
         cmds = []
@@ -417,6 +440,12 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         sets = {}
         solo = pipelined and world == 1                           # (then the loading thread parses, too)
 
+        def leave_filters(s, rs):
+            """default options: the filter files of a set this rank has just parsed, from its record counts"""
+            if synth_filters:
+                for c_, f_, b_ in zip(eng.file_reads(rs), files[s], bvs[s]):
+                    default_filter_bv(b_, f_, c_)
+
         def parse_own(s):
             """one of this rank's sets: parsed here and nowhere else; its packed image published for the ranks that need it
             (commet_readset_save writes a .tmp and renames it: the file appears complete or not at all)"""
@@ -424,6 +453,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             rs = eng.parse(files[s])
             prof["parse_s"] += time.perf_counter() - w0
             prof["sets_parsed"] += 1
+            leave_filters(s, rs)
             if s in needed_by_others:
                 w0 = time.perf_counter()
                 if use_ipc:                                       # a small descriptor file; the set stays alive for the importers
@@ -455,7 +485,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 for b in bvs[s]:
                     if not wait_file(b, f"the filter of set {s}", where=os.path.dirname(b)):
                         return False
-            parts = [read_bv(b) for b in bvs[s]]
+            if synth_filters:                                     # all ones (the set's owner has left the files: leave_filters)
+                parts = [(c, default_filter_bv(None, f, c)) for c, f in zip(counts[s], files[s])]
+            else:
+                parts = [read_bv(b) for b in bvs[s]]
             considered[s] = sum(popcount(b, nb) for nb, b in parts)
             for (nb, _), c, f in zip(parts, counts[s], files[s]):
                 if nb != c:
@@ -613,6 +646,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             sets[s] = eng.parse(files[s])
                             prof["parse_s"] += time.perf_counter() - w0
                             prof["sets_parsed"] += 1
+                            leave_filters(s, sets[s])
                         elif s not in sets and not fetch(s):
                             break
                         if not prepare(s):

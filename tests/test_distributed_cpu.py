@@ -342,6 +342,32 @@ def test_matrix_driver_single_rank_loader_failure_reaches_the_caller(tmp_path, m
     assert time.time() - t0 < 60
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_default_filter_vectors_equal_the_tools(tmp_path, world):
+    """Commet.py's default filter options remove no read: the driver writes the filter .bv files from the parser's record
+    counts (matrix.default_filter_bv) instead of running filter_reads over every file again.  Same bytes as the tool's
+    (COMMET_MATRIX_FILTER_TOOL=1 runs it), for FASTA / FASTQ / gzip files, read counts that are and are not multiples of 8,
+    sets of several files; and the same results behind them.  One rank and three."""
+    import filecmp
+    import numpy as np
+    import util
+    rng = np.random.default_rng(3)
+    reads = [util.random_reads(rng, n, 30, 120, n_rate=0.02) for n in (1501, 800, 64, 7)]
+    for name, r, fmt in (("a.fa", reads[0], "fa"), ("b.fq", reads[1], "fq"), ("c.fa.gz", reads[2], "fa.gz"), ("d.fa", reads[3], "fa")):
+        util.write_reads(str(tmp_path / name), r, fmt, rng=rng)
+    (tmp_path / "sets.txt").write_text("A: a.fa; d.fa\nB: b.fq\nC: c.fa.gz\n")
+    for out, env in (("out_s/", {}), ("out_t/", {"COMMET_MATRIX_FILTER_TOOL": "1"})):
+        p = _launch(world, [os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", out, "20", "2"], str(tmp_path), launcher="spawn", extra_env=env) \
+            if world > 1 else subprocess.run([sys.executable, os.path.join(ROOT, "tests", "matrix_worker.py"), "sets.txt", out, "20", "2"], cwd=str(tmp_path),
+                                             env=dict({k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK")}, **env),
+                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+    names = sorted(f for f in os.listdir(tmp_path / "out_t") if f.endswith((".bv", ".csv")))
+    assert [f for f in names if "_in_" not in f and f.endswith(".bv")] == ["a.fa.bv", "b.fq.bv", "c.fa.gz.bv", "d.fa.bv"]
+    assert not [f for f in names if not filecmp.cmp(tmp_path / "out_t" / f, tmp_path / "out_s" / f, shallow=False)]
+    assert sorted(f for f in os.listdir(tmp_path / "out_s") if f.endswith((".bv", ".csv"))) == names
+
+
 def test_bench_matrix_leg_sizes_itself_to_the_host(tmp_path):
     """the default matrix leg (10 x 50 M reads as FASTA in the scratch root when there are several GPUs) must not drive the host out of
     memory: what it needs is priced and compared with what the host has free"""
