@@ -709,6 +709,12 @@ def main():
 
     emit(matrix_detail, matrix_c2)
 
+    if world > 1 and ranks.failed:
+        # the matrix leg lost a rank (its error is in the line): a thread of this process may still sit in a HIP call that never
+        # returns (an import from a rank that has left), so no teardown — the headline is out, leave
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     ranks.close()
 
 

@@ -557,6 +557,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         def fetch(s):
             """another rank's set: from its owner's device buffers, or from its packed image; False: this rank is stopping"""
             ipc_path, pk_path = os.path.join(scratch, f"set{s}.ipc"), os.path.join(scratch, f"set{s}.pk")
+            if hasattr(ranks, "check"):
+                ranks.check()                                     # (no import from a job that has lost a rank: its owner may be leaving)
             if hand["ipc"]:
                 if not wait_file(ipc_path, f"the descriptor of set {s}"):
                     return False
@@ -667,9 +669,13 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         def wait_for(s):
             if loader is not None:
                 w0 = time.perf_counter()
+                polls = 0
                 while not ready[s].wait(0.05):
                     if filter_err:                               # a filter_reads process of this rank failed
                         raise filter_err[0]
+                    polls += 1
+                    if world > 1 and polls % 5 == 0 and hasattr(ranks, "check"):
+                        ranks.check()                            # (has a rank given up?  Its sets will never come)
                 set_wait[0] += time.perf_counter() - w0
                 if load_err:
                     raise load_err[0]
@@ -781,10 +787,17 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             ranks.abort(f"{type(ex).__name__}: {ex}")
         raise
     finally:
+        failed = sys.exc_info()[0] is not None
         if stop_ev is not None:
             stop_ev.set()
+        if failed and world > 1 and exported:
+            # the other ranks may be in the middle of importing a set of this one: they notice the abort within a quarter of a second
+            # and start no new import; what is under way takes tens of ms.  An exporter that left at once would leave them in a HIP
+            # call that never returns (seen: 120 s until their own watchdog).
+            time.sleep(float(os.environ.get("COMMET_ABORT_LINGER_S", "2")))
         if loader is not None and loader.is_alive():             # (an error in the job thread)
-            loader.join()
+            loader.join(timeout=5.0 if failed else None)
+        stuck = loader is not None and loader.is_alive()         # in a HIP call that does not return: the process is on its way out
         if server is not None and server.is_alive():
             serve_stop.set()
             server.join()
@@ -792,7 +805,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             canary.kill()
         if filter_pool is not None:
             filter_pool.shutdown(wait=True, cancel_futures=True)
-        eng.close()
+        if not stuck:
+            eng.close()                                          # (never under a thread that is still inside the library)
         if scratch is not None:
             # rank 0 removes the scratch directory once everybody is through; a failing rank removes its own images
             if sys.exc_info()[0] is None and not getattr(ranks, "failed", False):
