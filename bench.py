@@ -362,6 +362,8 @@ def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
             os.environ["COMMET_SCRATCH"] = saved_scratch
         if not ranks.failed:
             ranks.barrier()
+        if ranks.failed and ranks.world > 1:
+            time.sleep(3.0)                             # (the other ranks notice within a second and are out of their jobs by then)
         if ranks.rank == 0 or ranks.failed:             # (a failed job: whoever gets here removes what is left)
             shutil.rmtree(work, ignore_errors=True)
         _WORK_DIRS.remove(work)

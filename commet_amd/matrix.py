@@ -784,6 +784,11 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         # with several ranks: tell the others at once (their waits end with an error naming this rank) instead of leaving them in a
         # gather until the timeout
         if world > 1 and hasattr(ranks, "abort"):
+            if not isinstance(ex, RuntimeError) or "rendezvous" not in str(ex):
+                try:                                              # what this rank ran into may only be the wake of another rank's failure
+                    ranks.check()                                 # (scratch gone under its feet): then THAT is the error to report
+                except RuntimeError as first:
+                    raise first from ex
             ranks.abort(f"{type(ex).__name__}: {ex}")
         raise
     finally:
