@@ -165,6 +165,12 @@ class HipEngine:
         # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
         self._api = commet_amd
         self.ctx = commet_amd.Context(k=k, t=t, device=int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if "COMMET_FORCE_DEVICE" in os.environ and world > 1:
+            # several ranks on ONE device (a rehearsal): the cached query lists of all of them must fit it together — no rank can
+            # take memory back from another one's cache
+            self.ctx.set_option("query_list_budget_mb", (64 << 10) // world)
+            self.ctx.set_option("query_list_max_mb", 4 << 10)
 
     def parse(self, files):
         return self._api.ReadSet.from_fasta(self.ctx, files)

@@ -122,7 +122,7 @@ int             commet_readset_kmer_counts(const commet_readset *rs, uint32_t *k
 /* Derived data cached WITH a resident set: the query list of the tiled search (the set's lane-a addresses sorted by
  * address slice; depends on (k, t) and the set only, made on the set's first scan, ~6 bytes per first-hit window — 2.2 GB
  * for 10 M x 100 bp reads at k = 32, t = 2, against 0.5 GB for the packed set).  The lists of a context are held to a
- * budget (option "query_list_budget_mb", COMMET_QUERY_LIST_GB; default 64 GiB): the least recently used ones are given
+ * budget (option "query_list_budget_mb", COMMET_QUERY_LIST_GB; default: half the device's memory, at least 64 GiB): the least recently used ones are given
  * back first, and all of them (but the running job's) when a device allocation of the context fails, which is then
  * tried again.  cache_bytes: HBM the set's list holds now; drop_cache: give it back (rebuilt on the next scan that
  * wants it; no-op while a job uses the set); cache_stats: the context's totals.  No counterpart in the reference. */
@@ -223,7 +223,8 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        tables, whose later passes skip the reads already found), 1 = never, 2 = always
  *   slice_wide_words     cap on the words per wide row (a multiple of 8, 32 chunk filters per word; 0 = by the memory free)
  *   query_list_budget_mb HBM the cached query lists of the context's read sets may hold (see commet_readset_cache_bytes)
- *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096
+ *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 16384 on devices of 128 GiB or more
+ *                        (a 50 M-read set's list is 11 GB), else 4096
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
