@@ -181,7 +181,14 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     if (c->tiled_mode == 2) return true;
     // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB.  Measured
     // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
-    return rs->n_reads >= (1ull << 20) && rs->n_reads * (uint64_t) first_hit_windows * 8 <= c->ql_max_list;
+    const uint64_t est = rs->n_reads * (uint64_t) first_hit_windows * 8;
+    if (rs->n_reads < (1ull << 20) || est > c->ql_max_list) return false;
+    // A list of more than 4 GiB (sets of 15 M reads and up) is built for a set's SECOND such scan: a set that is scanned once —
+    // every target of a rank that holds few pairs of a large matrix — would pay 12 ms of kernels and an 11 GB allocation for a
+    // 7.6 ms gain (one J2 / J3 job of configs[3]: 54.7 against 62.3 ms), a set that is scanned again and again — every set of a
+    // matrix on one GPU, the reference set of a rank's pairs — gets its list one scan late.
+    if (est > (4ull << 30) && !rs->ql.built && rs->ql_wanted++ == 0) return false;
+    return true;
 }
 
 // the set's query list for this context's (k, t): counted, scanned, filled; kept with the set

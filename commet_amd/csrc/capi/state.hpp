@@ -275,6 +275,7 @@ struct commet_readset {
         }
     };
     mutable QueryList ql;
+    mutable uint32_t ql_wanted = 0;                 // scans that would have taken the tiled search had the set's (large) list existed (tiled_ok)
     mutable bool in_job = false;                    // part of the commet_index_and_search call that is running: its list stays
     bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
     uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;
