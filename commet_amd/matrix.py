@@ -500,6 +500,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 if nb != c:
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
+            if considered[s] == sum(counts[s]):
+                sel[s] = None                                     # every read selected (the default filters): no bitmap to upload, dense plans
             return True
 
         stop_ev = threading.Event()                               # set when this rank is through (or has failed): ends every wait below
