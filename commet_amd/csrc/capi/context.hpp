@@ -45,14 +45,13 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
     c->job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
     c->ingest_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
-    {   // query lists: half the device at most (64 GiB on small devices), one list up to 16 GiB where the device has 128 GiB or more —
-        // 50 M-read sets (11 GB lists) then take the tiled search against 1-2 chunk filters, too: 54.7 against 62.3 ms per J2 / J3 job
-        // of configs[3], 11.23 against 11.80 s for its matrix on one GPU (ten lists, 110 GB)
+    {   // query lists: half the device at most (64 GiB on small devices).  One list: 4 GiB (sets of up to ~15 M reads).  Larger lists
+        // (COMMET_QUERY_LIST_MAX_GB / option query_list_max_mb; a 50 M-read set's is 11 GB) pay in a long-lived context — a J2 / J3
+        // job of configs[3] 54.7 against 62.3 ms, its matrix 11.1-11.4 against 11.8 s when the device memory comes cheap — but not
+        // where the memory is allocated for the one run: hipMalloc + hipFree of large buffers cost 15-30 ms per GiB on this driver
+        // (64 GiB: 1.9 s, 128 GiB: 3.8-4.8 s, commet_membench's table), ten lists = 110 GB: the same matrix 14.7-15.0 s
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-            c->ql_budget = std::max<uint64_t>(64ull << 30, (uint64_t) tot / 2);
-            if (tot >= ((size_t) 128 << 30)) c->ql_max_list = 16ull << 30;
-        }
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->ql_budget = std::max<uint64_t>(64ull << 30, (uint64_t) tot / 2);
     }
     if (const char *e = getenv("COMMET_QUERY_LIST_MAX_GB")) c->ql_max_list = (uint64_t) (std::max(0.0, atof(e)) * (double) (1ull << 30));
     if (const char *e = getenv("COMMET_QUERY_LIST_GB")) c->ql_budget = (uint64_t) (std::max(0.0, atof(e)) * (double) (1ull << 30));

@@ -215,7 +215,7 @@ struct commet_ctx {
     std::mutex ql_mu;                                 // guards the registry and every query list of the context
     std::vector<commet_readset *> sets;               // read sets alive on this context
     uint64_t ql_bytes = 0, ql_budget = 64ull << 30, ql_clock = 0, ql_evictions = 0;   // (budget: half the device when that is more, commet_create)
-    uint64_t ql_max_list = 4ull << 30;                // auto mode: sets whose list (8 bytes per first-hit window, estimated) is larger keep the gather kernels (16 GiB on devices of 128 GiB or more)
+    uint64_t ql_max_list = 4ull << 30;                // auto mode: sets whose list (8 bytes per first-hit window, estimated) is larger keep the gather kernels
 
     uint32_t *slot_ptr(int i) const { return filter + (uint64_t) i * 4 * plane_words; }
     FilterView view() const

@@ -170,7 +170,6 @@ class HipEngine:
             # several ranks on ONE device (a rehearsal): the cached query lists of all of them must fit it together — no rank can
             # take memory back from another one's cache
             self.ctx.set_option("query_list_budget_mb", (64 << 10) // world)
-            self.ctx.set_option("query_list_max_mb", 4 << 10)
 
     def parse(self, files):
         return self._api.ReadSet.from_fasta(self.ctx, files)
@@ -500,7 +499,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 if nb != c:
                     raise eng.mismatch_error(f"Number of reads in {f} and boolean vector size are not equal -> quit")
             _, sel[s] = concat_bits(parts)
-            if considered[s] == sum(counts[s]):
+            if considered[s] == sum(counts[s]) and os.environ.get("COMMET_MATRIX_KEEP_SEL", "0") != "1":
                 sel[s] = None                                     # every read selected (the default filters): no bitmap to upload, dense plans
             return True
 

@@ -223,8 +223,9 @@ int commet_index_and_search(commet_ctx *ctx,
  *                        tables, whose later passes skip the reads already found), 1 = never, 2 = always
  *   slice_wide_words     cap on the words per wide row (a multiple of 8, 32 chunk filters per word; 0 = by the memory free)
  *   query_list_budget_mb HBM the cached query lists of the context's read sets may hold (see commet_readset_cache_bytes)
- *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 16384 on devices of 128 GiB or more
- *                        (a 50 M-read set's list is 11 GB), else 4096
+ *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096 (sets of up to ~15 M reads;
+ *                        larger lists — a 50 M-read set's is 11 GB — pay in long-lived contexts only: allocating them costs
+ *                        15-30 ms per GiB; lists of more than 4 GiB are built for a set's second eligible scan)
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
