@@ -352,7 +352,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
     # neighbour and of rank 0; else as a packed image in the scratch directory (0.5 s to write, 0.2 s to read).
     use_ipc = False
 
-    def import_guarded(blob):
+    def import_guarded(blob, limit_s=None):
         """eng.import_set with a deadline: a HIP call that hangs cannot be cancelled from inside the process, so a rank whose
         import does not return leaves (non-zero; the launcher ends the job) rather than keep its peers waiting for good.
         COMMET_IPC_LOCK=1 also takes a lock file of the node around the import (one import at a time on the node: a round-3
@@ -373,7 +373,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                         pass
             os._exit(4)
 
-        limit = float(os.environ.get("COMMET_IPC_IMPORT_LIMIT_S", "120"))
+        limit = float(limit_s if limit_s is not None else os.environ.get("COMMET_IPC_IMPORT_LIMIT_S", "120"))
         watch = threading.Timer(limit, give_up)
         watch.daemon = True
         watch.start()
@@ -411,7 +411,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     if blobs[src] is None:
                         ok = 0
                     else:
-                        got = import_guarded(blobs[src])    # every rank's probe set holds the same reads:
+                        got = import_guarded(blobs[src], os.environ.get("COMMET_IPC_PROBE_LIMIT_S", "30"))   # (four reads: seconds are generous) every rank's probe set holds the same reads:
                         if hasattr(eng, "same_set") and not eng.same_set(got, probe):   # a copy that arrives damaged counts as no hand-over
                             say("device-to-device hand-over of sets: the probe set did not arrive intact: packed images instead")
                             ok = 0
