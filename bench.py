@@ -402,7 +402,8 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports {world}", file=sys.stderr)
     if args.rendezvous_only:
         elapsed = sharding.timed_region(ranks, lambda: None, lambda: time.sleep(0.01 * (rank + 1)), args.steps)
-        devices = ranks.gather_objects(int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+        # (no HIP call here: BENCH_FAKE_DEVICE_COUNT stands in for commet_device_count() in the CPU test of the launch path)
+        devices = ranks.gather_objects(sharding.pick_device(local_rank, int(os.environ.get("BENCH_FAKE_DEVICE_COUNT", "0")) or None))
         torch_in = ranks.gather_objects("torch" in sys.modules)
         if rank == 0:
             print(json.dumps({"metric": "rendezvous only (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -425,8 +426,9 @@ def main():
         b0, o0 = synth.synth_set(2 * rank, n, L, base_set=2 * rank)
         b1, o1 = synth.synth_set(2 * rank + 1, n, L, base_set=2 * rank)
 
-    # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
-    device = int(os.environ.get("COMMET_FORCE_DEVICE", local_rank))
+    # a launcher may give every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): LOCAL_RANK modulo
+    # what this process sees.  COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
+    device = sharding.pick_device(local_rank, commet_amd.device_count())
     ctx = commet_amd.Context(k=k, t=t, device=device)
     t_up = time.perf_counter()
     irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])   # host threads 2-bit pack, planes cross PCIe (reported, never part of `value`)
@@ -635,7 +637,11 @@ def main():
                            "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
                            "matrix": matrix_detail, "matrix_configs2": matrix_c2},
             }
-            if matrix_detail and "error" not in matrix_detail:
+            if matrix_detail and "error" in matrix_detail:
+                # the leg failed: say so where a reader of the per-N lines looks (a linear weak-scaling `value` with no matrix object
+                # beside it would read as a clean run); detail.matrix carries the same
+                out["matrix"] = {"error": matrix_detail["error"], "world": world}
+            elif matrix_detail:
                 # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
                 # (the same workload at every N — BASELINE configs[3] when the host holds it — so the per-N values are one curve)
                 out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
@@ -662,7 +668,7 @@ def main():
                                                           f"(index {fj['index_s']} s + search {fj['search_s']} s), .bv bytes equal the GPU's: {fj['bv_bytes_equal_gpu']}")
             print(json.dumps(out), flush=True)
 
-    matrix_detail, matrix_c2 = None, None
+    matrix_detail, matrix_c2, failed_here = None, None, False
     if not args.no_matrix and args.matrix_sets >= 2:
         # The extra legs must never cost the headline: if they are not done after BENCH_MATRIX_LIMIT_S (default 900 s; configs[3] takes
         # ~60 s on one GPU, most of it writing the FASTA files) every rank gives up — rank 0 prints the line without them — ends its
@@ -706,16 +712,24 @@ def main():
             import traceback
             traceback.print_exc()
             matrix_detail = {"error": f"{type(ex).__name__}: {ex}"}
+            # did the failure begin HERE, or is this the wake of another rank's (its waits ended with "rendezvous: rank X gave up ...")?
+            failed_here = not (isinstance(ex, RuntimeError) and "rendezvous" in str(ex))
         finally:
             watch.cancel()
 
     emit(matrix_detail, matrix_c2)
 
     if world > 1 and ranks.failed:
-        # the matrix leg lost a rank (its error is in the line): a thread of this process may still sit in a HIP call that never
-        # returns (an import from a rank that has left), so no teardown — the headline is out, leave
+        # The matrix leg lost a rank: its error is in the line, top level ("matrix": {"error": ...}) and detail.  A thread of this
+        # process may still sit in a HIP call that never returns (an import from a rank that has left), so no teardown.  Exit codes:
+        # rank 0 has printed the intact headline and leaves with 0; the rank the failure began in leaves NON-ZERO (3), a few seconds
+        # later so that a launcher that ends the group on the first failure (torch.distributed.run) does not end rank 0 in
+        # the middle of its line; the ranks that only saw another one fail leave with 0.
         sys.stdout.flush()
         sys.stderr.flush()
+        if rank != 0 and failed_here:
+            time.sleep(float(os.environ.get("BENCH_FAILED_RANK_LINGER_S", "5")))
+            os._exit(3)
         os._exit(0)
     ranks.close()
 

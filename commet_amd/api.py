@@ -37,6 +37,11 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def device_count():
+    """commet_device_count: HIP devices this process sees (0 without one; counting initialises nothing a later fork would mind)"""
+    return int(_l.load().commet_device_count())
+
+
 class Context:
     """commet_ctx: device, k, t, the 4-lane Bloom filter in HBM."""
 

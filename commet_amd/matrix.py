@@ -162,9 +162,10 @@ class HipEngine:
 
     def __init__(self, k, t, local_rank):
         import commet_amd
+        # LOCAL_RANK modulo the devices this process sees (a launcher may give every rank one visible device);
         # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
         self._api = commet_amd
-        self.ctx = commet_amd.Context(k=k, t=t, device=int(os.environ.get("COMMET_FORCE_DEVICE", local_rank)))
+        self.ctx = commet_amd.Context(k=k, t=t, device=sharding.pick_device(local_rank, commet_amd.device_count()))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if "COMMET_FORCE_DEVICE" in os.environ and world > 1:
             # several ranks on ONE device (a rehearsal): the cached query lists of all of them must fit it together — no rank can

@@ -257,6 +257,82 @@ class _Store:
             pass
 
 
+# ---- what the ranks tell each other, on the wire ------------------------------------------------------------------
+# Small host objects only (numbers, strings, a 264-byte descriptor, dicts of pair -> count): JSON with three tags for what JSON
+# lacks — bytes, tuples, dicts whose keys are not strings.  Nothing that arrives over the socket is ever executed or
+# unpickled: a local user who guesses the job token can make a rank fail, not run code in it.
+def _to_wire(o):
+    if o is None or isinstance(o, (bool, str)):
+        return o
+    if isinstance(o, int):
+        return o
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else {"__f__": repr(o)}
+    if isinstance(o, (bytes, bytearray, memoryview)):
+        import base64
+        return {"__b__": base64.b64encode(bytes(o)).decode("ascii")}
+    if isinstance(o, tuple):
+        return {"__t__": [_to_wire(x) for x in o]}
+    if isinstance(o, (list, set, frozenset)):
+        return [_to_wire(x) for x in (sorted(o) if isinstance(o, (set, frozenset)) else o)]
+    if isinstance(o, dict):
+        if all(isinstance(k, str) and not k.startswith("__") for k in o):
+            return {k: _to_wire(v) for k, v in o.items()}
+        return {"__d__": [[_to_wire(k), _to_wire(v)] for k, v in o.items()]}
+    item = getattr(o, "item", None)              # numpy scalars
+    if callable(item) and getattr(o, "shape", None) == ():
+        return _to_wire(item())
+    tolist = getattr(o, "tolist", None)          # small numpy arrays
+    if callable(tolist):
+        return _to_wire(tolist())
+    raise TypeError(f"rendezvous: cannot send a {type(o).__name__} between ranks (numbers, strings, bytes, lists, tuples, dicts only)")
+
+
+def _from_wire(o):
+    if isinstance(o, list):
+        return [_from_wire(x) for x in o]
+    if isinstance(o, dict):
+        if len(o) == 1:
+            (k, v), = o.items()
+            if k == "__b__":
+                import base64
+                return base64.b64decode(v)
+            if k == "__t__":
+                return tuple(_from_wire(x) for x in v)
+            if k == "__d__":
+                return {_hashable(_from_wire(a)): _from_wire(b) for a, b in v}
+            if k == "__f__":
+                return float(v)
+        return {k: _from_wire(v) for k, v in o.items()}
+    return o
+
+
+def _hashable(k):
+    return tuple(_hashable(x) for x in k) if isinstance(k, list) else k
+
+
+def _encode_value(obj):
+    import json
+    return json.dumps(_to_wire(obj), separators=(",", ":"), allow_nan=False).encode("utf-8")
+
+
+def _decode_value(body):
+    import json
+    return _from_wire(json.loads(body.decode("utf-8")))
+
+
+def pick_device(local_rank, n_devices=None):
+    """The HIP device of a rank: COMMET_FORCE_DEVICE when set (a debugging aid: several ranks on one GPU; never set by the
+    driver), else LOCAL_RANK modulo the devices this process sees — a launcher that hands every rank ONE visible device
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) must end on device 0 of each, not on device LOCAL_RANK, which
+    such a process does not have.  n_devices None or 0 (count unknown: nothing has asked the library): LOCAL_RANK as it is."""
+    import os
+    forced = os.environ.get("COMMET_FORCE_DEVICE")
+    if forced is not None:
+        return int(forced)
+    return int(local_rank) % int(n_devices) if n_devices else int(local_rank)
+
+
 class Ranks:
     """Barrier / gather / MAX / SUM over the ranks of a job (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT from the
     environment, as torch.distributed.run and bench.py's own launcher set them).  world_size 1 needs nothing.
@@ -376,17 +452,15 @@ class Ranks:
     def _dumps(self, obj):
         import hashlib
         import hmac
-        import pickle
-        body = pickle.dumps(obj, protocol=4)
+        body = _encode_value(obj)
         return hmac.new(_rdzv_token(), body, hashlib.sha256).digest() + body
 
     def _loads(self, blob):
         import hashlib
         import hmac
-        import pickle
         if not hmac.compare_digest(blob[:32], hmac.new(_rdzv_token(), blob[32:], hashlib.sha256).digest()):
             raise RuntimeError("rendezvous: a value in the store was not written by a rank of this job")
-        return pickle.loads(blob[32:])
+        return _decode_value(blob[32:])
 
     def _gather_tcp(self, obj):
         seq = self._seq
