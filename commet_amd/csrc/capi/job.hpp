@@ -468,20 +468,32 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 if (!tiled_ok(c, rs, tg) || build_query_list(c, rs) != 0 || ensure_query_results(c, rs) != 0) return 1;
                 return launch_search_tiled(c, rs, tg, slot0, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, tcnt, (uint32_t) (2 * n_search)) ? 2 : 0;
             };
-            const int tiled2 = g == 2 ? try_tiled(2, 0, cnt) : 1;   // large set, two chunk filters: lane-a gathers served from L2, slice by slice
+            // a pass over few of the set's reads (the host plan visits less than half of them): their list, not the set (kernels.hpp,
+            // ActiveList); the tiled search probes EVERY record of the set's query list, so such a pass takes the gather kernels
+            const uint64_t *sel_s = all_visited[s] ? nullptr : rs->d_sel;
+            const bool sparse = rs->n_reads && sparse_pass(c, rs, sel_s, visited[s]);
+            ActiveList al{nullptr, nullptr};
+            auto list_for_pass = [&]() -> bool {            // (re-made per pass: the tags of the pass before have shrunk it)
+                al = ActiveList{nullptr, nullptr};
+                return sparse && build_active_list(c, rs, sel_s, rs->d_tags, visited[s], &al) == 0;
+            };
+            const int tiled2 = (g == 2 && !sparse) ? try_tiled(2, 0, cnt) : 1;   // large set, two chunk filters: lane-a gathers served from L2, slice by slice
             if (tiled2 == 2) { rc = 1; break; }
             if (tiled2 == 0) {
                 if (rs->n_reads) ++n_search_launches;
             } else if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
-                if (launch_search_group(c, rs, g, gs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes)) { rc = 1; break; }
+                (void) list_for_pass();
+                if (launch_search_group(c, rs, g, gs, sel_s, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes, al, visited[s])) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
                     c->cur_slot = i;
-                    const int tiled1 = try_tiled(1, i, cnt + 2 * (uint64_t) i * n_search);   // the same, one filter at a time
+                    const int tiled1 = sparse ? 1 : try_tiled(1, i, cnt + 2 * (uint64_t) i * n_search);   // the same, one filter at a time
                     if (tiled1 == 2) rc = 1;
-                    else if (tiled1 == 1 &&
-                             launch_search(c, rs, all_visited[s] ? nullptr : rs->d_sel, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes)) rc = 1;
+                    else if (tiled1 == 1) {
+                        (void) list_for_pass();
+                        if (launch_search(c, rs, sel_s, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes, al, visited[s])) rc = 1;
+                    }
                     if (rs->n_reads) ++n_search_launches;
                 }
             }

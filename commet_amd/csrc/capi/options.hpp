@@ -45,6 +45,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->tiled_mode = (int) value;
         return 0;
     }
+    if (!strcmp(name, "sparse_search")) {     // 0 auto, 1 never, 2 whenever a selection applies: a pass over few of a set's reads walks their list (kernels.hpp, ActiveList)
+        if (value < 0 || value > 2) return fail("sparse_search must be 0, 1 or 2");
+        c->sparse_search = (int) value;
+        return 0;
+    }
     if (!strcmp(name, "tq_parts")) {          // tiled search: parts of the set whose replay runs beside the next part's probe (1 = off)
         if (value < 1 || value > 16) return fail("tq_parts must be 1..16");
         c->tq_parts = (int) value;

@@ -12,11 +12,14 @@ inline int t_eff(const commet_ctx *c, const commet_readset *rs)
     return (int) std::min<uint64_t>((uint64_t) c->t, (uint64_t) rs->max_len / (uint64_t) c->k + 1);
 }
 
+// al.ids != nullptr: a pass over the n_launch (at most) listed reads (kernels.hpp, ActiveList) instead of the whole set
 int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t *d_tags, uint64_t *d_found,
-                  unsigned long long *d_counters, unsigned long long *d_probes = nullptr)
+                  unsigned long long *d_counters, unsigned long long *d_probes = nullptr, ActiveList al = ActiveList{nullptr, nullptr},
+                  uint64_t n_launch = 0)
 {
     if (rs->n_reads == 0) return 0;
-    const uint64_t blocks = (rs->n_reads + 255) / 256;
+    if (al.ids && n_launch == 0) return 0;
+    const uint64_t blocks = ((al.ids ? n_launch : rs->n_reads) + 255) / 256;
     if (blocks >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
     const dim3 g((unsigned) blocks), b(256);
     const bool cnt = d_probes != nullptr;
@@ -24,17 +27,17 @@ int launch_search(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
     if (c->k <= 32) {
         if (cnt)
             COMMET_LAUNCH((search_kernel<uint32_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
-                               d_tags, d_found, d_counters, d_probes);
+                               d_tags, d_found, d_counters, d_probes, al);
         else
             COMMET_LAUNCH((search_kernel<uint32_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
-                               d_tags, d_found, d_counters, d_probes);
+                               d_tags, d_found, d_counters, d_probes, al);
     } else {
         if (cnt)
             COMMET_LAUNCH((search_kernel<uint64_t, true>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
-                               d_tags, d_found, d_counters, d_probes);
+                               d_tags, d_found, d_counters, d_probes, al);
         else
             COMMET_LAUNCH((search_kernel<uint64_t, false>), g, b, 0, c->stream, rs->view(), c->view(), c->k, t_eff(c, rs), d_sel,
-                               d_tags, d_found, d_counters, d_probes);
+                               d_tags, d_found, d_counters, d_probes, al);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -82,9 +85,10 @@ int launch_interleave(commet_ctx *c, int g, int gs)
 
 template <typename W, int GS>
 int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterGroupView &fg, uint32_t nw_max, const uint64_t *d_sel,
-                          uint64_t *d_tags, unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes)
+                          uint64_t *d_tags, unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes, ActiveList al,
+                          uint64_t n_launch)
 {
-    const dim3 g((unsigned) ((rs->n_reads + 255) / 256)), b(256);
+    const dim3 g((unsigned) (((al.ids ? n_launch : rs->n_reads) + 255) / 256)), b(256);
     size_t lds = (size_t) fg.g * 2 * nw_max * 256 * sizeof(uint32_t);
     // the lanes' reads staged in LDS too (3 * nw_max words each) when that still fits 64 KiB
     uint32_t rw_nw = 0;
@@ -96,11 +100,11 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
     if (d_probes) {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         COMMET_LAUNCH((search_group_kernel<W, GS, true>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
-                           d_counters, cstride, d_probes, rw_nw);
+                           d_counters, cstride, d_probes, rw_nw, al);
     } else {
         HIP_OK(hipFuncSetAttribute((const void *) search_group_kernel<W, GS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         COMMET_LAUNCH((search_group_kernel<W, GS, false>), g, b, lds, c->stream, rs->view(), fg, c->k, t_eff(c, rs), nw_max, d_sel, d_tags,
-                           d_counters, cstride, d_probes, rw_nw);
+                           d_counters, cstride, d_probes, rw_nw, al);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -108,9 +112,11 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
 
 // one pass of rs over the `g` chunk filters in slots 0..g-1 (A planes already interleaved with stride gs)
 int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, const uint64_t *d_sel, uint64_t *d_tags,
-                        unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes)
+                        unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes, ActiveList al = ActiveList{nullptr, nullptr},
+                        uint64_t n_launch = 0)
 {
     if (rs->n_reads == 0) return 0;
+    if (al.ids && n_launch == 0) return 0;
     if ((rs->n_reads + 255) / 256 >= (1ull << 24)) return fail("search launch too large (>= 2^32 reads in one set)");
     FilterGroupView fg;
     fg.il_a = c->il_a;
@@ -119,34 +125,34 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.plane_words = c->plane_words;
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
-        const dim3 grid((unsigned) ((rs->n_reads + 255) / 256)), block(256);
+        const dim3 grid((unsigned) (((al.ids ? n_launch : rs->n_reads) + 255) / 256)), block(256);
         const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;   // mask words per strand and filter
         KScope ks(c, "search_group8_kernel", c->stream);
         if (c->k <= 32) {
             if (three)
                 COMMET_LAUNCH((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride);
+                                   d_tags, d_counters, cstride, al);
             else
                 COMMET_LAUNCH((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride);
+                                   d_tags, d_counters, cstride, al);
         } else {
             if (three)
                 COMMET_LAUNCH((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride);
+                                   d_tags, d_counters, cstride, al);
             else
                 COMMET_LAUNCH((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride);
+                                   d_tags, d_counters, cstride, al);
         }
         HIP_OK(hipGetLastError());
         return 0;
     }
     const uint32_t nw_max = (rs->max_len + 31) / 32;
     if (c->k <= 32) {
-        if (gs == 2) return launch_search_group_t<uint32_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
-        return launch_search_group_t<uint32_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+        if (gs == 2) return launch_search_group_t<uint32_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes, al, n_launch);
+        return launch_search_group_t<uint32_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes, al, n_launch);
     }
-    if (gs == 2) return launch_search_group_t<uint64_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
-    return launch_search_group_t<uint64_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes);
+    if (gs == 2) return launch_search_group_t<uint64_t, 2>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes, al, n_launch);
+    return launch_search_group_t<uint64_t, 4>(c, rs, fg, nw_max, d_sel, d_tags, d_counters, cstride, d_probes, al, n_launch);
 }
 
 bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
@@ -162,6 +168,46 @@ bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 {
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
+}
+
+// ---- sparse passes: the reads of a pass as a list (kernels.hpp, ActiveList) --------------------------------------
+// A pass that searches less than half of a set's reads — Commet.py's third job of a pair searches a set restricted to the first
+// job's result (Commet.py:233), ~22 % of it — walks the list of those reads (sel & ~tags, in order) instead of the set: every lane
+// of a wave then has a read, where the bitmap form kept 64 lanes waiting through a read's dependent round trips for the 14 that had
+// one (a J3 job of configs[3]: search 46 -> 12 ms).  `selected` = the reads the host plan visits (tags can only shrink the list).
+bool sparse_pass(const commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, uint64_t selected)
+{
+    if (!d_sel || c->sparse_search == 1 || c->count_probes || rs->n_reads >= (1ull << 32)) return false;
+    if (c->sparse_search == 2) return true;
+    return rs->n_reads >= 4096 && selected * 2 < rs->n_reads;
+}
+
+// builds the list on the job's stream (three small launches, no synchronisation); 0 = done, 1 = no room (the caller takes the bitmap form)
+int build_active_list(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, const uint64_t *d_tags, uint64_t selected, ActiveList *al)
+{
+    const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
+    if (c->act_cap < selected || c->actblk_cap < nb + 1) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+        (void) hipFree(c->d_act), (void) hipFree(c->d_actblk);
+        c->d_act = c->d_actblk = nullptr, c->act_cap = c->actblk_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(selected, 1024);
+        if (dev_alloc(c, (void **) &c->d_act, cap * sizeof(uint32_t), true) != hipSuccess ||
+            dev_alloc(c, (void **) &c->d_actblk, (nb + 1) * sizeof(uint32_t), true) != hipSuccess) {
+            (void) hipGetLastError();
+            (void) hipFree(c->d_act), (void) hipFree(c->d_actblk);
+            c->d_act = c->d_actblk = nullptr;
+            return 1;
+        }
+        c->act_cap = cap, c->actblk_cap = nb + 1;
+    }
+    KScope ks(c, "active_list_kernels", c->stream);
+    COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, d_sel, n_words, c->d_actblk, d_tags);
+    COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_actblk, (uint32_t) nb);
+    COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, d_sel, n_words, c->d_actblk, c->d_act, d_tags);
+    if (hipGetLastError() != hipSuccess) return 1;
+    al->ids = c->d_act;
+    al->n = c->d_actblk + nb;
+    return 0;
 }
 
 // ---- tiled search (tile_search.hpp) ----------------------------------------------------------------------------

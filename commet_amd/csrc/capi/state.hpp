@@ -110,6 +110,9 @@ struct commet_ctx {
     unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
     uint32_t *d_ids = nullptr, *d_idblk = nullptr;   // read numbers of the index selection of the running job, in order (sel_ids_kernel)
     uint64_t ids_cap = 0, idblk_cap = 0;
+    uint32_t *d_act = nullptr, *d_actblk = nullptr;  // read numbers of a sparse search pass (sel & ~tags, in order) and the scan's block sums
+    uint64_t act_cap = 0, actblk_cap = 0;
+    int sparse_search = 0;                           // option: 0 auto (a pass over less than half of a set's reads), 1 never, 2 whenever a selection applies
     unsigned long long *d_plansum = nullptr;  // per-block k-mer sums of a selection (host planner input)
     uint64_t plansum_cap = 0;
     uint64_t jobcnt_cap = 0;

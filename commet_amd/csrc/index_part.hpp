@@ -46,9 +46,15 @@ constexpr uint32_t TILE_WORDS = 1u << (TILE_BITS - 5);      // 16384 words = 64 
 constexpr int      S1_NT = COMMET_S1_NT;                    // scatter-1 workgroup size
 constexpr uint32_t S1_KEYS = 32u * COMMET_S1_NT;            // keys staged per scatter-1 round (64 KiB)
 constexpr uint32_t S1_ITEMS = S1_NT;                        // octet items per round: one per thread, keys cached
-constexpr int      S2_NT = 512;                             // scatter-2 workgroup size
-constexpr uint32_t S2_KEYS = 8192;                          // keys per scatter-2 block (16 per thread)
+#ifndef COMMET_S2_NT
+#define COMMET_S2_NT 512   // (448 threads x 72 VGPRs = four workgroups per CU instead of three: 4.52 against 4.54 ms per configs[1] step; 384: 5.06)
+#endif
+constexpr int      S2_NT = COMMET_S2_NT;                    // scatter-2 workgroup size
+constexpr uint32_t S2_KEYS = 16u * COMMET_S2_NT;            // keys per scatter-2 block (16 per thread)
 constexpr uint32_t S2_PER_THREAD = S2_KEYS / S2_NT;
+#ifndef S2P_WAVES
+#define S2P_WAVES 6   // 80 VGPRs, three workgroups per CU; 8 (64 VGPRs, four per CU with S2P_MAX_SUB = 128) spills and measured 4.6 instead of 4.1 ms
+#endif
 constexpr uint32_t S2P_MAX_SUB = 256;                       // packed scatter-2: final buckets per coarse bucket (k <= 33: the reference's default k takes the packed
                                                             // geometry too; 41.9 KiB of LDS, three workgroups of 80 VGPRs per CU either way)
 constexpr int      HIST_NT = 1024;                          // histogram workgroup size
@@ -416,10 +422,12 @@ __device__ __forceinline__ void item_lookup(const uint32_t *istart, uint32_t R, 
 // Three small launches per job: set bits per block of 4096 reads, their exclusive scan, the ids.
 // ---------------------------------------------------------------------------
 constexpr uint32_t IDS_BLOCK_WORDS = 64;                  // bitmap words (64 reads each) per block
-__global__ __launch_bounds__(64) void sel_count_kernel(const uint64_t *__restrict__ sel, uint64_t n_words, uint32_t *__restrict__ blk)
+// minus != nullptr: the reads whose bit is set there do not count (a search pass: selected and not yet tagged)
+__global__ __launch_bounds__(64) void sel_count_kernel(const uint64_t *__restrict__ sel, uint64_t n_words, uint32_t *__restrict__ blk,
+                                                       const uint64_t *__restrict__ minus = nullptr)
 {
     const uint64_t w = (uint64_t) blockIdx.x * IDS_BLOCK_WORDS + threadIdx.x;
-    uint32_t c = w < n_words ? (uint32_t) __popcll(sel[w]) : 0u;
+    uint32_t c = w < n_words ? (uint32_t) __popcll(sel[w] & ~(minus ? minus[w] : 0ull)) : 0u;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if (threadIdx.x == 0) blk[blockIdx.x] = c;
 }
@@ -446,10 +454,10 @@ __global__ __launch_bounds__(1024) void sel_scan_kernel(uint32_t *__restrict__ b
 }
 
 __global__ __launch_bounds__(64) void sel_ids_kernel(const uint64_t *__restrict__ sel, uint64_t n_words, const uint32_t *__restrict__ blk,
-                                                     uint32_t *__restrict__ ids)
+                                                     uint32_t *__restrict__ ids, const uint64_t *__restrict__ minus = nullptr)
 {
     const uint64_t w = (uint64_t) blockIdx.x * IDS_BLOCK_WORDS + threadIdx.x;
-    uint64_t bits = w < n_words ? sel[w] : 0ull;
+    uint64_t bits = w < n_words ? sel[w] & ~(minus ? minus[w] : 0ull) : 0ull;
     const uint32_t c = (uint32_t) __popcll(bits);
     uint32_t inc = c;
     for (int o = 1; o < 64; o <<= 1) {
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
 // scatter2: coarse buckets -> final buckets.  Flat grid over bufA; a slab that
 // straddles coarse buckets is processed segment by segment.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+__global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                               const uint64_t *__restrict__ off, PartGeom g,
                                                               unsigned long long *__restrict__ cursor2, uint64_t total)
 {
@@ -1030,9 +1038,6 @@ __global__ __launch_bounds__(S2_NT, 6) void part_scatter2_kernel(const uint32_t 
 // as possible, the bucket cursors reserved (one atomic per run, whole groups, as part_scan_kernel's bound on the groups
 // of a bucket assumes) while the keys are placed, and the dispatcher balancing one slab per workgroup.
 // ---------------------------------------------------------------------------
-#ifndef S2P_WAVES
-#define S2P_WAVES 6   // 80 VGPRs, three workgroups per CU; 8 (64 VGPRs, four per CU with S2P_MAX_SUB = 128) spills and measured 4.6 instead of 4.1 ms
-#endif
 __global__ __launch_bounds__(S2_NT, S2P_WAVES) void part_scatter2_packed_kernel(const uint32_t *__restrict__ in, uint2 *__restrict__ out,
                                                                      const uint64_t *__restrict__ off, PartGeom g,
                                                                      unsigned long long *__restrict__ cursor2, uint64_t total)

@@ -26,6 +26,21 @@
 
 namespace commet {
 
+// Scalar-register budget of the latency-bound kernels.  A CU admits floor(800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256
+// threads (MI355X_MICROARCH.md, "Residency and cooperative launch": <= 80 SGPRs: 8 workgroups, 82-96: 7, 98-112: 6), whatever
+// the LDS and the vector registers would allow; left alone the compiler takes 92-106 for the search kernels (kernel arguments
+// and loop-invariant addresses), i.e. 6-7 workgroups.  These kernels are chains of dependent memory round trips and run on
+// workgroups in flight: tq_replay_kernel 5.91 -> 5.20 ms per configs[1] step with the cap alone (tools/kernel_resources.py lists
+// every kernel's registers and what a CU admits).  What does not fit is kept in lanes of a vector register (v_writelane).
+#ifndef COMMET_SGPR_CAP
+#define COMMET_SGPR_CAP 80
+#endif
+#if COMMET_SGPR_CAP
+#define COMMET_SGPRS __attribute__((amdgpu_num_sgpr(COMMET_SGPR_CAP)))
+#else
+#define COMMET_SGPRS
+#endif
+
 struct ReadsView {
     const uint32_t *planes;      // word triples
     const uint64_t *goff;        // n+1 cumulative base offsets (unused when uniform_len != 0)
@@ -95,6 +110,60 @@ __device__ __forceinline__ void add_chunk_counters(unsigned long long *__restric
     __syncthreads();
     if (threadIdx.x < 2u * (unsigned) n_chunks && wg_cnt[threadIdx.x])
         atomicAdd(&counters[(uint64_t) (threadIdx.x >> 1) * cstride + (threadIdx.x & 1u)], (unsigned long long) wg_cnt[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// Which read a search thread works on.  Usually thread i of the launch takes read i and the bitmaps decide (sel: reads to
+// search, tags: reads found by an earlier chunk).  A pass over FEW of a set's reads — Commet.py's third job searches a set
+// restricted to the first job's result, ~22 % of its reads (Commet.py:233) — gets the numbers of those reads as a list instead
+// (ActiveList: sel & ~tags, in order; sel_ids_kernel): thread i takes read ids[i], every lane of a wave has work, and the
+// pass costs what its reads cost, not what the set's do (a wave of the bitmap form waits for its busiest lane through all of
+// a read's dependent round trips whether 14 or 64 of its lanes are active: 46 ms against 12 for 11 of 50 M reads).
+// ---------------------------------------------------------------------------
+struct ActiveList {
+    const uint32_t *ids;   // nullptr: bitmap form
+    const uint32_t *n;     // number of listed reads (device memory: the launch is sized by a bound the host knows)
+};
+
+struct SearchLane {
+    uint64_t r, word, tagw;
+    bool     active, in_range;
+};
+
+__device__ __forceinline__ SearchLane search_lane(const ReadsView &rv, const ActiveList &al, const uint64_t *__restrict__ sel,
+                                                  const uint64_t *__restrict__ tags)
+{
+    SearchLane me;
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (al.ids) {
+        me.active = i < (uint64_t) *al.n;
+        me.r = me.active ? (uint64_t) al.ids[i] : rv.n;      // (rv.n: no read)
+        me.word = me.r >> 6, me.tagw = 0, me.in_range = false;
+        return me;
+    }
+    me.r = i;
+    me.word = i >> 6;
+    const int lane = threadIdx.x & 63;
+    me.in_range = (me.word << 6) < rv.n;
+    uint64_t selw = ~0ull;
+    me.tagw = 0;
+    if (me.in_range) {
+        if (sel) selw = sel[me.word];
+        if (tags) me.tagw = tags[me.word];
+    }
+    me.active = (i < rv.n) && ((selw >> lane) & 1ull) && !((me.tagw >> lane) & 1ull);
+    return me;
+}
+
+// the found flags of the launch: one ballot word per 64 consecutive reads (bitmap form) or one atomic OR per found read (list form)
+__device__ __forceinline__ void publish_found(const ActiveList &al, const SearchLane &me, bool found, uint64_t *__restrict__ tags)
+{
+    if (al.ids) {
+        if (found && tags) (void) __hip_atomic_fetch_or(tags + me.word, 1ull << (me.r & 63ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint64_t fb = __ballot(found);
+    if ((threadIdx.x & 63) == 0 && me.in_range && tags) tags[me.word] = me.tagw | fb;
 }
 
 // ---------------------------------------------------------------------------
@@ -375,27 +444,21 @@ __global__ __launch_bounds__(256) void index_kernel(ReadsView rv, FilterView f, 
 constexpr uint32_t SEARCH_MASK_WORDS = 8;   // reverse-strand lane-a bits remembered for the first 256 bases of a read
 
 template <typename W, bool COUNT>
-__global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f, int k, int t,
+__global__ __launch_bounds__(256) COMMET_SGPRS void search_kernel(ReadsView rv, FilterView f, int k, int t,
                                                      const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                      uint64_t *__restrict__ found_out,
                                                      unsigned long long *__restrict__ counters,
-                                                     unsigned long long *__restrict__ probe_counter)
+                                                     unsigned long long *__restrict__ probe_counter, ActiveList al)
 {
     using T = KeyTraits<W>;
     // per lane: lane-a bit of the reverse-complement key of every window probed in the forward pass, and which
     // windows were probed; [word][thread] so that a wave's accesses are conflict-free
     __shared__ uint32_t rc_bits[SEARCH_MASK_WORDS][256];
     __shared__ uint32_t rc_known[SEARCH_MASK_WORDS][256];
-    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
-    const uint64_t word = r >> 6;
+    const SearchLane me = search_lane(rv, al, sel, tags);
+    const uint64_t r = me.r, word = me.word;
     const int lane = threadIdx.x & 63;
-    const bool in_range = (word << 6) < rv.n;
-    uint64_t selw = ~0ull, tagw = 0;
-    if (in_range) {
-        if (sel) selw = sel[word];
-        if (tags) tagw = tags[word];
-    }
-    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    const bool in_range = me.in_range, active = me.active;
     const bool paired = k >= 2;                 // plane A is stored strand-paired (psi_a)
     bool found = false;
     uint32_t probes = 0;   // filter words the REFERENCE control flow loads (COUNT builds only)
@@ -486,10 +549,10 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
             }
         }
     }
-    const uint64_t fb = __ballot(found);
-    if (lane == 0 && in_range) {
-        if (tags) tags[word] = tagw | fb;
-        if (found_out) found_out[word] = fb;
+    publish_found(al, me, found, tags);
+    if (found_out) {                            // (commet_search_reads: bitmap form only)
+        const uint64_t fb = __ballot(found);
+        if (lane == 0 && in_range) found_out[word] = fb;
     }
     if (counters) {
         __shared__ unsigned int wg_cnt[2];
@@ -513,6 +576,9 @@ __global__ __launch_bounds__(256) void search_kernel(ReadsView rv, FilterView f,
 #endif
 #ifndef G8_HEAVY
 #define G8_HEAVY 20   // (8 / 12 / 16 / 20 / 24 / 28: 140 / 130 / 105 / 104 / 101 / 104 ms on a 2 x 50 M-read pair) search_group8_kernel: a scan with more lane-a candidates than this walks them itself
+#endif
+#ifndef G8_WAVES
+#define G8_WAVES 1   // search_group8_kernel: waves per SIMD the register allocation is held to (= workgroups per CU)
 #endif
 #ifndef GROUP8_TAIL_WIN
 #define GROUP8_TAIL_WIN 32
@@ -556,10 +622,10 @@ template <> struct GroupWords<4> {
 };
 
 template <typename W, int GS, bool COUNT>
-__global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterGroupView fg, int k, int t, uint32_t nw_max,
+__global__ __launch_bounds__(256) COMMET_SGPRS void search_group_kernel(ReadsView rv, FilterGroupView fg, int k, int t, uint32_t nw_max,
                                                            const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                            unsigned long long *__restrict__ counters, uint32_t cstride,
-                                                           unsigned long long *__restrict__ probe_counter, uint32_t rw_nw)
+                                                           unsigned long long *__restrict__ probe_counter, uint32_t rw_nw, ActiveList al)
 {
     using T = KeyTraits<W>;
     extern __shared__ uint32_t gmask[];   // [chunk][strand][word][thread]
@@ -570,16 +636,14 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
     auto mask_at = [&](int i, int strand, uint32_t w) -> uint32_t & {
         return gmask[(((uint32_t) i * 2u + (uint32_t) strand) * nw_max + w) * 256u + threadIdx.x];
     };
-    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
-    const uint64_t word = r >> 6;
+    const SearchLane me = search_lane(rv, al, sel, tags);
+    const uint64_t r = me.r;
     const int lane = threadIdx.x & 63;
-    const bool in_range = (word << 6) < rv.n;
-    uint64_t selw = ~0ull, tagw = 0;
-    if (in_range) {
-        if (sel) selw = sel[word];
-        if (tags) tagw = tags[word];
-    }
-    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    const bool active = me.active;
+    // the read of another thread of the workgroup (the cooperative tails): thread x of the bitmap form has read block * 256 + x
+    __shared__ uint32_t wg_read[256];
+    if (al.ids) wg_read[threadIdx.x] = (uint32_t) r;
+    auto read_of = [&](uint32_t owner) -> uint64_t { return al.ids ? (uint64_t) wg_read[owner] : blockIdx.x * 256ull + owner; };
     bool found = false;
     int found_chunk = -1;
     uint32_t probes = 0;
@@ -703,7 +767,7 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
                         const int q = (int) (rq >> 8) + (int) wi;
                         uint64_t ot0;
                         uint32_t olen;
-                        read_extent(rv, blockIdx.x * 256ull + owner, ot0, olen);
+                        read_extent(rv, read_of(owner), ot0, olen);
                         if (q >= (int) olen) continue;
                         const uint32_t *op = rv.planes + 3 * ot0;
                         ItemWords<W> it;
@@ -805,8 +869,7 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
             if (found) found_chunk = i;
         }
     }
-    const uint64_t fb = __ballot(found);
-    if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
+    publish_found(al, me, found, tags);
     if (counters) {
         __shared__ unsigned int wg_cnt[2 * GS];
         add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);
@@ -826,9 +889,9 @@ __global__ __launch_bounds__(256) void search_group_kernel(ReadsView rv, FilterG
 // sparse replay of search_group_kernel, unrolled over the filters.  Sets of more than four chunks need half the passes.
 // ---------------------------------------------------------------------------
 template <typename W, int MW>
-__global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, FilterGroupView fg, int k, int t,
+__global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kernel(ReadsView rv, FilterGroupView fg, int k, int t,
                                                             const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
-                                                            unsigned long long *__restrict__ counters, uint32_t cstride)
+                                                            unsigned long long *__restrict__ counters, uint32_t cstride, ActiveList al)
 {
     using T = KeyTraits<W>;
     constexpr int GS = 8;
@@ -837,19 +900,16 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
     __shared__ uint32_t tail_req[256], tail_bits[256];
     __shared__ uint32_t tail_n;
     // the first-hit candidates of a scan are probed by the whole workgroup as well (see (2) below)
-    __shared__ uint32_t cand[256 * G8_HEAVY];
+    __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (7 bits: <= 96 first-hit windows)
     __shared__ uint32_t full_hit[MW][256];
     __shared__ uint32_t cand_n;
-    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
-    const uint64_t word = r >> 6;
-    const int lane = threadIdx.x & 63;
-    const bool in_range = (word << 6) < rv.n;
-    uint64_t selw = ~0ull, tagw = 0;
-    if (in_range) {
-        if (sel) selw = sel[word];
-        if (tags) tagw = tags[word];
-    }
-    const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    const SearchLane me = search_lane(rv, al, sel, tags);
+    const uint64_t r = me.r;
+    const bool active = me.active;
+    // the read of another thread of the workgroup (candidate sweeps, tails): thread x of the bitmap form has read block * 256 + x
+    __shared__ uint32_t wg_read[256];
+    if (al.ids) wg_read[threadIdx.x] = (uint32_t) r;
+    auto read_of = [&](uint32_t owner) -> uint64_t { return al.ids ? (uint64_t) wg_read[owner] : blockIdx.x * 256ull + owner; };
     bool found = false;
     int found_chunk = -1;
     uint64_t t0 = 0;
@@ -944,7 +1004,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                 uint32_t at = atomicAdd(&cand_n, ncand);   // <= 256 * G8_HEAVY in all
 #pragma unroll
                 for (int h = 0; h < MW; ++h)
-                    for (uint32_t m = mm[h]; m; m &= m - 1u) cand[at++] = threadIdx.x | ((32u * h + (uint32_t) __ffs((int) m) - 1u) << 8);
+                    for (uint32_t m = mm[h]; m; m &= m - 1u) cand[at++] = (uint16_t) (threadIdx.x | ((32u * h + (uint32_t) __ffs((int) m) - 1u) << 8));
             }
             __syncthreads();
             {
@@ -965,7 +1025,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                         const int q = q0 + (int) wq[u];
                         uint64_t ot0;
                         uint32_t olen;
-                        read_extent(rv, blockIdx.x * 256ull + owner[u], ot0, olen);
+                        read_extent(rv, read_of(owner[u]), ot0, olen);
                         ItemWords<W> it;
                         it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
                         W wh, wl;
@@ -1024,7 +1084,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
                     const int q = (int) (rq >> 8) + (int) w;
                     uint64_t ot0;
                     uint32_t olen;
-                    read_extent(rv, blockIdx.x * 256ull + owner, ot0, olen);
+                    read_extent(rv, read_of(owner), ot0, olen);
                     if (q >= (int) olen) continue;
                     ItemWords<W> it;
                     it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
@@ -1061,8 +1121,7 @@ __global__ __launch_bounds__(256) void search_group8_kernel(ReadsView rv, Filter
         }
         if (found && found_chunk < 0) found_chunk = i;
     }
-    const uint64_t fb = __ballot(found);
-    if (lane == 0 && in_range && tags) tags[word] = tagw | fb;
+    publish_found(al, me, found, tags);
     if (counters) {
         __shared__ unsigned int wg_cnt[2 * GS];
         add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);

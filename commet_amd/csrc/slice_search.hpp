@@ -154,7 +154,7 @@ template <int GW> struct SliceWord {
 };
 
 template <int GW>
-__global__ __launch_bounds__(256) void search_sliced_kernel(ReadsView rv, const uint32_t *__restrict__ tables, int k, int t, int g,
+__global__ __launch_bounds__(256) COMMET_SGPRS void search_sliced_kernel(ReadsView rv, const uint32_t *__restrict__ tables, int k, int t, int g,
                                                             const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
                                                             unsigned long long *__restrict__ counters, uint32_t cstride,
                                                             uint32_t block_stride)

@@ -27,12 +27,21 @@
 #include "index_part.hpp"   // block_scan
 
 #ifndef COMMET_TQ_ABLATE
-#define COMMET_TQ_ABLATE 0   // timing ablations exist only in builds made with -DCOMMET_TQ_ABLATE=<mask> (512: no gather, 1024: no replay)
+#define COMMET_TQ_ABLATE 0   // timing ablations exist only in builds made with -DCOMMET_TQ_ABLATE=<mask> (512: no gather, 1024: no replay, 262144 / 524288: plane-B probes / tail gathers folded into an L2-resident window)
 #endif
 
 namespace commet {
 
-constexpr uint32_t TQ_PIECE = 256;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
+#ifndef TQ_SWEEP_U
+#define TQ_SWEEP_U 2     // replay, step (2): candidates per thread and round of the balanced sweep
+#endif
+#ifndef TQ_COLLECT_U
+#define TQ_COLLECT_U 8   // replay, step (1): flat records per lane whose loads are in flight together
+#endif
+#ifndef COMMET_TQ_PIECE
+#define COMMET_TQ_PIECE 256
+#endif
+constexpr uint32_t TQ_PIECE = COMMET_TQ_PIECE;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
 constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
 
 struct QueryListView {
@@ -298,8 +307,10 @@ __global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const u
 }
 
 // replay: one workgroup per piece, one thread per read.
+// (scalar registers capped, COMMET_SGPRS in kernels.hpp: eight workgroups per CU instead of six — the LDS (19.3 KiB) and the 50
+// vector registers allow eight, and the kernel is a chain of dependent round trips that lives on workgroups in flight)
 template <typename W, int GS, int MW>
-__global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, QueryListView ql, const uint8_t *__restrict__ qres,
+__global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsView rv, QueryListView ql, const uint8_t *__restrict__ qres,
                                                              FilterGroupView fg, int k, int t, const uint64_t *__restrict__ sel,
                                                              uint64_t *__restrict__ tags, unsigned long long *__restrict__ counters,
                                                              uint32_t cstride, uint32_t piece0)
@@ -330,31 +341,48 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                 if ((int) lane >= o) inc += x;
             }
             const uint32_t total = __shfl(inc, 63, 64);
-            for (uint32_t f0 = 0; f0 < total; f0 += 64) {              // (uniform trip count: every lane takes part in the shuffles)
-                const uint32_t f = f0 + lane;
-                // tile of flat record f = number of lanes whose inclusive prefix is <= f (binary search over the 64 prefixes)
-                uint32_t lo = 0, hi = 64;
+            // TQ_COLLECT_U flat records per lane and round: their result bytes and owner words are independent loads, all issued
+            // before the first is looked at — one round trip per round instead of two per record (the loop used to wait for a
+            // record's result byte, then, for the one in four that is not zero, for its owner word).  The owner words of the
+            // zero results cost no memory traffic: their sectors are fetched for their neighbours anyway.
+            for (uint32_t f0 = 0; f0 < total; f0 += 64 * TQ_COLLECT_U) {              // (uniform trip count: every lane takes part in the shuffles)
+                unsigned long long ri[TQ_COLLECT_U];
+                bool ok[TQ_COLLECT_U];
 #pragma unroll
-                for (int step = 0; step < 7; ++step) {
-                    const uint32_t mid = min((lo + hi) >> 1, 63u);
-                    const uint32_t pm = __shfl(inc, (int) mid, 64);
-                    if (lo < hi) {
-                        if (pm <= f) lo = mid + 1;
-                        else hi = mid;
+                for (int u = 0; u < TQ_COLLECT_U; ++u) {
+                    const uint32_t f = f0 + 64u * (uint32_t) u + lane;
+                    // tile of flat record f = number of lanes whose inclusive prefix is <= f (binary search over the 64 prefixes)
+                    uint32_t lo = 0, hi = 64;
+#pragma unroll
+                    for (int step = 0; step < 7; ++step) {
+                        const uint32_t mid = min((lo + hi) >> 1, 63u);
+                        const uint32_t pm = __shfl(inc, (int) mid, 64);
+                        if (lo < hi) {
+                            if (pm <= f) lo = mid + 1;
+                            else hi = mid;
+                        }
                     }
+                    const uint32_t src = min(lo, 63u);
+                    const uint32_t before_raw = __shfl(inc, (int) (src ? src - 1 : 0), 64);
+                    const unsigned long long tbase = __shfl((unsigned long long) ta, (int) src, 64);
+                    ok[u] = f < total;
+                    ri[u] = ok[u] ? tbase + (f - (src ? before_raw : 0u)) : 0ull;     // (record 0 exists whenever the batch has one)
                 }
-                const uint32_t src = min(lo, 63u);
-                const uint32_t before_raw = __shfl(inc, (int) (src ? src - 1 : 0), 64);
-                const unsigned long long tbase = __shfl((unsigned long long) ta, (int) src, 64);
-                if (f >= total) continue;
-                const unsigned long long i = tbase + (f - (src ? before_raw : 0u));
-                const uint32_t res = __builtin_nontemporal_load(qres + i);
-                if (!res) continue;
-                const uint32_t who = __builtin_nontemporal_load(ql.qwho + i), rd = who & 255u, win = who >> 8;
+                uint32_t res[TQ_COLLECT_U], who[TQ_COLLECT_U];
 #pragma unroll
-                for (int c = 0; c < GS; ++c) {
-                    if ((res >> c) & 1u) atomicOr(&mask_at(c, 0, (int) (win >> 5), rd), 1u << (win & 31u));
-                    if ((res >> (GS + c)) & 1u) atomicOr(&mask_at(c, 1, (int) (win >> 5), rd), 1u << (win & 31u));
+                for (int u = 0; u < TQ_COLLECT_U; ++u) {
+                    res[u] = __builtin_nontemporal_load(qres + ri[u]);
+                    who[u] = __builtin_nontemporal_load(ql.qwho + ri[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < TQ_COLLECT_U; ++u) {
+                    if (!ok[u] || !res[u]) continue;
+                    const uint32_t rd = who[u] & 255u, win = who[u] >> 8;
+#pragma unroll
+                    for (int c = 0; c < GS; ++c) {
+                        if ((res[u] >> c) & 1u) atomicOr(&mask_at(c, 0, (int) (win >> 5), rd), 1u << (win & 31u));
+                        if ((res[u] >> (GS + c)) & 1u) atomicOr(&mask_at(c, 1, (int) (win >> 5), rd), 1u << (win & 31u));
+                    }
                 }
             }
         }
@@ -440,7 +468,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         const uint32_t ex = block_scan<TQ_PIECE>(cnt, scan_ws, &total);
         pre[threadIdx.x] = ex + cnt;                      // inclusive
         __syncthreads();
-        constexpr int U = 2;
+        constexpr int U = TQ_SWEEP_U;
         for (uint32_t f0 = threadIdx.x; f0 < total; f0 += U * TQ_PIECE) {
             uint32_t owner[U], bitn[U], fw[U], fbit[U];
             W ka[U], kb[U];
@@ -500,6 +528,7 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
         sweep(masks,
               [&](int i, W, W kb, uint32_t &bit) -> const uint32_t * {
                   bit = (uint32_t) kb & 31u;
+                  if (COMMET_TQ_ABLATE & 262144) return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words + ((kb >> 5) & 0x1FFFFu);   // timing bound: plane B served from L2
                   return fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words + (kb >> 5);
               },
               [&](uint32_t owner, int i, int h, uint32_t b, W ka, W kb) {
@@ -598,7 +627,8 @@ __global__ __launch_bounds__(TQ_PIECE) void tq_replay_kernel(ReadsView rv, Query
                     if (!it.window((uint32_t) q & 31u, k, kmask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
                     const W ka = strand ? (W) (~wh & kmask) : (W) (T::brev(wh) >> sh);
                     const W addr = psi_a<W>(ka, k);
-                    const uint32_t v = fg.il_a[(uint64_t) (addr >> 5) * GS + (uint32_t) (i >> 1)];
+                    const uint32_t v = (COMMET_TQ_ABLATE & 524288) ? fg.il_a[(uint64_t) ((addr >> 5) & 0x1FFFFu) * GS + (uint32_t) (i >> 1)]   // timing bound: tails served from L2
+                                                                   : fg.il_a[(uint64_t) (addr >> 5) * GS + (uint32_t) (i >> 1)];
                     if ((v >> ((uint32_t) addr & 31u)) & 1u) atomicOr(&tail_bits[owner], 1u << w);
                 }
                 __syncthreads();

@@ -166,6 +166,9 @@ class HipEngine:
         # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
         self._api = commet_amd
         self.ctx = commet_amd.Context(k=k, t=t, device=sharding.pick_device(local_rank, commet_amd.device_count()))
+        self._kernel_times = os.environ.get("COMMET_MATRIX_KERNEL_TIMES", "0") == "1"
+        if self._kernel_times:
+            self.ctx.set_option("kernel_timing", 1)
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if "COMMET_FORCE_DEVICE" in os.environ and world > 1:
             # several ranks on ONE device (a rehearsal): the cached query lists of all of them must fit it together — no rank can
@@ -219,6 +222,11 @@ class HipEngine:
 
     def index_and_search(self, index, searches, isel, ssels):
         return self.ctx.index_and_search(index, searches, isel, ssels)
+
+    def kernel_times(self):
+        """COMMET_MATRIX_KERNEL_TIMES=1: {kernel: [launches, ms]} of this rank's jobs (a hipEvent pair around every launch; the chunks
+        of a group are then built one after the other, so the figures add up but the run is a little slower) — else None"""
+        return {k: [c, round(ms, 3)] for k, (c, ms) in self.ctx.kernel_times().items()} if self._kernel_times else None
 
     def synchronize(self):
         self.ctx.synchronize()
@@ -738,6 +746,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
         prof["jobs_s"] = jobs_s
         prof["set_wait_s"] = set_wait[0]
+        if hasattr(eng, "kernel_times") and eng.kernel_times() is not None:
+            prof["kernel_ms"] = eng.kernel_times()
         if loader is not None:
             for s in order:                                      # (one rank: a set no pair needs is still loaded and counted)
                 wait_for(s)

@@ -170,6 +170,49 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
                 pos += n
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_job_sparse_passes_match_oracle(tmp_path, seed):
+    """a pass over a selection of a search set walks the list of its reads (kernels.hpp ActiveList: sel & ~tags, in order, re-made
+    per pass) instead of the set's bitmap — forced on the randomised scenarios (multi-file sets, filter bvs incl. all-zero ones,
+    ragged / short / N-rich reads, t = 1..4) for the plain kernel and groups of 2, 4 and 5..8 chunk filters, 32- and 64-bit keys"""
+    import commet_amd as commet
+    k = [16, 20, 25, 32, 33, 12, 28, 34][seed % 8]
+    scn = Scenario(str(tmp_path / "scn"), 1300 + seed, k=k, n_scale=[1.0, 6.0, 20.0][seed % 3], allow_zero_bv=seed % 5 == 0)
+    max_kmer = [0, 2500, 700][(seed // 8) % 3] if k >= 16 else 0
+    out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
+    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o, max_kmer=max_kmer)
+    assert rc == 0
+    with commet.Context(k=scn.k, t=scn.t) as ctx:
+        irs, isel = _load_set(commet, ctx, scn.sets[scn.index_name], scn.dir)
+        srs, ssel = [], []
+        for nme in sorted(scn.search_names):
+            r, s = _load_set(commet, ctx, scn.sets[nme], scn.dir)
+            srs.append(r)
+            ssel.append(s)
+        ctx.set_option("sparse_search", 2)
+        ctx.set_option("slice_mode", 1)                       # (the bit-sliced regime has no list form: the slot kernels)
+        ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("chunk_group", [8, 1, 2, 4][(seed // 2) % 4])
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, srs, isel, ssel)
+        times = ctx.kernel_times()
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        # a set with a filter bv that does not select every read, searched against at least one chunk: its passes walked a list
+        partial = [any(bv and not sel.all() for _, bv, _, sel in scn.sets[nme]) and sum(len(r) for _, _, r, _ in scn.sets[nme]) > 0
+                   for nme in sorted(scn.search_names)]
+        if chunks and any(partial):
+            assert "active_list_kernels" in times
+        by_name = {r["name"]: r for r in res}
+        for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
+            o = by_name[nme]
+            assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
+            pos = 0
+            for fa, _, reads, _ in scn.sets[nme]:
+                _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
+                pos += n
+
+
 @pytest.mark.parametrize("k,t,chunk_group", [(20, 2, 4), (24, 3, 2), (33, 2, 4), (16, 2, 1)])
 def test_long_and_ragged_reads(tmp_path, k, t, chunk_group):
     """reads far longer than the fast paths' limits (search masks cover 256 bases, chunk groups need <= 64 KiB of

@@ -19,8 +19,13 @@ def main():
         s1 = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
         for rep in range(2):
             out = {}
+            ctx.set_option("kernel_timing", 1)
+            t1, st1, info1 = ctx.index_and_search(s0, [s1])                 # J1: S_1 in S_0
+            kt1 = ctx.kernel_times()
             ctx.set_option("kernel_timing", 0)
-            t1, _, _ = ctx.index_and_search(s0, [s1])                       # J1: S_1 in S_0
+            out["J1"] = dict(total_ms=round(info1["total_ms"], 2), index_ms=round(info1["index_ms"], 2), search_ms=round(info1["search_ms"], 2),
+                             chunks=info1["n_chunks"], shared=st1[0]["shared"],
+                             kernels={k: [c, round(ms, 3)] for k, (c, ms) in sorted(kt1.items(), key=lambda kv: -kv[1][1]) if ms > 0.5})
             for name, idx, srch, sel in (("J2", s1, s0, t1[0]), ("J3", s0, s1, None)):
                 if name == "J3":
                     sel = out["_t2"]
