@@ -41,8 +41,6 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     if (const char *e = getenv("COMMET_TQ_WPX")) c->tq_wpx = (unsigned) std::max(1, atoi(e));
     if (const char *e = getenv("COMMET_TQ_PARTS")) c->tq_parts = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("COMMET_LANE_STAGGER")) c->lane_stagger = atoi(e) != 0;
-    if (const char *e = getenv("COMMET_WS_CANDIDATES")) c->ws_candidates = std::max(1, std::min(8, atoi(e)));
-    c->ws_verbose = getenv("COMMET_WS_VERBOSE") != nullptr;
     c->stage_reads = getenv("COMMET_NO_STAGE_READS") == nullptr;
     c->job_verbose = getenv("COMMET_JOB_VERBOSE") != nullptr;
     c->ingest_verbose = getenv("COMMET_INGEST_VERBOSE") != nullptr;
@@ -123,7 +121,6 @@ void commet_destroy(commet_ctx *c)
     (void) hipFree(c->d_actblk);
     c->part[0].release();
     c->part[1].release();
-    trim_ws_pool(c);
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
     if (c->load_stream) (void) hipStreamSynchronize(c->load_stream), (void) hipStreamDestroy(c->load_stream);
     if (c->ev_stagger) (void) hipEventDestroy(c->ev_stagger);

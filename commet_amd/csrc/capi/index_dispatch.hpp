@@ -98,8 +98,8 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         ws.cap_keys = 0;
         const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
         // (touched there, too: a first touch inside the first scatter launch cost 15.6 instead of 2.5 ms)
-        HIP_OK(alloc_fastest(c, (void **) &ws.bufA, cap * sizeof(uint32_t), stream, c->ws_candidates, lane ? "scatter workspace A (lane 1)" : "scatter workspace A"));
-        HIP_OK(alloc_fastest(c, (void **) &ws.bufB, cap * sizeof(uint32_t), stream, c->ws_candidates, lane ? "scatter workspace B (lane 1)" : "scatter workspace B"));
+        HIP_OK(alloc_workspace(c, (void **) &ws.bufA, cap * sizeof(uint32_t), stream));
+        HIP_OK(alloc_workspace(c, (void **) &ws.bufB, cap * sizeof(uint32_t), stream));
         ws.cap_keys = cap;
     }
     const bool wide = c->k > 32;

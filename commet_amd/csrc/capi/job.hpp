@@ -588,7 +588,6 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     }
     if (info && !rc)
         info->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    trim_ws_pool(c);   // workspace candidates nobody took in this job (a one-lane job leaves two): given back, outside the job's clock
     return rc;
 }
 

@@ -89,12 +89,7 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->lane_stagger = value != 0;
         return 0;
     }
-    if (!strcmp(name, "ws_candidates")) {     // scatter workspaces allocated per buffer, the fastest kept (1 = take the first); applies to
-        if (value < 1 || value > 8) return fail("ws_candidates must be in [1, 8]");   // workspaces allocated from now on
-        c->ws_candidates = (int) value;
-        return 0;
-    }
-    if (!strcmp(name, "drop_workspaces")) {   // frees the scatter workspaces; the next bucketed index build allocates them again (tools/s1_variance.py)
+    if (!strcmp(name, "drop_workspaces")) {   // frees the scatter workspaces; the next bucketed index build allocates them again
         (void) hipStreamSynchronize(c->stream);
         (void) hipStreamSynchronize(c->aux_stream);
         for (auto &w : c->part) {
@@ -102,7 +97,6 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
             w.bufA = w.bufB = nullptr;
             w.cap_keys = 0;
         }
-        trim_ws_pool(c);
         return 0;
     }
     if (!strcmp(name, "part_packed")) {

@@ -124,11 +124,6 @@ struct commet_ctx {
     int lane_stagger = 1;                     // option / COMMET_LANE_STAGGER: the second lane's chunk starts behind the first lane's scatter1 (index_dispatch.hpp)
     bool stagger_armed = false;
     hipEvent_t ev_stagger = nullptr;
-    int ws_candidates = 4;                    // option / COMMET_WS_CANDIDATES: buffers allocated and timed when a scatter workspace is first needed (alloc_fastest)
-    struct WsCand { void *ptr; size_t bytes; float ms; };
-    std::vector<WsCand> ws_pool;              // timed candidates not (yet) chosen: the next workspaces take the fastest that fits; freed when the job ends
-    std::mutex ws_pool_mu;
-    bool ws_verbose = false;                  // COMMET_WS_VERBOSE: the candidates' fill times on stderr
 
     int n_slots = 1;                  // filter slots allocated behind `filter` (chunk groups, kernels.hpp)
     int cur_slot = 0;                 // slot the index / search launch helpers work on

@@ -203,11 +203,6 @@ int commet_index_and_search(commet_ctx *ctx,
  *   index_lanes (1/2)    2 = the chunks of a group are built on two streams (default)
  *   lane_stagger (0/1)   two lanes: the second lane's chunk starts when the first lane's scatter1 is through (default 1), so that
  *                        its VALU-bound phases run beside the first chunk's HBM-bound ones; 0 = both chunks start together
- *   ws_candidates (1..8) buffers allocated and timed (one fill each) when a scatter workspace is first needed: the fastest becomes
- *                        that workspace, the others serve the workspaces asked for next (the job's second buffer, the second
- *                        index lane) fastest first, and what is left is freed when the job ends (default 4 = the four buffers
- *                        of a two-lane context: no allocation beyond those; how a multi-GB buffer is backed decides how fast
- *                        kernels sweep it, and that is drawn per allocation)
  *   drop_workspaces      frees the scatter workspaces (the next bucketed index build allocates them again)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
  *                        for read sets with at most 96 first-hit windows per read, else 4)
@@ -226,6 +221,10 @@ int commet_index_and_search(commet_ctx *ctx,
  *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096 (sets of up to ~15 M reads;
  *                        larger lists — a 50 M-read set's is 11 GB — pay in long-lived contexts only: allocating them costs
  *                        15-30 ms per GiB; lists of more than 4 GiB are built for a set's second eligible scan)
+ *   sparse_search (0/1/2) a pass over a SELECTION of a search set (a filter bv that leaves few reads: file_manager.h:88-112 skips the
+ *                        others) walks the list of the selected, not yet tagged reads instead of the set's bitmap, so that every
+ *                        lane of a wave has a read: 0 = when the host plan visits less than half of the set's reads, 1 = never,
+ *                        2 = whenever a selection applies (tests)
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction

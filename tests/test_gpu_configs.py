@@ -141,65 +141,6 @@ def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# one pair of configs[3]: 2 x 50 M reads, 7 index chunks -> search_group8_kernel<u32, 2>, one pass
-# ---------------------------------------------------------------------------------------------------------------
-def test_c4_sized_pair_seven_chunks(tmp_path):
-    """one pair of BASELINE configs[3] (10 x 50 M reads) at full size: J1 (7 chunks, every grouping of the chunk filters),
-    then J2 and J3 on the selection-restricted index sets, every job bit-exact on a 20 000-read sample"""
-    import commet_amd
-    from commet_amd import synth
-    k, t, n, L = 32, 2, 50_000_000, 100
-    b0, o0 = synth.synth_set(0, n, L)
-    b1, o1 = synth.synth_set(1, n, L)
-    with commet_amd.Context(k=k, t=t) as ctx:
-        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
-        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
-        del o0, o1
-        kc = irs.kmer_counts()
-        tags, stats, info = ctx.index_and_search(irs, [qrs])              # default: up to 8 chunk filters per pass
-        assert info["n_chunks"] == 7 and info["search_launches"] == 1
-        for group in (1, 4):                                              # the reference's order; the LDS-mask kernel
-            ctx.set_option("chunk_group", group)
-            tg, sg, ig = ctx.index_and_search(irs, [qrs])
-            assert ig["search_launches"] == (7 if group == 1 else 2)
-            assert np.array_equal(tg[0], tags[0]), group
-            assert (sg[0]["indexed"], sg[0]["searched"], sg[0]["shared"]) == \
-                (stats[0]["indexed"], stats[0]["searched"], stats[0]["shared"]), group
-        # the rest of the pair's chain as Commet.py runs it (Commet.py:186-240) at configs[3]'s size:
-        # J2 = S_0 in (S_1 restricted to J1's result), J3 = S_1 in (S_0 restricted to J2's result)
-        kc1 = qrs.kmer_counts()
-        ctx.set_option("chunk_group", 8)
-        tags2, stats2, info2 = ctx.index_and_search(qrs, [irs], index_select=tags[0])
-        tags3, stats3, info3 = ctx.index_and_search(irs, [qrs], index_select=tags2[0])
-    found = util.bools_from_bits(tags[0], n)
-    assert stats[0]["shared"] == int(found.sum())
-    assert stats[0]["indexed"] == n - 6                                   # six look-ahead reads dropped (SURVEY Q1)
-    assert found[: n // 4].mean() > 0.85 and found[n // 4:].mean() < 0.02
-    T2, T3 = util.bools_from_bits(tags2[0], n), util.bools_from_bits(tags3[0], n)
-    assert stats2[0]["shared"] == int(T2.sum()) and stats3[0]["shared"] == int(T3.sum())
-    # (T3 within T1 is NOT an invariant: J3's two chunks each span reads that J1 had in several of its seven chunks, so two
-    # hits that J1 saw in different filters can meet in one of J3's; the sample replays below are the check.  It is rare.)
-    assert int((T3 & ~found).sum()) < n // 1000
-    assert info2["n_chunks"] == 2 and info3["n_chunks"] == 2              # a quarter of 50 M reads: 8.6e8 k-mers
-    rng = np.random.default_rng(5)
-    smp, smp0 = _sample(rng, n, 6000, 14000), _sample(rng, n, 6000, 14000)
-    sb = np.ascontiguousarray(b1.reshape(n, L)[smp]).reshape(-1)
-    sb0 = np.ascontiguousarray(b0.reshape(n, L)[smp0]).reshape(-1)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(3) as pool:   # 7 + 2 + 2 chunk filters, each built by a worker process of its own
-        r1 = pool.submit(_replay, str(tmp_path), "c4", b0, L, None, kc, k, t, sb)
-        r2 = pool.submit(_replay, str(tmp_path), "c4j2", b1, L, found, kc1, k, t, sb0)   # index set restricted to J1's result
-        r3 = pool.submit(_replay, str(tmp_path), "c4j3", b0, L, T2, kc, k, t, sb)
-        (want, nch), (want2, nch2), (want3, nch3) = r1.result(), r2.result(), r3.result()
-    assert nch == 7
-    assert np.array_equal(found[smp], want)
-    assert want.sum() > 4000
-    assert nch2 == 2 and np.array_equal(T2[smp0], want2)
-    assert nch3 == 2 and np.array_equal(T3[smp], want3)
-    assert want2.sum() > 4000 and want3.sum() > 4000
-
-
-# ---------------------------------------------------------------------------------------------------------------
 # search_group8_kernel: three mask words (65..96 first-hit windows) and 64-bit keys, more than four chunks each
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("k,t,L,max_kmer,n_idx", [
@@ -589,13 +530,31 @@ def test_c4_matrix_as_the_driver_runs_it(c4m, tmp_path):
         rs_ref = commet_amd.ReadSet.from_files(ctx, [(b_ref, offs)])
         rs_i = commet_amd.ReadSet.from_files(ctx, [(b_i, offs)])
         kc_ref, kc_i = rs_ref.kmer_counts(), rs_i.kmer_counts()
-        tags1, st1, inf1 = ctx.index_and_search(rs_ref, [rs_i])          # J1(ref, i) on its own
+        tags1, st1, inf1 = ctx.index_and_search(rs_ref, [rs_i])          # J1(ref, i) on its own: up to 8 chunk filters per pass
+        assert inf1["n_chunks"] == 7 and inf1["search_launches"] == 1
+        for group in (1, 4):                                             # the reference's order; the LDS-mask kernel (4 + 3 filters)
+            ctx.set_option("chunk_group", group)
+            tg, sg, ig = ctx.index_and_search(rs_ref, [rs_i])
+            assert ig["search_launches"] == (7 if group == 1 else 2)
+            assert np.array_equal(tg[0], tags1[0]), group
+            assert (sg[0]["indexed"], sg[0]["searched"], sg[0]["shared"]) == (st1[0]["indexed"], st1[0]["searched"], st1[0]["shared"]), group
+        ctx.set_option("chunk_group", 8)
+        # the rest of the pair's chain through the API (Commet.py:186-240): the same bits as the driver's files
+        tags2, st2, inf2 = ctx.index_and_search(rs_i, [rs_ref], index_select=tags1[0])
+        tags3, st3, inf3 = ctx.index_and_search(rs_ref, [rs_i], index_select=tags2[0])
+        assert inf2["n_chunks"] == 2 and inf3["n_chunks"] == 2           # a quarter of 50 M reads: 8.6e8 k-mers
     del offs
     T1 = util.bools_from_bits(tags1[0], n)
+    assert st1[0]["shared"] == int(T1.sum()) and st1[0]["indexed"] == n - 6      # six look-ahead reads dropped
+    assert T1[: n // 4].mean() > 0.4 and T1[n // 4:].mean() < 0.02      # (both sets' first quarters are mutated copies of set 0's)
     _, n2, bits2 = util.read_bv(os.path.join(out, f"set{ref}.fa_in_S{i}.bv"))      # J2: S_ref in (S_i restricted to T1)
     _, n3, bits3 = util.read_bv(os.path.join(out, f"set{i}.fa_in_S{ref}.bv"))      # J3: S_i in (S_ref restricted to T2)
     T2, T3 = util.bools_from_bits(bits2, n2), util.bools_from_bits(bits3, n3)
     assert n2 == n3 == n and inf1["n_chunks"] == 7
+    assert np.array_equal(util.bools_from_bits(tags2[0], n), T2) and np.array_equal(util.bools_from_bits(tags3[0], n), T3)
+    # (T3 within T1 is NOT an invariant: J3's two chunks each span reads that J1 had in several of its seven chunks, so two
+    # hits that J1 saw in different filters can meet in one of J3's; the sample replays below are the check.  It is rare.)
+    assert int((T3 & ~T1).sum()) < n // 1000
     assert T3.sum() == m[i][ref] and T2.sum() == m[ref][i]
     for (a, b) in [(0, 9), (9, 0), (5, 4)]:
         _, nn, bits = util.read_bv(os.path.join(out, f"set{a}.fa_in_S{b}.bv"))

@@ -4,7 +4,7 @@
 #   e.g.  bash tools/env_ab.sh COMMET_TQ_WPX 16 32 64 128                                            (probe workgroups per XCD)
 #         bash tools/env_ab.sh COMMET_TQ_PARTS 1 2 3 4
 #         bash tools/env_ab.sh COMMET_SLICE_WIDE 1 2 -- --reads 20000000 --read-len 150 -k 21 -t 5   (configs[4]: narrow tables / wide rows)
-#         bash tools/env_ab.sh COMMET_INDEX_LANES 1 2 ; bash tools/env_ab.sh COMMET_WS_CANDIDATES 1 4
+#         bash tools/env_ab.sh COMMET_INDEX_LANES 1 2
 set -e
 cd $GRAFT_REPO_ROOT
 V=$1; shift
