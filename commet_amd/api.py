@@ -42,6 +42,16 @@ def device_count():
     return int(_l.load().commet_device_count())
 
 
+def device_cache_trim(device=-1):
+    """commet_device_cache_trim: gives the device memory the library keeps for reuse back to the driver; returns the bytes released"""
+    return int(_l.load().commet_device_cache_trim(int(device)))
+
+
+def device_cache_bytes(device=0):
+    """commet_device_cache_bytes: device memory filed for reuse on `device`"""
+    return int(_l.load().commet_device_cache_bytes(int(device)))
+
+
 class Context:
     """commet_ctx: device, k, t, the 4-lane Bloom filter in HBM."""
 

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <functional>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <set>

@@ -32,7 +32,7 @@ uint64_t shrink_query_lists(commet_ctx *c, uint64_t target, bool even_in_job)
 // hipMalloc that gives the cached query lists back and tries once more when the device is out of memory
 hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
 {
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = dm_malloc(p, bytes);
     if (e != hipErrorOutOfMemory) return e;
     (void) hipGetLastError();
     uint64_t freed;
@@ -41,7 +41,7 @@ hipError_t dev_alloc(commet_ctx *c, void **p, size_t bytes, bool job_thread)
         freed = shrink_query_lists(c, 0, job_thread);
     }
     if (!freed) return e;
-    e = hipMalloc(p, bytes);
+    e = dm_malloc(p, bytes);
     if (e == hipErrorOutOfMemory) (void) hipGetLastError();
     return e;
 }
@@ -78,6 +78,16 @@ void commet_readset_drop_cache(commet_readset *rs)
     if (rs->in_job) return;                              // (never under a running job)
     drop_query_list(c, rs);
     rs->ql.failed = false;                               // a list that did not fit once may fit now
+}
+
+uint64_t commet_device_cache_trim(int device)
+{
+    return (uint64_t) dm_trim(device);
+}
+
+uint64_t commet_device_cache_bytes(int device)
+{
+    return (uint64_t) dm_filed_bytes(device);
 }
 
 int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions)

@@ -65,7 +65,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->plane_words = plane_bits < 32 ? 1 : plane_bits / 32;
     c->filter_bytes = 4 * c->plane_words * sizeof(uint32_t);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **) &c->filter, c->filter_bytes);
+    if (e == hipSuccess) e = dm_malloc((void **) &c->filter, c->filter_bytes);
     if (e != hipSuccess) {
         if (e == hipErrorOutOfMemory)
             fail("Index memory allocation impossible, try with a lower k value or with more RAM memory");
@@ -73,7 +73,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
         commet_destroy(c);
         return nullptr;
     }
-    e = hipMalloc((void **) &c->d_counters, N_COUNTERS * sizeof(unsigned long long));
+    e = dm_malloc((void **) &c->d_counters, N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **) &c->h_counters, N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_i0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_i1);
@@ -100,25 +100,25 @@ void commet_destroy(commet_ctx *c)
     if (!c) return;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    if (c->filter) (void) hipFree(c->filter);
+    if (c->filter) (void) dm_free(c->filter);
     for (commet_ctx::IngestBuf &b : c->ingest_pool) {
         if (b.h_planes) (void) hipHostFree(b.h_planes);
         if (b.h_goff) (void) hipHostFree(b.h_goff);
         if (b.done) (void) hipEventDestroy(b.done);
     }
     c->kclock.release();
-    (void) hipFree(c->d_qres);
-    (void) hipFree(c->slice_stage);
-    (void) hipFree(c->slice_tables);
-    (void) hipFree(c->wide_tables);
-    (void) hipFree(c->d_slice_chunks);
-    (void) hipFree(c->il_a);
-    (void) hipFree(c->d_jobcnt);
-    (void) hipFree(c->d_plansum);
-    (void) hipFree(c->d_ids);
-    (void) hipFree(c->d_idblk);
-    (void) hipFree(c->d_act);
-    (void) hipFree(c->d_actblk);
+    (void) dm_free(c->d_qres);
+    (void) dm_free(c->slice_stage);
+    (void) dm_free(c->slice_tables);
+    (void) dm_free(c->wide_tables);
+    (void) dm_free(c->d_slice_chunks);
+    (void) dm_free(c->il_a);
+    (void) dm_free(c->d_jobcnt);
+    (void) dm_free(c->d_plansum);
+    (void) dm_free(c->d_ids);
+    (void) dm_free(c->d_idblk);
+    (void) dm_free(c->d_act);
+    (void) dm_free(c->d_actblk);
     c->part[0].release();
     c->part[1].release();
     if (c->aux_stream) (void) hipStreamSynchronize(c->aux_stream), (void) hipStreamDestroy(c->aux_stream);
@@ -126,10 +126,10 @@ void commet_destroy(commet_ctx *c)
     if (c->ev_stagger) (void) hipEventDestroy(c->ev_stagger);
     if (c->list_stream) (void) hipStreamSynchronize(c->list_stream), (void) hipStreamDestroy(c->list_stream);
     if (c->ev_list) (void) hipEventDestroy(c->ev_list);
-    (void) hipFree(c->d_ql_totals);
+    (void) dm_free(c->d_ql_totals);
     if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void) hipEventDestroy(c->ev_join);
-    if (c->d_counters) (void) hipFree(c->d_counters);
+    if (c->d_counters) (void) dm_free(c->d_counters);
     if (c->h_counters) (void) hipHostFree(c->h_counters);
     if (c->ev_i0) (void) hipEventDestroy(c->ev_i0);
     if (c->ev_i1) (void) hipEventDestroy(c->ev_i1);
@@ -153,6 +153,7 @@ int commet_device_memory(const commet_ctx *c, uint64_t *free_bytes, uint64_t *to
     HIP_OK(hipSetDevice(c->device));
     size_t f = 0, t = 0;
     HIP_OK(hipMemGetInfo(&f, &t));
+    f += dm_filed_bytes(c->device);                          // (blocks the library keeps for reuse are free to its callers)
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return 0;

@@ -79,8 +79,8 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     if (g.b2 == 0) g.packed = 0;   // single level: scatter1 writes the final buckets itself, as plain keys
     const uint64_t total = 4 * kmers;
     if (ws.nb != g.nb) {
-        (void) hipFree(ws.hist); (void) hipFree(ws.wl); (void) hipFree(ws.off); (void) hipFree(ws.goff);
-        (void) hipFree(ws.cur2);
+        (void) dm_free(ws.hist); (void) dm_free(ws.wl); (void) dm_free(ws.off); (void) dm_free(ws.goff);
+        (void) dm_free(ws.cur2);
         ws.hist = ws.wl = nullptr; ws.off = ws.goff = nullptr; ws.cur2 = nullptr;
         HIP_OK(dev_alloc(c, (void **) &ws.hist, (g.nb + 1) * sizeof(uint32_t), true));
         HIP_OK(dev_alloc(c, (void **) &ws.wl, (g.nb + 1) * sizeof(uint32_t), true));
@@ -93,7 +93,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     }
     if (ws.cap_keys < total) {
         HIP_OK(hipStreamSynchronize(stream));
-        (void) hipFree(ws.bufA); (void) hipFree(ws.bufB);
+        (void) dm_free(ws.bufA); (void) dm_free(ws.bufB);
         ws.bufA = ws.bufB = nullptr;
         ws.cap_keys = 0;
         const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant

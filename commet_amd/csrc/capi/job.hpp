@@ -118,7 +118,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         const uint64_t nblk = (index_rs->n_reads + PLAN_BLOCK_READS - 1) / PLAN_BLOCK_READS;
         if (c->plansum_cap < nblk) {
             HIP_OK(hipStreamSynchronize(c->stream));
-            (void) hipFree(c->d_plansum);
+            (void) dm_free(c->d_plansum);
             c->d_plansum = nullptr;
             c->plansum_cap = 0;
             HIP_OK(dev_alloc(c, (void **) &c->d_plansum, nblk * sizeof(unsigned long long), true));
@@ -175,7 +175,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         bool ok = true;
         if (c->ids_cap < plan.indexed_reads || c->idblk_cap < nb + 1) {
             HIP_OK(hipStreamSynchronize(c->stream));
-            (void) hipFree(c->d_ids), (void) hipFree(c->d_idblk);
+            (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
             c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
             const uint64_t cap = std::max<uint64_t>(plan.indexed_reads, index_rs->n_reads / 2);   // (grown rarely)
             ok = dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true) == hipSuccess &&
@@ -222,7 +222,7 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
     std::vector<unsigned long long> h_cnt(n_cnt, 0);
     if (c->jobcnt_cap < n_cnt) {   // kept between calls: hipMalloc / hipFree per job cost more than the counters' kernels
         HIP_OK(hipStreamSynchronize(c->stream));
-        (void) hipFree(c->d_jobcnt);
+        (void) dm_free(c->d_jobcnt);
         c->d_jobcnt = nullptr;
         c->jobcnt_cap = 0;
         HIP_OK(dev_alloc(c, (void **) &c->d_jobcnt, std::max<uint64_t>(n_cnt, 64) * sizeof(unsigned long long), true));

@@ -9,8 +9,8 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
     HIP_OK(hipSetDevice(c->device));
     if (atomic == 4 || atomic == 5) {   // streaming ceilings: 4 = device-to-device copy of table_bytes, 5 = fill
         uint8_t *a = nullptr, *b = nullptr;
-        HIP_OK(hipMalloc((void **) &a, table_bytes));
-        HIP_OK(hipMalloc((void **) &b, table_bytes));
+        HIP_OK(dm_malloc((void **) &a, table_bytes));
+        HIP_OK(dm_malloc((void **) &b, table_bytes));
         hipEvent_t e0, e1;
         HIP_OK(hipEventCreate(&e0));
         HIP_OK(hipEventCreate(&e1));
@@ -28,8 +28,8 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         if (ms_out) *ms_out = ms;
         (void) hipEventDestroy(e0);
         (void) hipEventDestroy(e1);
-        (void) hipFree(a);
-        (void) hipFree(b);
+        (void) dm_free(a);
+        (void) dm_free(b);
         return 0;
     }
     if (atomic >= 100) {   // windowed gathers: atomic = 100 + log2(window bytes), +1000 = XCD-aware sweep; n_access gathers in all
@@ -37,8 +37,8 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         const uint32_t win_words = (1u << ((atomic % 1000) - 100)) / 4;
         const uint64_t n_windows = table_bytes / 4 / win_words;
         uint32_t *table = nullptr, *sink = nullptr;
-        HIP_OK(hipMalloc((void **) &table, n_windows * win_words * 4));
-        HIP_OK(hipMalloc((void **) &sink, 4));
+        HIP_OK(dm_malloc((void **) &table, n_windows * win_words * 4));
+        HIP_OK(dm_malloc((void **) &sink, 4));
         HIP_OK(hipMemsetAsync(table, 0, n_windows * win_words * 4, c->stream));
         // one resident set of workgroups (8 per CU); every thread does `iters` gathers in each window of its XCD's eighth
         const uint32_t grid = 256 * 8;
@@ -57,15 +57,15 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
         if (ms_out) *ms_out = ms / ((double) iters * (double) (n_windows / 8) * grid * 256.0) * (double) n_access;
         (void) hipEventDestroy(e0);
         (void) hipEventDestroy(e1);
-        (void) hipFree(table);
-        (void) hipFree(sink);
+        (void) dm_free(table);
+        (void) dm_free(sink);
         return 0;
     }
     uint64_t words = 1;
     while (words * 2 * 4 <= table_bytes) words *= 2;   // power of two words
     uint32_t *table = nullptr, *sink = nullptr;
-    HIP_OK(hipMalloc((void **) &table, words * 4));
-    HIP_OK(hipMalloc((void **) &sink, 4));
+    HIP_OK(dm_malloc((void **) &table, words * 4));
+    HIP_OK(dm_malloc((void **) &sink, 4));
     HIP_OK(hipMemsetAsync(table, 0, words * 4, c->stream));
     const uint64_t threads = 256ull * 256 * 32;   // 32 blocks of 256 per CU
     const uint32_t iters = (uint32_t) std::max<uint64_t>(1, n_access / threads);
@@ -89,8 +89,8 @@ int commet_membench(commet_ctx *c, int atomic, uint64_t table_bytes, uint64_t n_
     if (ms_out) *ms_out = ms / ((double) iters * threads) * (double) n_access;   // scaled to n_access
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
-    (void) hipFree(table);
-    (void) hipFree(sink);
+    (void) dm_free(table);
+    (void) dm_free(sink);
     return 0;
 }
 
@@ -100,7 +100,7 @@ int commet_ldsbench(commet_ctx *c, int mode, uint32_t n_words, uint64_t n_access
     if (n_words == 0 || (n_words & (n_words - 1)) || n_words > 32768) return fail("ldsbench: n_words must be a power of two <= 32768");
     if (mode < 0 || mode > 5) return fail("ldsbench: mode 0..5");
     uint32_t *sink = nullptr;
-    HIP_OK(hipMalloc((void **) &sink, 4));
+    HIP_OK(dm_malloc((void **) &sink, 4));
     const uint64_t threads = 512ull * 256 * 8;   // 8 workgroups of 512 per CU (LDS permitting)
     const uint32_t iters = (uint32_t) std::max<uint64_t>(1, n_access / threads);
     const size_t lds = (size_t) n_words * 4;
@@ -123,7 +123,7 @@ int commet_ldsbench(commet_ctx *c, int mode, uint32_t n_words, uint64_t n_access
     if (ms_out) *ms_out = ms / ((double) iters * threads) * (double) n_access;
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
-    (void) hipFree(sink);
+    (void) dm_free(sink);
     return 0;
 }
 

@@ -93,7 +93,7 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         (void) hipStreamSynchronize(c->stream);
         (void) hipStreamSynchronize(c->aux_stream);
         for (auto &w : c->part) {
-            (void) hipFree(w.bufA); (void) hipFree(w.bufB);
+            (void) dm_free(w.bufA); (void) dm_free(w.bufB);
             w.bufA = w.bufB = nullptr;
             w.cap_keys = 0;
         }
@@ -129,13 +129,13 @@ int commet_filter_export_reference(commet_ctx *c, uint8_t *out, uint64_t out_byt
     if (nbytes == 0) return 0;
     HIP_OK(hipSetDevice(c->device));
     uint8_t *d_out = nullptr;
-    HIP_OK(hipMalloc((void **) &d_out, nbytes));
+    HIP_OK(dm_malloc((void **) &d_out, nbytes));
     const uint64_t blocks = std::min<uint64_t>((nbytes + 255) / 256, 1u << 20);   // grid-stride beyond
     COMMET_LAUNCH(export_reference_kernel, dim3((unsigned) blocks), dim3(256), 0, c->stream, c->view(), c->k, nbytes, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void) hipFree(d_out);
+    (void) dm_free(d_out);
     if (e != hipSuccess) return fail("filter export failed: %s", hipGetErrorString(e));
     return 0;
 }

@@ -62,19 +62,19 @@ void commet_readset_destroy(commet_readset *rs)
         c->ql_bytes -= std::min(c->ql_bytes, rs->ql.bytes);
         c->sets.erase(std::remove(c->sets.begin(), c->sets.end(), rs), c->sets.end());
     }
-    (void) hipFree(rs->d_planes);
-    (void) hipFree(rs->d_goff);
-    (void) hipFree(rs->d_kcnt);
-    (void) hipFree(rs->d_lenmm);
-    (void) hipFree(rs->d_sel);
-    (void) hipFree(rs->d_tags);
-    (void) hipFree(rs->d_found);
+    (void) dm_free(rs->d_planes);
+    (void) dm_free(rs->d_goff);
+    (void) dm_free(rs->d_kcnt);
+    (void) dm_free(rs->d_lenmm);
+    (void) dm_free(rs->d_sel);
+    (void) dm_free(rs->d_tags);
+    (void) dm_free(rs->d_found);
     rs->ql.release();
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
         if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);
-        (void) hipFree(rs->st[i].d_bases);
-        (void) hipFree(rs->st[i].d_offs);
+        (void) dm_free(rs->st[i].d_bases);
+        (void) dm_free(rs->st[i].d_offs);
         if (rs->st[i].done) (void) hipEventDestroy(rs->st[i].done);
     }
     delete rs;
@@ -99,8 +99,8 @@ int commet_readset_stage_acquire(commet_readset *rs, uint8_t **bases, uint64_t *
     if (!s.h_bases) {   // staging buffers are created on first use (commet_readset_from_fasta has its own)
         HIP_OK(hipHostMalloc((void **) &s.h_bases, rs->stage_bases));
         HIP_OK(hipHostMalloc((void **) &s.h_offs, (rs->stage_reads + 1) * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void **) &s.d_bases, rs->stage_bases));
-        HIP_OK(hipMalloc((void **) &s.d_offs, (rs->stage_reads + 1) * sizeof(uint64_t)));
+        HIP_OK(dm_malloc((void **) &s.d_bases, rs->stage_bases));
+        HIP_OK(dm_malloc((void **) &s.d_offs, (rs->stage_reads + 1) * sizeof(uint64_t)));
         HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     if (s.inflight) {
@@ -409,8 +409,8 @@ int commet_readset_finalize(commet_readset *rs)
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
         if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);
-        (void) hipFree(rs->st[i].d_bases);
-        (void) hipFree(rs->st[i].d_offs);
+        (void) dm_free(rs->st[i].d_bases);
+        (void) dm_free(rs->st[i].d_offs);
         rs->st[i].h_bases = nullptr;
         rs->st[i].h_offs = nullptr;
         rs->st[i].d_bases = nullptr;

@@ -51,13 +51,13 @@ int ensure_slots(commet_ctx *c, int g, int gs)
         uint32_t *nf = nullptr;
         hipError_t e = dev_alloc(c, (void **) &nf, (size_t) g * c->filter_bytes, true);
         if (e != hipSuccess) return fail("cannot allocate %d filter slots: %s", g, hipGetErrorString(e));
-        (void) hipFree(c->filter);
+        (void) dm_free(c->filter);
         c->filter = nf;
         c->n_slots = g;
     }
     if (c->il_stride < gs) {
         HIP_OK(hipStreamSynchronize(c->stream));
-        (void) hipFree(c->il_a);
+        (void) dm_free(c->il_a);
         c->il_a = nullptr;
         c->il_stride = 0;
         HIP_OK(dev_alloc(c, (void **) &c->il_a, (size_t) gs * c->plane_words * sizeof(uint32_t), true));
@@ -188,13 +188,13 @@ int build_active_list(commet_ctx *c, const commet_readset *rs, const uint64_t *d
     const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
     if (c->act_cap < selected || c->actblk_cap < nb + 1) {
         if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
-        (void) hipFree(c->d_act), (void) hipFree(c->d_actblk);
+        (void) dm_free(c->d_act), (void) dm_free(c->d_actblk);
         c->d_act = c->d_actblk = nullptr, c->act_cap = c->actblk_cap = 0;
         const uint64_t cap = std::max<uint64_t>(selected, 1024);
         if (dev_alloc(c, (void **) &c->d_act, cap * sizeof(uint32_t), true) != hipSuccess ||
             dev_alloc(c, (void **) &c->d_actblk, (nb + 1) * sizeof(uint32_t), true) != hipSuccess) {
             (void) hipGetLastError();
-            (void) hipFree(c->d_act), (void) hipFree(c->d_actblk);
+            (void) dm_free(c->d_act), (void) dm_free(c->d_actblk);
             c->d_act = c->d_actblk = nullptr;
             return 1;
         }
@@ -259,17 +259,17 @@ int build_query_list(commet_ctx *c, const commet_readset *rs)
     unsigned long long *d_totals = nullptr;
     // (the caller holds ql_mu: on an allocation failure here the other sets' lists are given back directly)
     auto alloc = [&](void **ptr, size_t bytes) -> hipError_t {
-        hipError_t ae = hipMalloc(ptr, bytes);
+        hipError_t ae = dm_malloc(ptr, bytes);
         if (ae != hipErrorOutOfMemory) return ae;
         (void) hipGetLastError();
         if (!shrink_query_lists(c, 0, false)) return ae;
-        ae = hipMalloc(ptr, bytes);
+        ae = dm_malloc(ptr, bytes);
         if (ae == hipErrorOutOfMemory) (void) hipGetLastError();
         return ae;
     };
     hipError_t e = alloc((void **) &ql.d_tile_off, (entries + 1) * sizeof(unsigned long long));
     if (e == hipSuccess && c->ql_totals_cap < (uint64_t) nb + 1) {
-        (void) hipFree(c->d_ql_totals);                     // (grows a few times in a context's life)
+        (void) dm_free(c->d_ql_totals);                     // (grows a few times in a context's life)
         c->d_ql_totals = nullptr, c->ql_totals_cap = 0;
         e = alloc((void **) &c->d_ql_totals, ((size_t) nb + 1) * sizeof(unsigned long long));
         if (e == hipSuccess) c->ql_totals_cap = (uint64_t) nb + 1;
@@ -353,12 +353,12 @@ int ensure_query_results(commet_ctx *c, const commet_readset *rs)
     const uint64_t need = rs->ql.n_records;
     if (c->qres_cap >= need && c->d_qres) return 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
-    (void) hipFree(c->d_qres);
+    (void) dm_free(c->d_qres);
     c->d_qres = nullptr, c->qres_cap = 0;
-    hipError_t e = hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
+    hipError_t e = dm_malloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
     if (e == hipErrorOutOfMemory) {   // (the caller holds ql_mu) give back the lists of sets outside this job and try once more
         (void) hipGetLastError();
-        if (shrink_query_lists(c, 0, false)) e = hipMalloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
+        if (shrink_query_lists(c, 0, false)) e = dm_malloc((void **) &c->d_qres, std::max<uint64_t>(need, 1));
     }
     if (e != hipSuccess) {
         (void) hipGetLastError();
@@ -456,19 +456,19 @@ int ensure_slice_buffers(commet_ctx *c, int gw, uint64_t n_chunks)
     if (c->slice_stage_words < stage_words || c->slice_table_words < table_words || c->slice_chunks_cap < n_chunks) {
         HIP_OK(hipStreamSynchronize(c->stream));
         if (c->slice_stage_words < stage_words) {
-            (void) hipFree(c->slice_stage);
+            (void) dm_free(c->slice_stage);
             c->slice_stage = nullptr, c->slice_stage_words = 0;
             HIP_OK(dev_alloc(c, (void **) &c->slice_stage, stage_words * 4, true));
             c->slice_stage_words = stage_words;
         }
         if (c->slice_table_words < table_words) {
-            (void) hipFree(c->slice_tables);
+            (void) dm_free(c->slice_tables);
             c->slice_tables = nullptr, c->slice_table_words = 0;
             HIP_OK(dev_alloc(c, (void **) &c->slice_tables, table_words * 4, true));
             c->slice_table_words = table_words;
         }
         if (c->slice_chunks_cap < n_chunks) {
-            (void) hipFree(c->d_slice_chunks);
+            (void) dm_free(c->d_slice_chunks);
             c->d_slice_chunks = nullptr, c->slice_chunks_cap = 0;
             HIP_OK(dev_alloc(c, (void **) &c->d_slice_chunks, n_chunks * sizeof(SliceChunk), true));
             c->slice_chunks_cap = n_chunks;
@@ -541,7 +541,7 @@ WidePlan wide_plan(const commet_ctx *c, uint64_t n_chunks, int slice_gw)
     // four tables of 2^k rows: 16 bytes per row word and key; at most a third of what is free now, and 48 GiB
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return w;
-    const uint64_t have = (uint64_t) c->wide_table_words * 4;        // (what the context already holds counts as free)
+    const uint64_t have = (uint64_t) c->wide_table_words * 4 + dm_filed_bytes(c->device);   // (what the context already holds, and what the library keeps for reuse, counts as free)
     const uint64_t budget = std::min<uint64_t>(((uint64_t) free_b + have) / 3, 48ull << 30);
     uint64_t cap = std::min<uint64_t>(WIDE_MAX_ROW_WORDS, budget / (16ull << c->k));
     if (c->wide_cap_words) cap = std::min<uint64_t>(cap, c->wide_cap_words);
@@ -563,7 +563,7 @@ int ensure_wide_tables(commet_ctx *c, const WidePlan &w)
     const uint64_t words = ((uint64_t) 4 * w.rw) << c->k;
     if (c->wide_table_words >= words) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));
-    (void) hipFree(c->wide_tables);
+    (void) dm_free(c->wide_tables);
     c->wide_tables = nullptr, c->wide_table_words = 0;
     if (dev_alloc(c, (void **) &c->wide_tables, words * 4, true) != hipSuccess) {
         (void) hipGetLastError();

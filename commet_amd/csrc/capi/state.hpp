@@ -37,6 +37,127 @@ inline void note_launch(const void *entry)
         hipLaunchKernelGGL(kernel, __VA_ARGS__);                      \
     } while (0)
 
+// ---- device memory kept for reuse ----------------------------------------------------------------------------------------
+// On this driver a hipMalloc of GBs costs 15-30 ms per GiB, and one that follows the hipFree of tens of GB now and then blocks
+// for 50-150 ms (seen up to 2 s): a context created after another one was closed, a query list built after one was dropped, a
+// workspace that grows — all of them on some job's path (bench.py's configs[2] leg behind the headline: 1.50 s of device time
+// against 1.15 s in a fresh process, the difference being the GPU idling behind such calls; profiles/r05_c2_variance).  So the
+// library never gives a block of 8 MiB or more back while the process lives: dm_free waits for the device, as hipFree does (its
+// callers count on that), and files the block; dm_malloc takes the smallest filed block of the current device that is large enough
+// and at most a quarter larger, else asks hipMalloc — and when hipMalloc is out of memory, everything filed is given back and
+// it is asked once more.  Blocks are never split (an exported set's IPC handle must be that of a whole allocation).
+// At most half the device (COMMET_DEVMEM_CACHE_GB) is kept, the largest blocks going first; commet_device_cache_trim gives all of
+// it back.  COMMET_DEVMEM_CACHE=0: plain hipMalloc / hipFree.
+struct DevMemCache {
+    std::mutex mu;
+    std::map<void *, std::pair<int, size_t>> live;                 // blocks handed out: device, bytes as allocated
+    std::multimap<size_t, void *> filed[16];                       // per device, by size
+    size_t filed_bytes[16] = {0};
+    size_t cap[16] = {0};                                          // bytes kept at most per device (COMMET_DEVMEM_CACHE_GB; default: half the device)
+    int on = -1;
+    bool enabled()
+    {
+        if (on < 0) {
+            const char *e = getenv("COMMET_DEVMEM_CACHE");
+            on = !(e && atoi(e) == 0);
+        }
+        return on != 0;
+    }
+};
+DevMemCache g_devmem;
+constexpr size_t DEVMEM_MIN_FILED = (size_t) 8 << 20;
+
+// gives every filed block of `device` (-1: all) back to the driver; returns the bytes released
+size_t dm_trim(int device)
+{
+    std::vector<void *> drop;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_devmem.mu);
+        for (int d = 0; d < 16; ++d) {
+            if (device >= 0 && d != device) continue;
+            for (auto &b : g_devmem.filed[d]) drop.push_back(b.second), bytes += b.first;
+            g_devmem.filed[d].clear();
+            g_devmem.filed_bytes[d] = 0;
+        }
+    }
+    for (void *q : drop) (void) hipFree(q);
+    return bytes;
+}
+
+size_t dm_filed_bytes(int device)
+{
+    std::lock_guard<std::mutex> lk(g_devmem.mu);
+    return device >= 0 && device < 16 ? g_devmem.filed_bytes[device] : 0;
+}
+
+hipError_t dm_malloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (!g_devmem.enabled()) return hipMalloc(p, bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipMalloc(p, bytes);
+    if (bytes >= DEVMEM_MIN_FILED) {
+        std::lock_guard<std::mutex> lk(g_devmem.mu);
+        auto it = g_devmem.filed[dev].lower_bound(bytes);
+        if (it != g_devmem.filed[dev].end() && it->first <= bytes + bytes / 4) {
+            *p = it->second;
+            g_devmem.filed_bytes[dev] -= it->first;
+            g_devmem.live[*p] = {dev, it->first};
+            g_devmem.filed[dev].erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && dm_trim(dev)) {
+        (void) hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && bytes >= DEVMEM_MIN_FILED) {
+        std::lock_guard<std::mutex> lk(g_devmem.mu);
+        g_devmem.live[*p] = {dev, bytes};
+    }
+    return e;
+}
+
+hipError_t dm_free(void *p)
+{
+    if (!p) return hipSuccess;
+    if (g_devmem.enabled()) {
+        std::pair<int, size_t> what{-1, 0};
+        {
+            std::lock_guard<std::mutex> lk(g_devmem.mu);
+            auto it = g_devmem.live.find(p);
+            if (it != g_devmem.live.end()) what = it->second, g_devmem.live.erase(it);
+        }
+        if (what.first >= 0) {
+            (void) hipDeviceSynchronize();                         // what hipFree does: no kernel still reads the block when somebody else gets it
+            std::vector<void *> over;                              // kept within the cap (other processes may share the device): largest first
+            {
+                std::lock_guard<std::mutex> lk(g_devmem.mu);
+                const int d = what.first;
+                g_devmem.filed[d].emplace(what.second, p);
+                g_devmem.filed_bytes[d] += what.second;
+                if (!g_devmem.cap[d]) {
+                    size_t fr = 0, tot = 0;
+                    const char *e = getenv("COMMET_DEVMEM_CACHE_GB");
+                    if (e) g_devmem.cap[d] = (size_t) (std::max(0.0, atof(e)) * (double) (1ull << 30)) + 1;
+                    else g_devmem.cap[d] = hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 2 : (size_t) 64 << 30;
+                }
+                while (g_devmem.filed_bytes[d] > g_devmem.cap[d] && !g_devmem.filed[d].empty()) {
+                    auto last = std::prev(g_devmem.filed[d].end());
+                    over.push_back(last->second);
+                    g_devmem.filed_bytes[d] -= last->first;
+                    g_devmem.filed[d].erase(last);
+                }
+            }
+            for (void *q : over) (void) hipFree(q);
+            return hipSuccess;
+        }
+    }
+    return hipFree(p);
+}
+
 int fail(const char *fmt, ...)
 {
     char buf[1024];
@@ -102,8 +223,8 @@ struct commet_ctx {
         uint32_t nb = 0;
         void release()
         {
-            (void) hipFree(bufA); (void) hipFree(bufB); (void) hipFree(hist); (void) hipFree(wl); (void) hipFree(off); (void) hipFree(goff);
-            (void) hipFree(cur2); (void) hipFree(blockoff); (void) hipFree(blockcnt);
+            (void) dm_free(bufA); (void) dm_free(bufB); (void) dm_free(hist); (void) dm_free(wl); (void) dm_free(off); (void) dm_free(goff);
+            (void) dm_free(cur2); (void) dm_free(blockoff); (void) dm_free(blockcnt);
             *this = PartWs();
         }
     } part[2];
@@ -268,7 +389,7 @@ struct commet_readset {
         uint64_t bytes = 0, last_use = 0;           // HBM held; the context's ql_clock at the last scan that used the list
         void release()
         {
-            (void) hipFree(d_tile_off); (void) hipFree(d_qaddr); (void) hipFree(d_qwho); (void) hipFree(d_tstart); (void) hipFree(d_tlen);
+            (void) dm_free(d_tile_off); (void) dm_free(d_qaddr); (void) dm_free(d_qwho); (void) dm_free(d_tstart); (void) dm_free(d_tlen);
             *this = QueryList();
         }
     };

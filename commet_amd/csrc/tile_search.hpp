@@ -32,9 +32,6 @@
 
 namespace commet {
 
-#ifndef TQ_PROBE_PREFETCH
-#define TQ_PROBE_PREFETCH 1
-#endif
 #ifndef TQ_SWEEP_U
 #define TQ_SWEEP_U 2     // replay, step (2): candidates per thread and round of the balanced sweep
 #endif
@@ -286,28 +283,7 @@ __global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const u
         if (a4 < e4) {
             const unsigned long long step = (unsigned long long) wpx * 256, m_end = e4 / 4;
             unsigned long long m = a4 / 4 + (unsigned long long) j * 256 + threadIdx.x;
-#if TQ_PROBE_PREFETCH
-            // the next group's addresses travel (an HBM stream: ~2 us) while this group's four gathers (L2: ~0.5 us) are made, instead of
-            // one after the other in every round
-            uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-            if (m < m_end) {
-                const uint32_t *qp = ql.qaddr + 4 * m;
-                q0 = __builtin_nontemporal_load(qp), q1 = __builtin_nontemporal_load(qp + 1), q2 = __builtin_nontemporal_load(qp + 2), q3 = __builtin_nontemporal_load(qp + 3);
-            }
-            while (m < m_end) {
-                const unsigned long long mn = m + step;
-                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-                if (mn < m_end) {
-                    const uint32_t *qp = ql.qaddr + 4 * mn;
-                    n0 = __builtin_nontemporal_load(qp), n1 = __builtin_nontemporal_load(qp + 1), n2 = __builtin_nontemporal_load(qp + 2), n3 = __builtin_nontemporal_load(qp + 3);
-                }
-                const uint32_t r = tq_probe_one<GS>(base, q0) | (tq_probe_one<GS>(base, q1) << 8) | (tq_probe_one<GS>(base, q2) << 16) |
-                                   (tq_probe_one<GS>(base, q3) << 24);
-                __builtin_nontemporal_store(r, (uint32_t *) (qres + 4 * m));
-                q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-                m = mn;
-            }
-#else
+            // (the next group's addresses prefetched while this group's gathers are made: 2.59 against 2.37 ms — the extra registers in flight cost more than the overlap gives)
             for (; m < m_end; m += step) {
                 const uint32_t *qp = ql.qaddr + 4 * m;
                 const uint32_t q0 = __builtin_nontemporal_load(qp), q1 = __builtin_nontemporal_load(qp + 1),
@@ -316,7 +292,6 @@ __global__ __launch_bounds__(256) void tq_probe_kernel(QueryListView ql, const u
                                    (tq_probe_one<GS>(base, q3) << 24);
                 __builtin_nontemporal_store(r, (uint32_t *) (qres + 4 * m));
             }
-#endif
         }
         // the up to three records before a4 and after e4 (all of the slice when it has no whole group)
         if (j == 0 && threadIdx.x < 8) {

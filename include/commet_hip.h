@@ -129,6 +129,14 @@ int             commet_readset_kmer_counts(const commet_readset *rs, uint32_t *k
 uint64_t        commet_readset_cache_bytes(const commet_readset *rs);
 void            commet_readset_drop_cache(commet_readset *rs);
 int             commet_cache_stats(commet_ctx *ctx, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions);
+/* Device memory the library keeps for reuse.  On this driver a hipMalloc of GBs costs 15-30 ms per GiB and now and then blocks
+ * for 50-150 ms behind the hipFree of tens of GB, so blocks of 8 MiB or more that a context, a read set or a cache gives up are
+ * filed per device (at most half the device, COMMET_DEVMEM_CACHE_GB) and handed to the next allocation they fit; they go back to
+ * the driver when an allocation is out of memory, or here.  commet_device_cache_trim(device; -1 = every device) returns the bytes
+ * released, commet_device_cache_bytes(device) what is filed now.  COMMET_DEVMEM_CACHE=0 turns the mechanism off.  Nothing in the
+ * reference corresponds to it (its filters are plain `new char[]`, bloom_filter.h:73). */
+uint64_t        commet_device_cache_trim(int device);
+uint64_t        commet_device_cache_bytes(int device);
 
 /* ---- the two kernels ------------------------------------------------------ */
 /* Replaces `new BloomFilter` per chunk (index_and_search.cpp:256-262,

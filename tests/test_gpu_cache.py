@@ -77,3 +77,39 @@ def test_packed_images_are_byte_reproducible(tmp_path):
         d.save(str(tmp_path / "d.pk"))
     A, Cc, D = (open(tmp_path / f, "rb").read() for f in ("a.pk", "c.pk", "d.pk"))
     assert A == Cc == D
+
+
+def test_device_memory_is_kept_for_reuse_and_given_back():
+    """blocks of 8 MiB or more that a context gives up are filed by the library and handed to the next allocation they fit (a
+    hipMalloc of GBs costs 15-30 ms per GiB on this driver and now and then stalls behind a large hipFree): a second context gets
+    the first one's filter and workspaces, results unchanged although the memory comes with the old bits in it; trimming gives it
+    all back to the driver"""
+    import commet_amd
+    rng = np.random.default_rng(17)
+    k, t, n, L = 28, 2, 150000, 100
+    b0, b1 = _sets(rng, 2, n, L)
+    commet_amd.device_cache_trim()
+    assert commet_amd.device_cache_bytes(0) == 0
+    runs = []
+    for rep in range(3):
+        before = commet_amd.device_cache_bytes(0)
+        with commet_amd.Context(k=k, t=t) as ctx:
+            during = commet_amd.device_cache_bytes(0)
+            a, b = commet_amd.ReadSet.from_files(ctx, [b0]), commet_amd.ReadSet.from_files(ctx, [b1])
+            ctx.set_option("index_mode", 2)                                   # the bucketed build: workspaces of tens of MB
+            tags, stats, info = ctx.index_and_search(a, [b])
+            runs.append((tags[0].copy(), stats[0]["shared"], info["n_chunks"]))
+        after = commet_amd.device_cache_bytes(0)
+        assert after >= (1 << (k - 1))                                        # the filter (2^(k-1) bytes) at least is filed
+        if rep:
+            assert during < before                                            # the new context took filed blocks (its filter first)
+            assert after <= before + (64 << 20)                               # ... and the same blocks came back: nothing new was needed
+    for r in runs[1:]:
+        assert np.array_equal(r[0], runs[0][0]) and r[1:] == runs[0][1:]
+    assert runs[0][1] > n // 4
+    freed = commet_amd.device_cache_trim()
+    assert freed >= (1 << (k - 1)) and commet_amd.device_cache_bytes(0) == 0
+    with commet_amd.Context(k=k, t=t) as ctx:                                 # and a context on fresh memory agrees
+        a, b = commet_amd.ReadSet.from_files(ctx, [b0]), commet_amd.ReadSet.from_files(ctx, [b1])
+        tags, stats, _ = ctx.index_and_search(a, [b])
+        assert np.array_equal(tags[0], runs[0][0]) and stats[0]["shared"] == runs[0][1]
