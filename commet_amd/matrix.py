@@ -705,6 +705,17 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             prof["call_ms"] += inf["total_ms"]
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
 
+        # the .bv and .log files of a job are written by two helper threads while the next job runs (6 MB per 50 M-read file: 3-4 ms
+        # of a job's ~6 ms of host time at configs[3]); all of them are on disk before the jobs' clock stops
+        from concurrent.futures import ThreadPoolExecutor
+        writer, written = ThreadPoolExecutor(2), []
+
+        def out_bv(path, comment, c, b):
+            written.append(writer.submit(write_bv, path, comment, c, b))
+
+        def out_log(*a):
+            written.append(writer.submit(_log, *a))
+
         t_jobs = time.perf_counter()
         for ref in refs:
             wait_for(ref)
@@ -730,19 +741,22 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     T2 = tags2[0]
                     _acc(inf2)
                     for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
-                        write_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-                    _log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
+                        out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
+                    out_log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
                     shared[(ref, i)] = st2[0]["shared"]
                     # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
                     tags3, st3, inf3 = eng.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
                     _acc(inf3)
                     for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
-                        write_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
-                    _log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
+                        out_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
+                    out_log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
                     shared[(i, ref)] = st3[0]["shared"]
                     reads_searched += considered[ref] + considered[i]
             note(f"jobs of set {ref} done ({prof['jobs']} so far)")
         eng.synchronize()
+        for f in written:                                        # (what a writer raised is raised here)
+            f.result()
+        writer.shutdown()
         jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
         prof["jobs_s"] = jobs_s
         prof["set_wait_s"] = set_wait[0]
