@@ -1,6 +1,7 @@
 """Randomised job-level parity cases shared by tests/test_gpu_fuzz.py (a few hundred seeds, in the suite) and tools/fuzz_gpu.py
 (tens of thousands, outside it): one scenario of tests/scenarios.py per seed — index modes, chunk-group sizes, input formats and,
-forced on, the bit-sliced regime (narrow tables and wide rows, one and several passes) and the tiled search (32- and 64-bit keys),
+forced on, the bit-sliced regime (narrow tables and wide rows, one and several passes), the tiled search (32- and 64-bit keys) and
+the list form of sparse search passes,
 a fifth of those with many small chunks (the library's `max_kmer` test hook; the CPU checker is chunked with the same constant).
 Every case compares the GPU job with the CPU checker: .bv bits, [indexed, searched, shared], chunk and k-mer counts, and (probe-
 counting builds) the reference's probe count.  TEST INFRASTRUCTURE ONLY."""
@@ -42,6 +43,8 @@ def fuzz_one(seed):
             ctx.set_option("count_probes", int(counting))
             ctx.set_option("index_mode", mode)
             ctx.set_option("chunk_group", 1 + seed % 8)
+            if not counting and seed % 3 == 1:
+                ctx.set_option("sparse_search", 2)     # passes over a selection walk the list of their reads (kernels.hpp, ActiveList)
             if forced:
                 counting = False
                 ctx.set_option("count_probes", 0)
