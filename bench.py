@@ -413,6 +413,11 @@ def main():
         ranks.close()
         return
 
+    if "COMMET_FORCE_DEVICE" in os.environ and world > 1:
+        # a rehearsal with several ranks on ONE device: what every rank's library keeps of the memory it frees (half the device by
+        # default) must fit the device together — no rank can take memory back from another one's cache
+        os.environ.setdefault("COMMET_DEVMEM_CACHE_GB", str(max(1, 96 // world)))
+
     import numpy as np  # noqa: F401
     import commet_amd
     from commet_amd import synth
