@@ -577,11 +577,8 @@ __global__ __launch_bounds__(256) COMMET_SGPRS void search_kernel(ReadsView rv, 
 #ifndef G8_HEAVY
 #define G8_HEAVY 20   // (8 / 12 / 16 / 20 / 24 / 28: 140 / 130 / 105 / 104 / 101 / 104 ms on a 2 x 50 M-read pair) search_group8_kernel: a scan with more lane-a candidates than this walks them itself
 #endif
-#ifndef GATHER_U
-#define GATHER_U 4   // group kernels, step (1): windows per thread whose lane-a gathers are in flight together
-#endif
 #ifndef G8_WAVES
-#define G8_WAVES 1   // search_group8_kernel: waves per SIMD the register allocation is held to (= workgroups per CU)
+#define G8_WAVES 1   // search_group8_kernel: waves per SIMD the register allocation is held to (1 = whatever 88 VGPRs allow: five workgroups per CU; 3 / 4 / 5 / 7 / 8: 105.6 / 105.7 / 103.7-106.5 / 108.3 / 110.5 ms per 50 M-read target)
 #endif
 #ifndef GROUP8_TAIL_WIN
 #define GROUP8_TAIL_WIN 32
@@ -679,36 +676,21 @@ __global__ __launch_bounds__(256) COMMET_SGPRS void search_group_kernel(ReadsVie
                 uint32_t fm[GS], rm[GS];
 #pragma unroll
                 for (int i = 0; i < GS; ++i) fm[i] = 0, rm[i] = 0;
-                // GATHER_U windows per round: addresses first, their loads issued together, the bits taken out afterwards (see
-                // search_group8_kernel)
-                for (uint32_t j0 = 0; j0 < nb; j0 += GATHER_U) {
-                    GroupWords<GS> gw[GATHER_U];
-                    uint32_t bit[GATHER_U];
-                    bool ok[GATHER_U], sp[GATHER_U];
-#pragma unroll
-                    for (uint32_t x = 0; x < GATHER_U; ++x) {
-                        const uint32_t j = j0 + x;
-                        ok[x] = false, sp[x] = false, bit[x] = 0;
-#pragma unroll
-                        for (int i = 0; i < GS; ++i) gw[x].x[i] = 0;
-                        if (j >= nb) continue;
-                        wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
-                        run = ((va >> j) & 1u) ? run + 1 : 0;
-                        if (run < (uint32_t) k) continue;
+                for (uint32_t j = 0; j < nb; ++j) {
+                    wh = (wh >> 1) | ((W) ((hi >> j) & 1u) << (k - 1));
+                    run = ((va >> j) & 1u) ? run + 1 : 0;
+                    if (run >= (uint32_t) k) {
                         bool selfp;
                         const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
-                        gw[x].load(fg.il_a + (uint64_t) (addr >> 5) * GS);
-                        bit[x] = (uint32_t) addr & 31u, sp[x] = selfp, ok[x] = true;
-                    }
-#pragma unroll
-                    for (uint32_t x = 0; x < GATHER_U; ++x) {
-                        if (!ok[x]) continue;
+                        GroupWords<GS> gw;
+                        gw.load(fg.il_a + (uint64_t) (addr >> 5) * GS);
+                        const uint32_t bit = (uint32_t) addr & 31u;
 #pragma unroll
                         for (int i = 0; i < GS; ++i) {
-                            const uint32_t fb = (gw[x].x[i] >> bit[x]) & 1u;
-                            const uint32_t rb = sp[x] ? fb : ((gw[x].x[i] >> (bit[x] ^ 1u)) & 1u);
-                            fm[i] |= fb << (j0 + x);
-                            rm[i] |= rb << (j0 + x);
+                            const uint32_t fb = (gw.x[i] >> bit) & 1u;
+                            const uint32_t rb = selfp ? fb : ((gw.x[i] >> (bit ^ 1u)) & 1u);
+                            fm[i] |= fb << j;
+                            rm[i] |= rb << j;
                         }
                     }
                 }
@@ -944,7 +926,9 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     for (int h = 0; h < MW; ++h)
 #pragma unroll
         for (int i = 0; i < GS; ++i) fm[h][i] = 0, rm[h][i] = 0;
-    // (1) gather
+    // (1) gather (one window per round trip on purpose: with 2 / 4 / 8 windows' loads in flight per thread the kernel took 105.5 / 104.5 /
+    // 124.2 instead of 101.3 ms per 50 M-read target, and search_group_kernel 48.4 / 49.3 / 49.4 instead of 47.0 — at the request
+    // ceiling more requests in flight per workgroup only lengthen the queues)
     if (active) {
         W wh = 0;
         uint32_t run = 0, cw = ~0u, hi = 0, va = 0;
@@ -955,38 +939,25 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
             run = ((va >> j) & 1u) ? run + 1 : 0;
         };
         for (int pos = 0; pos < q0 && pos <= pe; ++pos) roll(pos);
-        // GATHER_U windows per round: their addresses are made first, their loads issued together, the bits taken out afterwards — one
-        // round trip per round instead of one per window (the rolling of a window does not depend on what the filter holds)
 #pragma unroll
         for (int h = 0; h < MW; ++h) {
-            for (int jj0 = 0; jj0 < 32 && q0 + 32 * h + jj0 <= pe; jj0 += GATHER_U) {
-                uint4 v[GATHER_U], u[GATHER_U];
-                uint32_t bit[GATHER_U];
-                bool ok[GATHER_U], sp[GATHER_U];
-#pragma unroll
-                for (int x = 0; x < GATHER_U; ++x) {
-                    const int q = q0 + 32 * h + jj0 + x;
-                    ok[x] = false, sp[x] = false, bit[x] = 0;
-                    v[x] = u[x] = make_uint4(0, 0, 0, 0);
-                    if (jj0 + x >= 32 || q > pe) continue;
-                    roll(q);
-                    if (run < (uint32_t) k) continue;
+            for (int jj = 0; jj < 32; ++jj) {
+                const int q = q0 + 32 * h + jj;
+                if (q > pe) break;
+                roll(q);
+                if (run >= (uint32_t) k) {
                     bool selfp;
                     const W addr = psi_a<W>(T::brev(wh) >> sh, k, selfp);
                     const uint32_t *src = fg.il_a + (uint64_t) (addr >> 5) * GS;
-                    v[x] = *(const uint4 *) src, u[x] = *(const uint4 *) (src + 4);
-                    bit[x] = (uint32_t) addr & 31u, sp[x] = selfp, ok[x] = true;
-                }
-#pragma unroll
-                for (int x = 0; x < GATHER_U; ++x) {
-                    if (!ok[x]) continue;
-                    const uint32_t w8[GS] = {v[x].x, v[x].y, v[x].z, v[x].w, u[x].x, u[x].y, u[x].z, u[x].w};
+                    const uint4 v = *(const uint4 *) src, u = *(const uint4 *) (src + 4);
+                    const uint32_t x[GS] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
+                    const uint32_t bit = (uint32_t) addr & 31u;
 #pragma unroll
                     for (int i = 0; i < GS; ++i) {
-                        const uint32_t fb = (w8[i] >> bit[x]) & 1u;
-                        const uint32_t rb = sp[x] ? fb : ((w8[i] >> (bit[x] ^ 1u)) & 1u);
-                        fm[h][i] |= fb << (jj0 + x);
-                        rm[h][i] |= rb << (jj0 + x);
+                        const uint32_t fb = (x[i] >> bit) & 1u;
+                        const uint32_t rb = selfp ? fb : ((x[i] >> (bit ^ 1u)) & 1u);
+                        fm[h][i] |= fb << jj;
+                        rm[h][i] |= rb << jj;
                     }
                 }
             }

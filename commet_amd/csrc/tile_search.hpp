@@ -33,15 +33,15 @@
 namespace commet {
 
 #ifndef TQ_SWEEP_U
-#define TQ_SWEEP_U 2     // replay, step (2): candidates per thread and round of the balanced sweep
+#define TQ_SWEEP_U 2     // replay, step (2): candidates per thread and round of the balanced sweep (1 / 2 / 4: 4.52 / 4.54 / 4.59 ms)
 #endif
 #ifndef TQ_COLLECT_U
-#define TQ_COLLECT_U 8   // replay, step (1): flat records per lane whose loads are in flight together
+#define TQ_COLLECT_U 8   // replay, step (1): flat records per lane whose loads are in flight together (1 / 2 / 4 / 8: 5.20 / 4.82 / 4.68 / 4.63 ms)
 #endif
 #ifndef COMMET_TQ_PIECE
 #define COMMET_TQ_PIECE 256
 #endif
-constexpr uint32_t TQ_PIECE = COMMET_TQ_PIECE;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1])
+constexpr uint32_t TQ_PIECE = COMMET_TQ_PIECE;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1] in round 2; round 5: 256 / 128 / 64: 4.54 / 4.87 / 5.51)
 constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
 
 struct QueryListView {
