@@ -98,6 +98,12 @@ class Context:
     def synchronize(self):
         self._check(self._lib.commet_synchronize(self._h))
 
+    def device_memory(self):
+        """commet_device_memory: (free, total) bytes of the context's device; blocks the library keeps for reuse count as free"""
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.commet_device_memory(self._h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
     def filter_reset(self):
         self._check(self._lib.commet_filter_reset(self._h))
 
@@ -255,6 +261,15 @@ class ReadSet:
 
     def drop_cache(self):
         self._lib.commet_readset_drop_cache(self._h)
+
+    def cache_estimate(self):
+        """bytes of the set's query list for its context's (k, t); 0 = the set does not qualify for the tiled search"""
+        return int(self._lib.commet_readset_cache_estimate(self._ctx._h, self._h))
+
+    def reserve_cache(self):
+        """commet_readset_reserve_cache: asks the driver NOW (from the calling thread) for the memory the set's query list will need, so
+        that a list above the cap can be built later without an allocation on a job's path"""
+        self._ctx._check(self._lib.commet_readset_reserve_cache(self._ctx._h, self._h))
 
     def close(self):
         if getattr(self, "_h", None):

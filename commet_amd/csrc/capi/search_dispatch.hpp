@@ -228,7 +228,8 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB.  Measured
     // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
     const uint64_t est = rs->n_reads * (uint64_t) first_hit_windows * 8;
-    if (rs->n_reads < (1ull << 20) || est > c->ql_max_list) return false;
+    // (a list above the cap when its memory was set aside beforehand, commet_readset_reserve_cache: the allocation is then not on this job's path)
+    if (rs->n_reads < (1ull << 20) || (est > c->ql_max_list && !rs->ql_reserved.load())) return false;
     // A list of more than 4 GiB (sets of 15 M reads and up) is built for a set's SECOND such scan: a set that is scanned once —
     // every target of a rank that holds few pairs of a large matrix — would pay 12 ms of kernels and an 11 GB allocation for a
     // 7.6 ms gain (one J2 / J3 job of configs[3]: 54.7 against 62.3 ms), a set that is scanned again and again — every set of a
@@ -367,6 +368,23 @@ int ensure_query_results(commet_ctx *c, const commet_readset *rs)
     }
     c->qres_cap = need;
     return 0;
+}
+
+// what build_query_list and ensure_query_results will ask for, for this context's (k, t): block sizes in bytes (upper bounds: every
+// first-hit window of every read a record); false = the set does not qualify for the tiled search whatever the group
+bool query_list_blocks(const commet_ctx *c, const commet_readset *rs, uint64_t out[6])
+{
+    const int t = t_eff(c, rs);
+    const int64_t fhw = (int64_t) rs->max_len - (int64_t) t * c->k + 1;
+    if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || fhw < 1 || fhw > TQ_MAX_WIN || rs->n_reads < (1ull << 20) || rs->n_reads >= (1ull << 32)) return false;
+    const uint64_t records = rs->n_reads * (uint64_t) fhw;
+    if (records >= (1ull << 32)) return false;
+    int sbits = TQ_SBITS;
+    if (c->tq_sbits) sbits = std::max(c->k - 10, std::min(c->k - 1, c->tq_sbits));
+    const uint64_t entries = ((uint64_t) 1 << (c->k - sbits)) * ((rs->n_reads + TQ_PIECE - 1) / TQ_PIECE);
+    out[0] = (entries + 1) * 8, out[1] = records * 4, out[2] = records * 2, out[3] = entries * 4, out[4] = entries * 2;
+    out[5] = c->qres_cap >= records ? 0 : records;            // the context's result buffer, one byte per record
+    return true;
 }
 
 // one pass of rs over the g <= 2 chunk filters in slots slot0 .. slot0 + g - 1 (g == 2: slots 0, 1 with interleaved A planes)
@@ -595,3 +613,31 @@ int launch_search_wide(commet_ctx *c, const commet_readset *rs, const WidePlan &
 }
 
 }  // namespace
+
+extern "C" {
+
+// (here rather than in cache.hpp: they need the tiled search's geometry)
+uint64_t commet_readset_cache_estimate(commet_ctx *c, const commet_readset *rs)
+{
+    uint64_t b[6];
+    if (rs->ctx != c || !rs->finalized || !query_list_blocks(c, rs, b)) return 0;
+    return b[0] + b[1] + b[2] + b[3] + b[4];
+}
+
+int commet_readset_reserve_cache(commet_ctx *c, const commet_readset *rs)
+{
+    if (rs->ctx != c) return fail("read set belongs to another context");
+    if (!rs->finalized) return fail("read set not finalized");
+    HIP_OK(hipSetDevice(c->device));
+    uint64_t b[6];
+    {
+        std::lock_guard<std::mutex> lk(c->ql_mu);
+        if (rs->ql.built || rs->ql_reserved.load() || !g_devmem.enabled() || !query_list_blocks(c, rs, b)) return 0;
+    }
+    for (int i = 0; i < 6; ++i)
+        if (b[i] && dm_reserve((size_t) b[i]) != hipSuccess) return 0;      // no room: the set keeps the cap's rule
+    rs->ql_reserved.store(true);
+    return 0;
+}
+
+}  // extern "C"

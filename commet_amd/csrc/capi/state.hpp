@@ -120,6 +120,25 @@ hipError_t dm_malloc(void **p, size_t bytes)
     return e;
 }
 
+// a block of `bytes` asked from the driver NOW and filed at once, for an allocation that will come later on some job's path (a helper
+// thread pays the driver's 15-30 ms per GiB instead of the job thread); never taken from the filed blocks themselves
+hipError_t dm_reserve(size_t bytes)
+{
+    if (!g_devmem.enabled() || bytes < DEVMEM_MIN_FILED) return hipSuccess;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        return e;
+    }
+    std::lock_guard<std::mutex> lk(g_devmem.mu);
+    g_devmem.filed[dev].emplace(bytes, p);
+    g_devmem.filed_bytes[dev] += bytes;
+    return hipSuccess;
+}
+
 hipError_t dm_free(void *p)
 {
     if (!p) return hipSuccess;
@@ -395,6 +414,7 @@ struct commet_readset {
     };
     mutable QueryList ql;
     mutable uint32_t ql_wanted = 0;                 // scans that would have taken the tiled search had the set's (large) list existed (tiled_ok)
+    mutable std::atomic<bool> ql_reserved{false};   // the memory of the set's list waits in the library's device cache (commet_readset_reserve_cache): a list above the cap may be built
     mutable bool in_job = false;                    // part of the commet_index_and_search call that is running: its list stays
     bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel
     uint32_t host_min_len = 0xFFFFFFFFu, host_max_len = 0;

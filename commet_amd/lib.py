@@ -63,6 +63,8 @@ SIGNATURES = {
     "commet_readset_cache_bytes": (C.c_uint64, [C.c_void_p]),
     "commet_readset_drop_cache": (None, [C.c_void_p]),
     "commet_cache_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "commet_readset_cache_estimate": (C.c_uint64, [C.c_void_p, C.c_void_p]),
+    "commet_readset_reserve_cache": (C.c_int, [C.c_void_p, C.c_void_p]),
     "commet_device_cache_trim": (C.c_uint64, [C.c_int]),
     "commet_device_cache_bytes": (C.c_uint64, [C.c_int]),
     "commet_filter_reset": (C.c_int, [C.c_void_p]),

@@ -223,6 +223,15 @@ class HipEngine:
     def index_and_search(self, index, searches, isel, ssels):
         return self.ctx.index_and_search(index, searches, isel, ssels)
 
+    def list_estimate(self, rs):
+        return rs.cache_estimate()
+
+    def reserve_list(self, rs):
+        rs.reserve_cache()
+
+    def device_total(self):
+        return self.ctx.device_memory()[1]
+
     def kernel_times(self):
         """COMMET_MATRIX_KERNEL_TIMES=1: {kernel: [launches, ms]} of this rank's jobs (a hipEvent pair around every launch; the chunks
         of a group are then built one after the other, so the figures add up but the run is a little slower) — else None"""
@@ -631,6 +640,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             # the files, last set first, and ref = N-2, N-3, ... need the sets ref .. N-1.  Several ranks: the thread parses
             # this rank's own sets and publishes them, then takes the others' as they appear (no barrier in between).
             ready = [threading.Event() for _ in range(N)]
+            jobs_done = threading.Event()
             loader_stop = stop_ev
             load_err = []
             load_end = [t0]
@@ -649,6 +659,36 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 # the two sets of that job are there, whatever the other ranks are still parsing.
                 wanted_by = {s_: sum(1 for r in range(world) if any(s_ in pairs[c] for c in runs[r])) for s_ in owned}
                 own_first = sorted((s_ for s_ in owned if s_ in needed or s_ in needed_by_others), key=lambda s_: (-wanted_by[s_], s_))
+
+            loaded_all = [False]
+
+            def reserve_lists():
+                """COMMET_MATRIX_LARGE_LISTS=1 (off by default): query lists above the library's cap (a 50 M-read set's is 11 GB; it saves
+                ~12 ms of every J2 / J3 job that searches the set) for the sets this rank searches three times or more; their memory is asked
+                from the driver HERE, by the loader thread once every set is resident, and a set whose memory waits in the library's device
+                cache gets its list at its next eligible scan but one.  Measured on configs[3] (profiles/r05_large_lists): 11.0 s against
+                11.8 s on a box whose device memory had been used before (the driver's 110 GiB take no time there), 13.4 s on a fresh box —
+                there hipMalloc costs 15-30 ms per GiB (3.4 s), and while one thread is inside hipMalloc the HIP calls of every other thread
+                of the process wait, so the job thread stands still with it.  Hence opt-in: for long-lived hosts."""
+                if os.environ.get("COMMET_MATRIX_LARGE_LISTS", "0") != "1" or not hasattr(eng, "list_estimate"):
+                    return
+                scans = {}
+                for (r_, i_) in mine:                            # J2 searches the reference set, J3 the target (Commet.py:220, 233)
+                    scans[r_] = scans.get(r_, 0) + 1
+                    scans[i_] = scans.get(i_, 0) + 1
+                want = [s_ for s_ in sorted(scans, key=lambda s_: -scans[s_]) if scans[s_] >= 3 and s_ in sets]
+                est = {s_: eng.list_estimate(sets[s_]) for s_ in want}
+                want = [s_ for s_ in want if est[s_] > (4 << 30)]          # (smaller lists are the library's default already)
+                budget = 0.4 * eng.device_total()
+                got = 0
+                for s_ in want:
+                    if loader_stop.is_set() or jobs_done.is_set() or sum(est[x] for x in want[:want.index(s_) + 1]) > budget:
+                        break
+                    eng.reserve_list(sets[s_])
+                    got += 1
+                prof["lists_reserved"] = got
+                if got:
+                    note(f"memory of {got} large query lists set aside ({sum(est[x] for x in want[:got]) / 2**30:.0f} GiB)")
 
             def load_all():
                 try:
@@ -671,12 +711,16 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             break
                         ready[s].set()
                         note(f"set {s} resident")
+                    load_end[0] = time.perf_counter()
+                    loaded_all[0] = True
+                    reserve_lists()
                 except BaseException as ex:          # handed to the job thread, which is waiting for a set
                     load_err.append(ex)
                     for ev in ready:
                         ev.set()
                 finally:
-                    load_end[0] = time.perf_counter()
+                    if not loaded_all[0]:
+                        load_end[0] = time.perf_counter()
 
             loader = threading.Thread(target=load_all, name="commet-set-loader", daemon=True)
             loader.start()
@@ -754,6 +798,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                     reads_searched += considered[ref] + considered[i]
             note(f"jobs of set {ref} done ({prof['jobs']} so far)")
         eng.synchronize()
+        if loader is not None:
+            jobs_done.set()                                      # (no list memory is set aside for jobs that are over)
         for f in written:                                        # (what a writer raised is raised here)
             f.result()
         writer.shutdown()

@@ -136,6 +136,15 @@ int             commet_cache_stats(commet_ctx *ctx, uint64_t *bytes, uint64_t *b
  * released, commet_device_cache_bytes(device) what is filed now.  COMMET_DEVMEM_CACHE=0 turns the mechanism off.  Nothing in the
  * reference corresponds to it (its filters are plain `new char[]`, bloom_filter.h:73). */
 uint64_t        commet_device_cache_trim(int device);
+/* A query list above the cap (option "query_list_max_mb": 4 GiB, sets of ~15 M reads) costs its first user 15-30 ms per GiB of
+ * driver time on a box whose device memory has not been touched yet — on the job's path.  A driver that knows a set will be scanned
+ * again and again (the N x N matrix: a 50 M-read set's list is 11 GB and saves 12 ms per scan) calls commet_readset_reserve_cache
+ * from a helper thread while its jobs run: the blocks the list will need (for the context's k and t) are asked from the driver there
+ * and filed in the device cache; from then on the set may get its list whatever the cap says (built, as every list above 4 GiB,
+ * for its second eligible scan).  _estimate returns the bytes such a list takes (0: the set does not qualify for the tiled search).
+ * No-ops when the list exists, when the device cache is off, or when there is no room. */
+uint64_t        commet_readset_cache_estimate(commet_ctx *ctx, const commet_readset *rs);
+int             commet_readset_reserve_cache(commet_ctx *ctx, const commet_readset *rs);
 uint64_t        commet_device_cache_bytes(int device);
 
 /* ---- the two kernels ------------------------------------------------------ */

@@ -2,7 +2,8 @@
 tiled_ok) — a set that large gets its list for its SECOND eligible scan (the first keeps the gather kernels), and both scans must
 give the reference's bits.  A 16 M-read search set (est. list 4.7 GB > the 4 GiB default cap) against a 4 M-read index set (one
 chunk filter): the first job takes search_kernel, the second builds the list and takes the tiled pair of kernels; the tags of
-both are equal, and a 20 000-read sample is replayed on the CPU checker."""
+both are equal, and a 20 000-read sample is replayed on the CPU checker.  The same list once more with the cap back at its default
+but the list's memory set aside beforehand (commet_readset_reserve_cache: the N x N driver's way)."""
 import numpy as np
 import pytest
 
@@ -33,14 +34,29 @@ def test_a_query_list_above_4_gib_is_built_for_the_second_scan_and_gives_the_sam
         with ThreadPoolExecutor(1) as pool:
             fut = pool.submit(oracle_pool.search_sample_over_chunks, str(tmp_path / "orc"), "ll", b0, L, chunks, k, t, sb, 1)
             runs = []
-            for scan in range(3):
-                if scan == 1:
-                    ctx.set_option("query_list_max_mb", 16 << 10)          # lists of up to 16 GiB from here on
+            def scan_once():
                 ctx.set_option("kernel_timing", 1)
                 tags, stats, info = ctx.index_and_search(irs, [qrs])
                 runs.append(dict(tags=tags[0], shared=stats[0]["shared"], kernels=set(ctx.kernel_times()), cache=qrs.cache_bytes))
                 ctx.set_option("kernel_timing", 0)
+
+            for scan in range(3):
+                if scan == 1:
+                    ctx.set_option("query_list_max_mb", 16 << 10)          # lists of up to 16 GiB from here on
+                scan_once()
+            # the other way to a list above the cap: its memory set aside beforehand (commet_readset_reserve_cache — what the N x N driver's
+            # loader thread does for the sets it searches again and again), the cap itself back at its default
+            qrs.drop_cache()
+            ctx.set_option("query_list_max_mb", 4096)
+            scan_once()                                                     # runs[3]: the cap applies again
+            est, filed = qrs.cache_estimate(), commet_amd.device_cache_bytes(0)
+            qrs.reserve_cache()
+            reserved = commet_amd.device_cache_bytes(0) - filed
+            scan_once()                                                     # runs[4]: the list, although the cap says no
             want, fed = fut.result()
+    assert est > n_q * 37 * 6 and reserved >= est                            # (+ the context's result buffer when it had to grow)
+    assert "search_kernel" in runs[3]["kernels"] and runs[3]["cache"] == 0
+    assert {"tq_probe_kernel", "tq_replay_kernel", "tq_fill_kernel"} <= runs[4]["kernels"] and runs[4]["cache"] > (3 << 30)
     # default cap: a list of an estimated 16 M x 37 x 8 B = 4.7 GB is not built: the gather kernel
     assert "search_kernel" in runs[0]["kernels"] and "tq_replay_kernel" not in runs[0]["kernels"] and runs[0]["cache"] == 0
     # cap raised: the set's FIRST eligible scan still gathers (a set scanned once must not pay the list) ...
@@ -50,6 +66,7 @@ def test_a_query_list_above_4_gib_is_built_for_the_second_scan_and_gives_the_sam
     assert runs[2]["cache"] > n_q * 37 * 6 > (3 << 30)
     for r in runs[1:]:
         assert np.array_equal(r["tags"], runs[0]["tags"]) and r["shared"] == runs[0]["shared"]
+    commet_amd.device_cache_trim()                                            # (the 4 GB of the list go back to the driver: the next tests' child processes share the card)
     assert fed == [int(kc[a:e].sum()) for a, e in chunks]
     got = util.bools_from_bits(runs[2]["tags"], n_q)[smp]
     assert np.array_equal(got, want)
