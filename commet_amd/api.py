@@ -149,6 +149,27 @@ class Context:
         inf = {f: getattr(info, f) for f, _ in _l.JobInfo._fields_}
         return tags, st, inf
 
+    def index_many_and_search(self, index_sets, search_rs, index_selects=None, search_select=None):
+        """commet_index_many_and_search: job j indexes index_sets[j] (restricted to index_selects[j]) and searches search_rs; the jobs
+        share passes over the search set where the library can arrange it.  Returns (tags, stats, info): tags[j], stats[j] as
+        index_and_search(index_sets[j], [search_rs], ...) gives them for job j alone."""
+        nj = len(index_sets)
+        isel = [None] * nj
+        if index_selects is not None:
+            isel = [_as_bits(s, rs.num_reads, "index_select") for s, rs in zip(index_selects, index_sets)]
+        ssel = _as_bits(search_select, search_rs.num_reads, "search_select")
+        tags = [np.zeros(bits_nbytes(search_rs.num_reads), dtype=np.uint8) for _ in range(nj)]
+        rs_arr = (C.c_void_p * max(nj, 1))(*[rs._h for rs in index_sets])
+        sel_arr = (C.c_void_p * max(nj, 1))(*[(_ptr(s).value if s is not None else None) for s in isel])
+        tag_arr = (C.c_void_p * max(nj, 1))(*[_ptr(t).value for t in tags])
+        stats = (_l.PairStats * max(nj, 1))()
+        info = _l.JobInfo()
+        self._check(self._lib.commet_index_many_and_search(self._h, nj, rs_arr, sel_arr, search_rs._h, _ptr(ssel), tag_arr, stats,
+                                                           C.byref(info)))
+        st = [dict(indexed=int(stats[i].indexed), searched=int(stats[i].searched), shared=int(stats[i].shared),
+                   search_ms=float(stats[i].search_ms)) for i in range(nj)]
+        return tags, st, {f: getattr(info, f) for f, _ in _l.JobInfo._fields_}
+
     def export_filter_reference(self):
         nbytes = int(2 ** (self.k - 1))
         out = np.zeros(max(nbytes, 1), dtype=np.uint8)

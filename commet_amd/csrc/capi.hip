@@ -40,12 +40,13 @@
 // The implementation, part by part (one translation unit: the kernels above are templates and inline device code, and the
 // dispatch-coverage test resolves every launched entry point against this library's own symbol table).
 #include "capi/state.hpp"            // errors, launch bookkeeping, commet_ctx, commet_readset
-#include "capi/cache.hpp"            // query-list cache, allocations under pressure, workspace candidates
+#include "capi/cache.hpp"            // query-list cache, allocations under pressure, scatter workspaces
 #include "capi/context.hpp"          // commet_create / _destroy
 #include "capi/readset.hpp"          // resident read sets, host ingest
 #include "capi/images.hpp"           // packed images, HIP IPC hand-over
 #include "capi/index_dispatch.hpp"   // index construction: which path, its launches
 #include "capi/search_dispatch.hpp"  // search regimes: which one, its launches
 #include "capi/job.hpp"              // commet_index_reads / _search_reads / _index_and_search
+#include "capi/multi.hpp"            // commet_index_many_and_search: several jobs on one search set, their filters in one pass
 #include "capi/options.hpp"          // commet_set_option, measurement hooks
 #include "capi/microbench.hpp"       // commet_membench / _ldsbench

@@ -36,6 +36,7 @@ commet_ctx *commet_create(int device, int kmer_size, int min_hits)
     c->t = min_hits < 1 ? 1 : min_hits;
     if (const char *e = getenv("COMMET_INDEX_LANES")) c->index_lanes = atoi(e) == 1 ? 1 : 2;   // 1: one kernel at a time (per-kernel profiles)
     if (const char *e = getenv("COMMET_TILED")) c->tiled_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("COMMET_MULTI_JOB")) c->multi_job = atoi(e) == 1 ? 1 : 0;   // A/B runs: 1 = commet_index_many_and_search job by job
     if (const char *e = getenv("COMMET_SPARSE_SEARCH")) c->sparse_search = std::max(0, std::min(2, atoi(e)));   // A/B runs
     if (const char *e = getenv("COMMET_TQ_SBITS")) c->tq_sbits = atoi(e);
     if (const char *e = getenv("COMMET_TQ_WPX")) c->tq_wpx = (unsigned) std::max(1, atoi(e));
@@ -117,6 +118,7 @@ void commet_destroy(commet_ctx *c)
     (void) dm_free(c->d_plansum);
     (void) dm_free(c->d_ids);
     (void) dm_free(c->d_idblk);
+    (void) dm_free(c->d_mtags);
     (void) dm_free(c->d_act);
     (void) dm_free(c->d_actblk);
     c->part[0].release();

@@ -1,0 +1,245 @@
+// capi/multi.hpp — commet_index_many_and_search: several index_and_search jobs that search the SAME read set, their chunk filters side by side in one pass
+// (a part of the one translation unit capi.hip: included there, in order, after job.hpp)
+//
+// Commet.py runs, for a reference set S_ref and every other set S_i, J2 = "S_ref in (S_i restricted to J1's result)" and
+// J3 = "S_i in (S_ref restricted to J2's result)" (Commet.py:220, 233): index sets of a few chunk filters each, and the search set
+// of all J2 jobs of a reference set is that reference set (of all J3 jobs of a target, that target).  A job on its own costs ~55
+// L2-missing requests per searched read of which 37 are the lane-a gathers of the read's first-hit windows — addresses that depend on
+// the read alone.  With the filters of up to eight chunks of several such jobs in the slots of one pass (their A planes interleaved:
+// one 32-byte gather serves them all) the set is scanned once per pass instead of once per job; behind the gather
+// search_group8_kernel runs job by job (kernels.hpp, job_mask).  Every job's result is what commet_index_and_search gives for it
+// alone — tested against exactly that, and against the CPU checker through the N x N driver.
+//
+// The fast path takes what the N x N driver's jobs are: fixed-length index sets whose chunks (at most eight per job) take the bucketed
+// construction, a search set that is visited whole and qualifies for the register-mask kernel.  Anything else — and n_jobs = 1 — is
+// run job by job through commet_index_and_search itself.
+#pragma once
+
+extern "C" {
+
+int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset *const *index_rs, const uint8_t *const *index_select,
+                                 const commet_readset *search_rs, const uint8_t *search_select, uint8_t *const *tags_out,
+                                 commet_pair_stats *stats, commet_job_info *info)
+{
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (n_jobs < 0) return fail("n_jobs must be >= 0");
+    commet_job_info sum = commet_job_info();
+    auto one_by_one = [&]() -> int {
+        for (int j = 0; j < n_jobs; ++j) {
+            commet_job_info ji = commet_job_info();
+            const uint8_t *ss = search_select;
+            uint8_t *to = tags_out ? tags_out[j] : nullptr;
+            if (commet_index_and_search(c, index_rs[j], index_select ? index_select[j] : nullptr, 1, &search_rs, search_select ? &ss : nullptr,
+                                        tags_out ? &to : nullptr, stats ? &stats[j] : nullptr, &ji))
+                return 1;
+            sum.n_chunks += ji.n_chunks, sum.kmers_indexed += ji.kmers_indexed, sum.reads_scanned += ji.reads_scanned;
+            sum.reads_indexed += ji.reads_indexed, sum.index_launches += ji.index_launches, sum.search_launches += ji.search_launches;
+            sum.probes += ji.probes, sum.zero_ms += ji.zero_ms, sum.index_ms += ji.index_ms, sum.index_kernel_ms += ji.index_kernel_ms;
+            sum.search_ms += ji.search_ms;
+        }
+        sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        if (info) *info = sum;
+        return 0;
+    };
+    if (!search_rs->finalized) return fail("search read set not finalized");
+    if (search_rs->ctx != c) return fail("search read set belongs to another context");
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!index_rs[j]->finalized) return fail("index read set %d not finalized", j);
+        if (index_rs[j]->ctx != c) return fail("index read set %d belongs to another context", j);
+        if (index_rs[j] == search_rs) return fail("a set cannot be searched against itself in one call");
+    }
+    HIP_OK(hipSetDevice(c->device));
+    // ---- does the fast path take the call? ---------------------------------------------------------------------------------------
+    const uint8_t *ssel = search_select;
+    if (ssel && all_ones(ssel, search_rs->n_reads)) ssel = nullptr;
+    const uint64_t max_kmer = commet_max_kmer(c);
+    bool fast = n_jobs >= 2 && c->k >= 2 && !c->count_probes && c->chunk_group >= 8 && c->multi_job != 1 && search_rs->n_reads > 0 &&
+                slice_words(c, 8) == 0 && group8_ok(c, search_rs) && plan_fast_ok(search_rs->files, ssel, search_rs->empty_reads, 1) &&
+                (search_rs->n_reads + 255) / 256 < (1ull << 24);
+    struct Job {
+        IndexPlan plan;
+        const uint8_t *sel = nullptr;
+        std::vector<uint64_t> chunk_pos;        // first position of every chunk in the job's list of selected reads
+    };
+    std::vector<Job> jobs(fast ? (size_t) n_jobs : 0);
+    for (int j = 0; j < n_jobs && fast; ++j) {
+        const commet_readset *rs = index_rs[j];
+        Job &job = jobs[(size_t) j];
+        job.sel = index_select ? index_select[j] : nullptr;
+        if (job.sel && all_ones(job.sel, rs->n_reads)) job.sel = nullptr;
+        if (!rs->n_reads || rs->uniform_len == 0 || c->part_no_uni || !plan_blocks_ok(rs->files, job.sel, rs->empty_reads, max_kmer)) {
+            fast = false;
+            break;
+        }
+        // the plan from per-block k-mer sums made on the device (as commet_index_and_search does)
+        const uint64_t nblk = (rs->n_reads + PLAN_BLOCK_READS - 1) / PLAN_BLOCK_READS;
+        if (c->plansum_cap < nblk) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void) dm_free(c->d_plansum);
+            c->d_plansum = nullptr, c->plansum_cap = 0;
+            HIP_OK(dev_alloc(c, (void **) &c->d_plansum, nblk * sizeof(unsigned long long), true));
+            c->plansum_cap = nblk;
+        }
+        if (job.sel && upload_bits(c, rs->d_sel, job.sel, rs->n_reads)) return 1;
+        {
+            KScope ks(c, "block_kmer_sums_kernel", c->stream);
+            COMMET_LAUNCH(block_kmer_sums_kernel, dim3((unsigned) nblk), dim3(256), 0, c->stream, rs->d_kcnt, job.sel ? rs->d_sel : nullptr,
+                          rs->n_reads, c->d_plansum);
+        }
+        HIP_OK(hipGetLastError());
+        std::vector<uint64_t> blk_sums(nblk);
+        HIP_OK(hipMemcpyAsync(blk_sums.data(), c->d_plansum, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> kblock(PLAN_BLOCK_READS);
+        uint64_t kblock_no = ~0ull;
+        bool kfetch_failed = false;
+        auto kcnt_of = [&](uint64_t q) -> uint32_t {
+            if (rs->have_host_counts) return rs->h_kcnt[q];
+            const uint64_t blk = q / PLAN_BLOCK_READS;
+            if (blk != kblock_no) {
+                const uint64_t lo = blk * PLAN_BLOCK_READS, cnt = std::min<uint64_t>(PLAN_BLOCK_READS, rs->n_reads - lo);
+                if (hipMemcpy(kblock.data(), rs->d_kcnt + lo, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) kfetch_failed = true;
+                kblock_no = blk;
+            }
+            return kblock[q % PLAN_BLOCK_READS];
+        };
+        job.plan = plan_index_blocks(job.sel, kcnt_of, rs->n_reads, max_kmer, blk_sums.data(), PLAN_BLOCK_READS);
+        if (kfetch_failed) return fail("k-mer count fetch failed: %s", hipGetErrorString(hipGetLastError()));
+        if (job.plan.chunks.empty() || job.plan.chunks.size() > 8) fast = false;
+        uint64_t at = 0;
+        for (const Chunk &ch : job.plan.chunks) {
+            if (!ch.n_reads || !would_partition(c, rs, ch.kmers)) fast = false;    // (the bucketed build writes every tile of its slot itself)
+            job.chunk_pos.push_back(at), at += ch.n_reads;
+        }
+    }
+    if (fast) {
+        // A search set that takes the tiled search (a query list within the cap: sets of up to ~15 M reads) loses little on its own — its
+        // lane-a gathers come out of L2 — and jobs of one or two chunks each need no eight filter slots there (20 GiB more at k = 32, which a
+        // fresh box hands out at 15-30 ms per GiB): such jobs stay on their own (configs[2]'s leg: 1.5 s either way on a used box, 2.0 s
+        // against 1.5 s on a fresh one).
+        size_t most = 0;
+        for (const Job &job : jobs) most = std::max(most, job.plan.chunks.size());
+        std::lock_guard<std::mutex> qlk(c->ql_mu);
+        if (most <= 2 && tiled_ok(c, search_rs, 2)) fast = false;
+    }
+    if (!fast) return one_by_one();
+
+    // ---- passes: consecutive jobs while their chunks fit the eight slots ---------------------------------------------------------------
+    const uint64_t tag_words = bitmap_words(search_rs->n_reads);
+    if (c->mtags_cap < 8 * tag_words) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) dm_free(c->d_mtags);
+        c->d_mtags = nullptr, c->mtags_cap = 0;
+        HIP_OK(dev_alloc(c, (void **) &c->d_mtags, 8 * tag_words * sizeof(uint64_t), true));
+        c->mtags_cap = 8 * tag_words;
+    }
+    if (c->jobcnt_cap < 16) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        (void) dm_free(c->d_jobcnt);
+        c->d_jobcnt = nullptr, c->jobcnt_cap = 0;
+        HIP_OK(dev_alloc(c, (void **) &c->d_jobcnt, 64 * sizeof(unsigned long long), true));
+        c->jobcnt_cap = 64;
+    }
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&](hipEvent_t *e) -> int {
+        HIP_OK(hipEventCreate(e));
+        evs.push_back(*e);
+        return 0;
+    };
+    int rc = 0;
+    for (int j0 = 0; j0 < n_jobs && !rc;) {
+        int j1 = j0, g = 0;
+        while (j1 < n_jobs && g + (int) jobs[(size_t) j1].plan.chunks.size() <= 8) g += (int) jobs[(size_t) j1].plan.chunks.size(), ++j1;
+        if (ensure_slots(c, g, 8)) return 1;
+        hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+        if (new_event(&ea) || new_event(&eb) || new_event(&ec)) { rc = 1; break; }
+        (void) hipEventRecord(ea, c->stream);
+        uint32_t job_mask = 0;
+        int slot = 0;
+        for (int j = j0; j < j1 && !rc; ++j) {
+            const commet_readset *rs = index_rs[j];
+            Job &job = jobs[(size_t) j];
+            job_mask |= 1u << slot;
+            const uint32_t *d_ids = nullptr;
+            if (!job.plan.dense) {
+                // the job's selected reads as a list (index_part.hpp, sel_ids_kernel); the chunks of every job are built on the one
+                // stream, one after the other, so the list buffer of the context serves job after job
+                if (upload_bits(c, rs->d_sel, job.plan.indexed_bits.data(), rs->n_reads)) { rc = 1; break; }
+                const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
+                if (c->ids_cap < job.plan.indexed_reads || c->idblk_cap < nb + 1) {
+                    HIP_OK(hipStreamSynchronize(c->stream));
+                    (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
+                    c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
+                    const uint64_t cap = std::max<uint64_t>(job.plan.indexed_reads, rs->n_reads / 2);
+                    HIP_OK(dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true));
+                    HIP_OK(dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true));
+                    c->ids_cap = cap, c->idblk_cap = nb + 1;
+                }
+                KScope ks(c, "sel_ids_kernels", c->stream);
+                COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, (const uint64_t *) nullptr);
+                COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_idblk, (uint32_t) nb);
+                COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, c->d_ids, (const uint64_t *) nullptr);
+                if (hipGetLastError() != hipSuccess) { rc = fail("selection list launch failed"); break; }
+                d_ids = c->d_ids;
+            }
+            for (size_t ci = 0; ci < job.plan.chunks.size() && !rc; ++ci, ++slot) {
+                const Chunk &ch = job.plan.chunks[ci];
+                c->cur_slot = slot;
+                if (launch_index(c, rs, ch.first, ch.last - ch.first + 1, job.plan.dense ? nullptr : rs->d_sel, nullptr, ch.kmers, true, false, 0, d_ids,
+                                 d_ids ? job.chunk_pos[ci] : 0, ch.n_reads))
+                    rc = 1;
+                ++sum.index_launches;
+            }
+        }
+        c->cur_slot = 0;
+        if (rc) break;
+        if (launch_interleave(c, g, 8)) { rc = 1; break; }
+        (void) hipEventRecord(eb, c->stream);
+        if (hipMemsetAsync(c->d_mtags, 0, (size_t) (j1 - j0) * tag_words * sizeof(uint64_t), c->stream) != hipSuccess ||
+            hipMemsetAsync(c->d_jobcnt, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { rc = fail("memset failed"); break; }
+        if (launch_search_group(c, search_rs, g, 8, nullptr, c->d_mtags, c->d_jobcnt, 2, nullptr, ActiveList{nullptr, nullptr}, 0, job_mask, tag_words)) { rc = 1; break; }
+        ++sum.search_launches;
+        (void) hipEventRecord(ec, c->stream);
+        unsigned long long h_cnt[16];
+        if (hipMemcpyAsync(h_cnt, c->d_jobcnt, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail("counter copy failed"); break; }
+        for (int j = j0; j < j1 && !rc; ++j)
+            if (tags_out && tags_out[j] &&
+                hipMemcpyAsync(tags_out[j], c->d_mtags + (uint64_t) (j - j0) * tag_words, bitmap_bytes_host(search_rs->n_reads), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+                rc = fail("tag copy failed");
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        c->kclock.collect();
+        if (rc) break;
+        float ms_i = 0, ms_s = 0;
+        (void) hipEventElapsedTime(&ms_i, ea, eb);
+        (void) hipEventElapsedTime(&ms_s, eb, ec);
+        sum.index_ms += ms_i, sum.index_kernel_ms += ms_i, sum.search_ms += ms_s;
+        slot = 0;
+        for (int j = j0; j < j1; ++j) {
+            const Job &job = jobs[(size_t) j];
+            uint64_t shared = 0, last_scanned = 0;
+            for (size_t ci = 0; ci < job.plan.chunks.size(); ++ci, ++slot) {
+                last_scanned = search_rs->n_reads - shared;          // (the set is visited whole)
+                if (h_cnt[2 * slot] != last_scanned)
+                    rc = fail("internal error: device scanned %llu reads, host plan says %llu (job %d, chunk %zu)", h_cnt[2 * slot],
+                              (unsigned long long) last_scanned, j, ci);
+                shared += h_cnt[2 * slot + 1];
+                sum.reads_scanned += last_scanned;
+            }
+            if (stats) {
+                stats[j].indexed = job.plan.indexed_reads;
+                stats[j].searched = last_scanned;
+                stats[j].shared = shared;
+                stats[j].search_ms = ms_s / (double) (j1 - j0);      // (the pass is shared: an equal part each)
+            }
+            sum.n_chunks += job.plan.chunks.size(), sum.kmers_indexed += job.plan.kmers, sum.reads_indexed += job.plan.indexed_reads;
+        }
+        j0 = j1;
+    }
+    for (hipEvent_t e : evs) (void) hipEventDestroy(e);
+    if (rc) return rc;
+    sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (info) *info = sum;
+    return 0;
+}
+
+}  // extern "C"

@@ -45,6 +45,11 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->tiled_mode = (int) value;
         return 0;
     }
+    if (!strcmp(name, "multi_job")) {         // 0 = commet_index_many_and_search puts the chunk filters of several jobs into one pass where it can, 1 = job by job
+        if (value < 0 || value > 1) return fail("multi_job must be 0 or 1");
+        c->multi_job = (int) value;
+        return 0;
+    }
     if (!strcmp(name, "sparse_search")) {     // 0 auto, 1 never, 2 whenever a selection applies: a pass over few of a set's reads walks their list (kernels.hpp, ActiveList)
         if (value < 0 || value > 2) return fail("sparse_search must be 0, 1 or 2");
         c->sparse_search = (int) value;

@@ -111,9 +111,10 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
 }
 
 // one pass of rs over the `g` chunk filters in slots 0..g-1 (A planes already interleaved with stride gs)
+// job_mask != 0 (gs == 8 only): the g filters belong to several jobs, bit i = filter i opens one; job j's tags at d_tags + j * job_tag_words
 int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, const uint64_t *d_sel, uint64_t *d_tags,
                         unsigned long long *d_counters, uint32_t cstride, unsigned long long *d_probes, ActiveList al = ActiveList{nullptr, nullptr},
-                        uint64_t n_launch = 0)
+                        uint64_t n_launch = 0, uint32_t job_mask = 0, uint64_t job_tag_words = 0)
 {
     if (rs->n_reads == 0) return 0;
     if (al.ids && n_launch == 0) return 0;
@@ -131,17 +132,17 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
         if (c->k <= 32) {
             if (three)
                 COMMET_LAUNCH((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al);
+                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
             else
                 COMMET_LAUNCH((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al);
+                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
         } else {
             if (three)
                 COMMET_LAUNCH((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al);
+                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
             else
                 COMMET_LAUNCH((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al);
+                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
         }
         HIP_OK(hipGetLastError());
         return 0;

@@ -252,6 +252,9 @@ struct commet_ctx {
     uint64_t ids_cap = 0, idblk_cap = 0;
     uint32_t *d_act = nullptr, *d_actblk = nullptr;  // read numbers of a sparse search pass (sel & ~tags, in order) and the scan's block sums
     uint64_t act_cap = 0, actblk_cap = 0;
+    uint64_t *d_mtags = nullptr;                     // found flags of the jobs of a commet_index_many_and_search pass (up to eight bitmaps over the search set)
+    uint64_t mtags_cap = 0;
+    int multi_job = 0;                               // option: 0 = commet_index_many_and_search shares passes between jobs where it can, 1 = job by job
     int sparse_search = 0;                           // option: 0 auto (a pass over less than half of a set's reads), 1 never, 2 whenever a selection applies
     unsigned long long *d_plansum = nullptr;  // per-block k-mer sums of a selection (host planner input)
     uint64_t plansum_cap = 0;

@@ -891,8 +891,14 @@ __global__ __launch_bounds__(256) COMMET_SGPRS void search_group_kernel(ReadsVie
 template <typename W, int MW>
 __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kernel(ReadsView rv, FilterGroupView fg, int k, int t,
                                                             const uint64_t *__restrict__ sel, uint64_t *__restrict__ tags,
-                                                            unsigned long long *__restrict__ counters, uint32_t cstride, ActiveList al)
+                                                            unsigned long long *__restrict__ counters, uint32_t cstride, ActiveList al,
+                                                            uint32_t job_mask, uint64_t job_tag_words)
 {
+    // job_mask != 0: the filters of the pass belong to SEVERAL jobs that search this one set (Commet.py's J2 jobs of a reference set,
+    // its J3 jobs of a target: each against two chunk filters of another restricted index set, commet_index_many_and_search): bit i
+    // set = filter i is the first of a job.  The lane-a gather — 37 of a J2 / J3 job's ~55 requests per read — then serves every job
+    // of the pass; everything behind it runs job by job: `found` starts afresh at a job's first filter, job j's found flags go to
+    // tags + j * job_tag_words (zeroed by the host: a job never spans passes), its counters to its own chunks' slots.
     using T = KeyTraits<W>;
     constexpr int GS = 8;
     // tails (the windows behind the first-hit ones, for a scan that has a hit but not yet t of them) are fetched by the
@@ -903,9 +909,12 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (7 bits: <= 96 first-hit windows)
     __shared__ uint32_t full_hit[MW][256];
     __shared__ uint32_t cand_n;
-    const SearchLane me = search_lane(rv, al, sel, tags);
+    const bool multi = job_mask != 0;
+    const SearchLane me = search_lane(rv, al, sel, multi ? nullptr : tags);
     const uint64_t r = me.r;
     const bool active = me.active;
+    __shared__ unsigned int wg_cnt[2 * GS];
+    int job = -1, job_first = 0;
     // the read of another thread of the workgroup (candidate sweeps, tails): thread x of the bitmap form has read block * 256 + x
     __shared__ uint32_t wg_read[256];
     if (al.ids) wg_read[threadIdx.x] = (uint32_t) r;
@@ -973,9 +982,20 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
             for (int i = 0; i < GS; ++i) n += __popc(fm[h][i]) + 3 * __popc(rm[h][i]);
         if (n == (uint32_t) t) found = true;   // (never with the t the bench uses... wrong results anyway)
     }
+    // (several jobs) what a job leaves behind: its found flags, one ballot word per 64 reads, and its chunks' counters
+    auto end_job = [&](int first, int end) {
+        const uint64_t fb = __ballot(found);
+        if ((threadIdx.x & 63) == 0 && me.in_range && tags) tags[(uint64_t) job * job_tag_words + me.word] = fb;
+        if (counters) add_chunk_counters(counters + (uint64_t) first * cstride, cstride, end - first, active, found_chunk < 0 ? -1 : found_chunk - first, wg_cnt);
+    };
 #pragma unroll
     for (int i = 0; i < GS; ++i) {
         if (i >= fg.g) continue;   // (uniform)
+        if (multi && ((job_mask >> i) & 1u)) {   // (uniform) filter i opens a job
+            if (job >= 0) end_job(job_first, i);
+            ++job, job_first = i;
+            found = false, found_chunk = -1;
+        }
         const uint32_t *pb = fg.slot0 + (uint64_t) i * fg.slot_words + fg.plane_words;
         const uint32_t *pc = pb + fg.plane_words;
         const uint32_t *pd = pc + fg.plane_words;
@@ -1123,11 +1143,12 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
         }
         if (found && found_chunk < 0) found_chunk = i;
     }
-    publish_found(al, me, found, tags);
-    if (counters) {
-        __shared__ unsigned int wg_cnt[2 * GS];
-        add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);
+    if (multi) {
+        if (job >= 0) end_job(job_first, fg.g);
+        return;
     }
+    publish_found(al, me, found, tags);
+    if (counters) add_chunk_counters(counters, cstride, fg.g, active, found_chunk, wg_cnt);
 }
 
 // il_a[w * GS + i] = plane A word w of filter slot i (0 for i >= g)

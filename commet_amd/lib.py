@@ -73,6 +73,8 @@ SIGNATURES = {
     "commet_index_and_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(PairStats),
                                           C.POINTER(JobInfo)]),
+    "commet_index_many_and_search": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(PairStats), C.POINTER(JobInfo)]),
     "commet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "commet_filter_export_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "commet_last_kernel_ms": (C.c_int, [C.c_void_p, f64p, f64p]),

@@ -223,6 +223,9 @@ class HipEngine:
     def index_and_search(self, index, searches, isel, ssels):
         return self.ctx.index_and_search(index, searches, isel, ssels)
 
+    def index_many_and_search(self, indexes, search, isels, ssel):
+        return self.ctx.index_many_and_search(indexes, search, isels, ssel)
+
     def list_estimate(self, rs):
         return rs.cache_estimate()
 
@@ -744,8 +747,8 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         shared = {}                    # (from set, in set) -> reads of `from` found in `in`
         reads_searched = 0
 
-        def _acc(inf):
-            prof["jobs"] += 1
+        def _acc(inf, n=1):
+            prof["jobs"] += n
             prof["call_ms"] += inf["total_ms"]
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
 
@@ -760,7 +763,29 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         def out_log(*a):
             written.append(writer.submit(_log, *a))
 
+        def jobs_on_one_search_set(index_ids, search_id, selections):
+            """Jobs that search the SAME set — the J2 jobs of a reference set, the J3 jobs of a target (Commet.py:220, 233) — in one call
+            where the engine has one (commet_index_many_and_search: their chunk filters share passes over the search set: the lane-a
+            gathers of its reads, two thirds of such a job's memory requests, are made once per pass instead of once per job);
+            -> [(tags, stats, index_ms)] in the jobs' order, bit for bit what the jobs give one by one."""
+            if not index_ids:
+                return []
+            if hasattr(eng, "index_many_and_search") and len(index_ids) > 1:
+                tags, st, inf = eng.index_many_and_search([sets[x] for x in index_ids], sets[search_id], selections, sel[search_id])
+                _acc(inf, len(index_ids))
+                return [(tags[j], st[j], inf["index_ms"] / len(index_ids)) for j in range(len(index_ids))]
+            out = []
+            for x, sl in zip(index_ids, selections):
+                tags, st, inf = eng.index_and_search(sets[x], [sets[search_id]], sl, [sel[search_id]])
+                _acc(inf)
+                out.append((tags[0], st[0], inf["index_ms"]))
+            return out
+
+        # Order of a rank's jobs: per reference set J1 (its index built once for all its targets), then the J2 jobs of its targets
+        # together (they all search S_ref); the J3 jobs — (ref, i) searches S_i — are kept back and run target by target at the end, so
+        # that the J3 jobs of a target share passes as well.  The files a job writes do not depend on when it runs.
         t_jobs = time.perf_counter()
+        kept_T2 = {}                   # (ref, i) -> J2's result, the index selection of J3(ref, i)
         for ref in refs:
             wait_for(ref)
             pending = [i for (r, i) in mine if r == ref]
@@ -779,24 +804,27 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 prof["j1_builds"] += 1
                 reads_searched += sum(considered[i] for i in targets)
                 _acc(inf1)
-                for i, T1 in zip(targets, tags1):
-                    # J2: X = S_i restricted to (S_i in S_ref); S_ref in X
-                    tags2, st2, inf2 = eng.index_and_search(sets[i], [sets[ref]], T1, [sel[ref]])
-                    T2 = tags2[0]
-                    _acc(inf2)
+                # J2 of every target: X_i = S_i restricted to (S_i in S_ref); S_ref in X_i
+                for i, (T2, st2, index_ms) in zip(targets, jobs_on_one_search_set(targets, ref, list(tags1))):
                     for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
                         out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-                    out_log(out_dir, names[ref], names[i], st2[0], inf2["index_ms"], time.perf_counter() - w0)
-                    shared[(ref, i)] = st2[0]["shared"]
-                    # J3: S_i in (S_ref restricted to J2's result)  — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)
-                    tags3, st3, inf3 = eng.index_and_search(sets[ref], [sets[i]], T2, [sel[i]])
-                    _acc(inf3)
-                    for f, c, b in zip(files[i], counts[i], split_bits(tags3[0], counts[i])):
-                        out_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
-                    out_log(out_dir, names[i], names[ref], st3[0], inf3["index_ms"], time.perf_counter() - w0)
-                    shared[(i, ref)] = st3[0]["shared"]
-                    reads_searched += considered[ref] + considered[i]
-            note(f"jobs of set {ref} done ({prof['jobs']} so far)")
+                    out_log(out_dir, names[ref], names[i], st2, index_ms, time.perf_counter() - w0)
+                    shared[(ref, i)] = st2["shared"]
+                    kept_T2[(ref, i)] = T2
+                    reads_searched += considered[ref]
+            note(f"J1 and J2 jobs of set {ref} done ({prof['jobs']} so far)")
+        # J3 of every pair: S_i in (S_ref restricted to J2's result) — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233) — target by target
+        for i in sorted({i for (_, i) in mine}):
+            w0 = time.perf_counter()
+            wait_for(i)
+            of_i = [r for (r, t_) in mine if t_ == i]
+            for ref, (T3, st3, index_ms) in zip(of_i, jobs_on_one_search_set(of_i, i, [kept_T2.pop((r, i)) for r in of_i])):
+                for f, c, b in zip(files[i], counts[i], split_bits(T3, counts[i])):
+                    out_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
+                out_log(out_dir, names[i], names[ref], st3, index_ms, time.perf_counter() - w0)
+                shared[(i, ref)] = st3["shared"]
+                reads_searched += considered[i]
+            note(f"J3 jobs of set {i} done ({prof['jobs']} so far)")
         eng.synchronize()
         if loader is not None:
             jobs_done.set()                                      # (no list memory is set aside for jobs that are over)

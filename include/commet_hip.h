@@ -210,6 +210,18 @@ int commet_index_and_search(commet_ctx *ctx,
                             const uint8_t *const *search_select,
                             uint8_t *const *tags_out, commet_pair_stats *stats,
                             commet_job_info *info);
+/* Several such jobs that search the SAME read set — Commet.py's J2 jobs of a reference set (Commet.py:220: for every other set S_i,
+ * "S_ref in (S_i restricted to J1's result)") and its J3 jobs of a target (Commet.py:233) — in one call: job j indexes index_rs[j]
+ * (restricted to index_select[j], may be NULL) and searches search_rs (search_select as above); tags_out[j], stats[j] are what
+ * commet_index_and_search(index_rs[j], ..., 1, &search_rs, ...) gives for job j alone, bit for bit.  Where the jobs allow it
+ * (fixed-length index sets whose chunks, at most eight per job, take the bucketed construction; a search set that is visited
+ * whole) the chunk filters of several jobs share a pass over the search set: the lane-a gathers of its reads, two thirds of a
+ * job's memory requests, are then made once per pass instead of once per job.  Otherwise (and with option "multi_job" = 1) the
+ * jobs run one after the other.  info (may be NULL) sums over the jobs. */
+int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_readset *const *index_rs,
+                                 const uint8_t *const *index_select, const commet_readset *search_rs,
+                                 const uint8_t *search_select, uint8_t *const *tags_out, commet_pair_stats *stats,
+                                 commet_job_info *info);
 
 /* ---- test / measurement hooks --------------------------------------------- */
 /* Tunables / diagnostics, by name.  Unknown names are an error.  None of them changes a result bit, except the test
@@ -238,6 +250,7 @@ int commet_index_and_search(commet_ctx *ctx,
  *   query_list_max_mb    auto mode of tiled_search: largest list (estimated) a set may get, default 4096 (sets of up to ~15 M reads;
  *                        larger lists — a 50 M-read set's is 11 GB — pay in long-lived contexts only: allocating them costs
  *                        15-30 ms per GiB; lists of more than 4 GiB are built for a set's second eligible scan)
+ *   multi_job (0/1)      commet_index_many_and_search: 0 = chunk filters of several jobs in one pass where possible, 1 = job by job
  *   sparse_search (0/1/2) a pass over a SELECTION of a search set (a filter bv that leaves few reads: file_manager.h:88-112 skips the
  *                        others) walks the list of the selected, not yet tagged reads instead of the set's bitmap, so that every
  *                        lane of a wave has a read: 0 = when the host plan visits less than half of the set's reads, 1 = never,

@@ -76,6 +76,19 @@ def fuzz_one(seed):
                     _, n, bits = util.read_bv(os.path.join(d, "o", os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
                     ok &= bool(np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)))
                     pos += n
+            if seed % 5 == 2 and len(loaded) >= 2 and irs.num_reads:
+                # the roles turned round: every search set of the scenario as an index set of its own, the index set searched by all of
+                # them in ONE call (commet_index_many_and_search: chunk filters of several jobs in one pass where the sets allow it) — against
+                # the same jobs one by one, which the lines above (and every other suite) pin to the CPU checker
+                ctx.set_option("count_probes", 0)
+                idx = [x[0] for x in loaded if x[0].num_reads]
+                sels = [x[1] for x in loaded if x[0].num_reads]
+                if len(idx) >= 2:
+                    many = ctx.index_many_and_search(idx, irs, sels, isel)
+                    for j, (rs_j, sel_j) in enumerate(zip(idx, sels)):
+                        one = ctx.index_and_search(rs_j, [irs], sel_j, [isel])
+                        ok &= bool(np.array_equal(many[0][j], one[0][0]))
+                        ok &= all(many[1][j][f] == one[1][0][f] for f in ("indexed", "searched", "shared"))
         return bool(ok), hook, f"seed {seed} k {scn.k} t {scn.t} index_mode {mode}" + (f" max_kmer {max_kmer}" if hook else "")
     finally:
         shutil.rmtree(d, ignore_errors=True)

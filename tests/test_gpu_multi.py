@@ -1,0 +1,65 @@
+"""commet_index_many_and_search: several jobs that search the SAME read set (Commet.py's J2 jobs of a reference set, its J3 jobs of a
+target, Commet.py:220, 233), their chunk filters side by side in one pass of search_group8_kernel — every job's tags and numbers must be
+what commet_index_and_search gives for that job alone (which the other suites pin to the CPU checker); the N x N driver's use of the
+call is checked against the checker itself in test_gpu_configs.py / test_gpu_matrix.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(rng, n, frac):
+    sel = rng.random(n) < frac
+    out = np.zeros(n // 8 + 1, dtype=np.uint8)
+    pk = np.packbits(sel, bitorder="little")
+    out[:pk.size] = pk
+    return out
+
+
+@pytest.mark.parametrize("k,t,L,max_kmer", [(32, 2, 100, 12_000_000), (33, 2, 100, 9_000_000), (26, 2, 130, 15_000_000), (28, 3, 110, 0)])
+def test_jobs_sharing_a_pass_equal_the_jobs_alone(k, t, L, max_kmer):
+    import commet_amd
+    from commet_amd import synth
+    rng = np.random.default_rng(k * 100 + t)
+    n_i, n_s = 400_000, 600_000
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("index_mode", 2)                  # the bucketed construction whatever a chunk's size (the fast path's condition)
+        ctx.set_option("max_kmer", max_kmer)             # several chunks per index set (test hook; both ways chunk alike)
+        srs = commet_amd.ReadSet.from_files(ctx, [synth.synth_set(0, n_s, L)])
+        irs = [commet_amd.ReadSet.from_files(ctx, [synth.synth_set(s, n_i, L)]) for s in (1, 2, 3, 4, 5)]
+        sels = [None, _bits(rng, n_i, 0.5), _bits(rng, n_i, 0.2), _bits(rng, n_i, 0.9), None]
+        # alone
+        alone = [ctx.index_and_search(rs, [srs], index_select=sel) for rs, sel in zip(irs, sels)]
+        # together
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_many_and_search(irs, srs, index_selects=sels)
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        chunks = [a[2]["n_chunks"] for a in alone]
+        assert info["n_chunks"] == sum(chunks) and max(chunks) <= 8
+        for j, a in enumerate(alone):
+            assert np.array_equal(tags[j], a[0][0]), j
+            assert {f: stats[j][f] for f in ("indexed", "searched", "shared")} == {f: a[1][0][f] for f in ("indexed", "searched", "shared")}, j
+            assert a[1][0]["shared"] > n_i // 8 * (0.1 if sels[j] is not None else 0.5)
+        assert info["kmers_indexed"] == sum(a[2]["kmers_indexed"] for a in alone)
+        # the jobs did share passes: consecutive jobs while their chunks fit eight slots
+        passes, g = 1, 0
+        for c_ in chunks:
+            if g + c_ > 8:
+                passes, g = passes + 1, 0
+            g += c_
+        assert times["search_group8_kernel"][0] == passes < len(irs) and info["search_launches"] == passes
+        # job by job on request, and whenever the fast path does not apply (a selection on the search set; a single job)
+        ctx.set_option("multi_job", 1)
+        t2, s2, i2 = ctx.index_many_and_search(irs, srs, index_selects=sels)
+        ctx.set_option("multi_job", 0)
+        assert i2["search_launches"] >= len(irs)
+        ssel = _bits(rng, n_s, 0.3)
+        t3, s3, i3 = ctx.index_many_and_search(irs[:2], srs, index_selects=sels[:2], search_select=ssel)
+        for j in range(len(irs)):
+            assert np.array_equal(t2[j], tags[j]) and s2[j]["shared"] == stats[j]["shared"]
+        for j in range(2):
+            a = ctx.index_and_search(irs[j], [srs], index_select=sels[j], search_selects=[ssel])
+            assert np.array_equal(t3[j], a[0][0]) and s3[j]["shared"] == a[1][0]["shared"] and s3[j]["searched"] == a[1][0]["searched"]
+        t4, s4, _ = ctx.index_many_and_search(irs[:1], srs, index_selects=sels[:1])
+        assert np.array_equal(t4[0], tags[0]) and s4[0]["shared"] == stats[0]["shared"]
