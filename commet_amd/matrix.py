@@ -10,6 +10,11 @@ on sets that stay packed in HBM:
                     J2  index S_i   restricted to T1         search S_ref    -> <G>_in_<S_i>.bv
                     J3  index S_ref restricted to J2's bits  search S_i      -> <F>_in_<S_ref>.bv
 
+Order on a rank: per reference set J1 (one call: its index built once for all its targets), then the J2 jobs of those targets in ONE
+call — they all search S_ref, and commet_index_many_and_search lets the chunk filters of up to four of them share a pass over it —
+and, once every reference set is through, the J3 jobs target by target (they all search S_i) the same way.  What a job writes does
+not depend on when it runs.
+
 One process per GPU.  The path has no exchange step, so ranks share nothing but small files
 and three host-side gathers (sharding.Ranks: a TCP store of rank 0, no torch in the ranks):
   * every set is PARSED ONCE on the node (set s by rank s % world; left-over sets by the ranks with
