@@ -150,7 +150,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
     for (int j0 = 0; j0 < n_jobs && !rc;) {
         int j1 = j0, g = 0;
         while (j1 < n_jobs && g + (int) jobs[(size_t) j1].plan.chunks.size() <= 8) g += (int) jobs[(size_t) j1].plan.chunks.size(), ++j1;
-        if (ensure_slots(c, g, 8)) return 1;
+        if (ensure_slots(c, g, 8)) { rc = 1; break; }
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (new_event(&ea) || new_event(&eb) || new_event(&ec)) { rc = 1; break; }
         (void) hipEventRecord(ea, c->stream);
