@@ -52,6 +52,11 @@ def device_cache_bytes(device=0):
     return int(_l.load().commet_device_cache_bytes(int(device)))
 
 
+def device_pooled_bytes(device=0):
+    """commet_device_pooled_bytes: bytes in use on `device` that came from the stream-ordered pool (not shareable over HIP IPC)"""
+    return int(_l.load().commet_device_pooled_bytes(int(device)))
+
+
 class Context:
     """commet_ctx: device, k, t, the 4-lane Bloom filter in HBM."""
 

@@ -90,6 +90,11 @@ uint64_t commet_device_cache_bytes(int device)
     return (uint64_t) dm_filed_bytes(device);
 }
 
+uint64_t commet_device_pooled_bytes(int device)
+{
+    return (uint64_t) dm_pooled_bytes(device);
+}
+
 int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions)
 {
     std::lock_guard<std::mutex> lk(c->ql_mu);

@@ -163,6 +163,12 @@ int commet_readset_export(const commet_readset *rs, void *blob, uint64_t cap, ui
     memset(&t, 0, sizeof t);
     t.device = c->device, t.has_goff = h.uniform_len ? 0 : 1;
     HIP_OK(hipStreamSynchronize(c->load_stream));        // the planes are complete
+    {   // buffers from the stream-ordered pool have no IPC handle: moved into hipMalloc blocks once, here (state.hpp, dm_make_shareable)
+        commet_readset *w = const_cast<commet_readset *>(rs);
+        if (rs->in_job) return fail("read set is part of a running job: export it before or after");
+        HIP_OK(dm_make_shareable((void **) &w->d_planes));
+        if (t.has_goff) HIP_OK(dm_make_shareable((void **) &w->d_goff));
+    }
     HIP_OK(hipIpcGetMemHandle(&t.planes, rs->d_planes));
     if (t.has_goff) HIP_OK(hipIpcGetMemHandle(&t.goff, rs->d_goff));
     memcpy(m + tail_at, &t, sizeof t);

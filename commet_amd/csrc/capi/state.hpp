@@ -38,23 +38,37 @@ inline void note_launch(const void *entry)
     } while (0)
 
 // ---- device memory kept for reuse ----------------------------------------------------------------------------------------
-// On this driver a hipMalloc of GBs costs 15-30 ms per GiB, and one that follows the hipFree of tens of GB now and then blocks
-// for 50-150 ms (seen up to 2 s): a context created after another one was closed, a query list built after one was dropped, a
+// On this driver a hipMalloc of GBs costs 15-30 ms per GiB on some boxes (and ~0 on others: tools/exp/alloc_cost*.hip — where a
+// 16 GiB hipMalloc took 483 ms, and 965 ms again after its hipFree, sixteen of 1 GiB took 0.3 ms and a hipMallocAsync of 16 GiB
+// 14 ms), and one that follows the hipFree of tens of GB now and then blocks for 50-150 ms (seen up to 2 s): a context created after another one was closed, a query list built after one was dropped, a
 // workspace that grows — all of them on some job's path (bench.py's configs[2] leg behind the headline: 1.50 s of device time
 // against 1.15 s in a fresh process, the difference being the GPU idling behind such calls; profiles/r05_c2_variance).  So the
 // library never gives a block of 8 MiB or more back while the process lives: dm_free waits for the device, as hipFree does (its
 // callers count on that), and files the block; dm_malloc takes the smallest filed block of the current device that is large enough
 // and at most a quarter larger, else asks hipMalloc — and when hipMalloc is out of memory, everything filed is given back and
 // it is asked once more.  Blocks are never split (an exported set's IPC handle must be that of a whole allocation).
+// COMMET_DEVMEM_POOL=1 (off by default): a new block of 256 MiB or more comes from hipMallocAsync on a stream of the cache's own,
+// drained before the block is handed out — 0.4-0.9 ms per GiB on either kind of box in isolation, but on a box whose hipMalloc
+// is free anyway the 10-set matrix of bench.py took 12.7 s with it against 10.9 s without (device time +4 %: kernels gather more
+// slowly from pool memory; the loader thread's waits 1.5 s against 0.6 s; profiles/r05_pool), and the box of the other kind has
+// not come up again to be measured.  No IPC handle can be had for such a block, so commet_readset_export first moves a set's
+// planes into a hipMalloc block (dm_make_shareable).
 // At most half the device (COMMET_DEVMEM_CACHE_GB) is kept, the largest blocks going first; commet_device_cache_trim gives all of
 // it back.  COMMET_DEVMEM_CACHE=0: plain hipMalloc / hipFree.
 struct DevMemCache {
+    struct Block {
+        int device;
+        size_t bytes;                                              // as allocated
+        bool pooled;                                               // from hipMallocAsync (no IPC handle can be had for it)
+    };
     std::mutex mu;
-    std::map<void *, std::pair<int, size_t>> live;                 // blocks handed out: device, bytes as allocated
-    std::multimap<size_t, void *> filed[16];                       // per device, by size
+    std::map<void *, Block> live;                                  // blocks handed out
+    std::multimap<size_t, std::pair<void *, bool>> filed[16];      // per device, by size: pointer, pooled
     size_t filed_bytes[16] = {0};
     size_t cap[16] = {0};                                          // bytes kept at most per device (COMMET_DEVMEM_CACHE_GB; default: half the device)
-    int on = -1;
+    hipStream_t pool_stream[16] = {nullptr};                       // the stream the stream-ordered allocations are ordered on (always drained before use)
+    int on = -1, pool_on = -1;
+    size_t pool_min = 0;                                           // COMMET_DEVMEM_POOL_MIN_MB (tests: a set of a few MB in pooled blocks); never below 8 MiB
     bool enabled()
     {
         if (on < 0) {
@@ -63,25 +77,86 @@ struct DevMemCache {
         }
         return on != 0;
     }
+    bool pooling()
+    {
+        if (pool_on < 0) {
+            const char *e = getenv("COMMET_DEVMEM_POOL");
+            pool_on = e && atoi(e) != 0;
+            const char *m = getenv("COMMET_DEVMEM_POOL_MIN_MB");
+            pool_min = m ? std::max<size_t>((size_t) atoll(m) << 20, (size_t) 8 << 20) : (size_t) 256 << 20;
+        }
+        return pool_on != 0;
+    }
 };
 DevMemCache g_devmem;
 constexpr size_t DEVMEM_MIN_FILED = (size_t) 8 << 20;
 
+// one block from the driver: stream-ordered from 256 MiB on unless an IPC handle will be asked for it
+hipError_t dm_driver_alloc(void **p, size_t bytes, int dev, bool shareable, bool *pooled)
+{
+    *pooled = false;
+    if (!shareable && g_devmem.pooling() && bytes >= g_devmem.pool_min) {
+        hipStream_t st;
+        {
+            std::lock_guard<std::mutex> lk(g_devmem.mu);
+            if (!g_devmem.pool_stream[dev] && hipStreamCreateWithFlags(&g_devmem.pool_stream[dev], hipStreamNonBlocking) != hipSuccess) {
+                (void) hipGetLastError();
+                g_devmem.pool_stream[dev] = nullptr;
+            }
+            st = g_devmem.pool_stream[dev];
+        }
+        if (st) {
+            hipError_t e = hipMallocAsync(p, bytes, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) {
+                *pooled = true;
+                return e;
+            }
+            if (e != hipErrorOutOfMemory) (void) hipGetLastError();     // (not supported here, ...: the plain call below)
+            else return e;
+        }
+    }
+    return hipMalloc(p, bytes);
+}
+
+void dm_driver_free(void *q, int dev, bool pooled)
+{
+    if (!pooled) {
+        (void) hipFree(q);
+        return;
+    }
+    hipStream_t st = g_devmem.pool_stream[dev];
+    (void) hipFreeAsync(q, st);
+    (void) hipStreamSynchronize(st);
+}
+
 // gives every filed block of `device` (-1: all) back to the driver; returns the bytes released
 size_t dm_trim(int device)
 {
-    std::vector<void *> drop;
+    std::vector<std::pair<int, std::pair<void *, bool>>> drop;
     size_t bytes = 0;
     {
         std::lock_guard<std::mutex> lk(g_devmem.mu);
         for (int d = 0; d < 16; ++d) {
             if (device >= 0 && d != device) continue;
-            for (auto &b : g_devmem.filed[d]) drop.push_back(b.second), bytes += b.first;
+            for (auto &b : g_devmem.filed[d]) drop.push_back({d, b.second}), bytes += b.first;
             g_devmem.filed[d].clear();
             g_devmem.filed_bytes[d] = 0;
         }
     }
-    for (void *q : drop) (void) hipFree(q);
+    bool any_pooled = false;
+    for (auto &q : drop) dm_driver_free(q.second.first, q.first, q.second.second), any_pooled |= q.second.second;
+    if (any_pooled) {                                              // the pool itself keeps nothing either
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        for (int d = 0; d < 16; ++d) {
+            if ((device >= 0 && d != device) || !g_devmem.pool_stream[d]) continue;
+            hipMemPool_t pool;
+            if (hipSetDevice(d) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess) (void) hipMemPoolTrimTo(pool, 0);
+        }
+        if (have) (void) hipSetDevice(cur);
+        (void) hipGetLastError();
+    }
     return bytes;
 }
 
@@ -91,7 +166,17 @@ size_t dm_filed_bytes(int device)
     return device >= 0 && device < 16 ? g_devmem.filed_bytes[device] : 0;
 }
 
-hipError_t dm_malloc(void **p, size_t bytes)
+size_t dm_pooled_bytes(int device)
+{
+    std::lock_guard<std::mutex> lk(g_devmem.mu);
+    size_t n = 0;
+    for (auto &b : g_devmem.live)
+        if (b.second.device == device && b.second.pooled) n += b.second.bytes;
+    return n;
+}
+
+// `shareable`: the block may be exported to another process (commet_readset_export), so it comes from hipMalloc
+hipError_t dm_malloc(void **p, size_t bytes, bool shareable = false)
 {
     *p = nullptr;
     if (!g_devmem.enabled()) return hipMalloc(p, bytes);
@@ -99,42 +184,44 @@ hipError_t dm_malloc(void **p, size_t bytes)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipMalloc(p, bytes);
     if (bytes >= DEVMEM_MIN_FILED) {
         std::lock_guard<std::mutex> lk(g_devmem.mu);
-        auto it = g_devmem.filed[dev].lower_bound(bytes);
-        if (it != g_devmem.filed[dev].end() && it->first <= bytes + bytes / 4) {
-            *p = it->second;
+        for (auto it = g_devmem.filed[dev].lower_bound(bytes); it != g_devmem.filed[dev].end() && it->first <= bytes + bytes / 4; ++it) {
+            if (shareable && it->second.second) continue;
+            *p = it->second.first;
             g_devmem.filed_bytes[dev] -= it->first;
-            g_devmem.live[*p] = {dev, it->first};
+            g_devmem.live[*p] = {dev, it->first, it->second.second};
             g_devmem.filed[dev].erase(it);
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(p, bytes);
+    bool pooled = false;
+    hipError_t e = dm_driver_alloc(p, bytes, dev, shareable, &pooled);
     if (e == hipErrorOutOfMemory && dm_trim(dev)) {
         (void) hipGetLastError();
-        e = hipMalloc(p, bytes);
+        e = dm_driver_alloc(p, bytes, dev, shareable, &pooled);
     }
     if (e == hipSuccess && bytes >= DEVMEM_MIN_FILED) {
         std::lock_guard<std::mutex> lk(g_devmem.mu);
-        g_devmem.live[*p] = {dev, bytes};
+        g_devmem.live[*p] = {dev, bytes, pooled};
     }
     return e;
 }
 
 // a block of `bytes` asked from the driver NOW and filed at once, for an allocation that will come later on some job's path (a helper
-// thread pays the driver's 15-30 ms per GiB instead of the job thread); never taken from the filed blocks themselves
+// thread pays the driver's price instead of the job thread); never taken from the filed blocks themselves
 hipError_t dm_reserve(size_t bytes)
 {
     if (!g_devmem.enabled() || bytes < DEVMEM_MIN_FILED) return hipSuccess;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     void *p = nullptr;
-    const hipError_t e = hipMalloc(&p, bytes);
+    bool pooled = false;
+    const hipError_t e = dm_driver_alloc(&p, bytes, dev, false, &pooled);
     if (e != hipSuccess) {
         (void) hipGetLastError();
         return e;
     }
     std::lock_guard<std::mutex> lk(g_devmem.mu);
-    g_devmem.filed[dev].emplace(bytes, p);
+    g_devmem.filed[dev].emplace(bytes, std::make_pair(p, pooled));
     g_devmem.filed_bytes[dev] += bytes;
     return hipSuccess;
 }
@@ -143,20 +230,20 @@ hipError_t dm_free(void *p)
 {
     if (!p) return hipSuccess;
     if (g_devmem.enabled()) {
-        std::pair<int, size_t> what{-1, 0};
+        DevMemCache::Block what{-1, 0, false};
         {
             std::lock_guard<std::mutex> lk(g_devmem.mu);
             auto it = g_devmem.live.find(p);
             if (it != g_devmem.live.end()) what = it->second, g_devmem.live.erase(it);
         }
-        if (what.first >= 0) {
+        if (what.device >= 0) {
             (void) hipDeviceSynchronize();                         // what hipFree does: no kernel still reads the block when somebody else gets it
-            std::vector<void *> over;                              // kept within the cap (other processes may share the device): largest first
+            std::vector<std::pair<void *, bool>> over;             // kept within the cap (other processes may share the device): largest first
+            const int d = what.device;
             {
                 std::lock_guard<std::mutex> lk(g_devmem.mu);
-                const int d = what.first;
-                g_devmem.filed[d].emplace(what.second, p);
-                g_devmem.filed_bytes[d] += what.second;
+                g_devmem.filed[d].emplace(what.bytes, std::make_pair(p, what.pooled));
+                g_devmem.filed_bytes[d] += what.bytes;
                 if (!g_devmem.cap[d]) {
                     size_t fr = 0, tot = 0;
                     const char *e = getenv("COMMET_DEVMEM_CACHE_GB");
@@ -170,11 +257,38 @@ hipError_t dm_free(void *p)
                     g_devmem.filed[d].erase(last);
                 }
             }
-            for (void *q : over) (void) hipFree(q);
+            for (auto &q : over) dm_driver_free(q.first, d, q.second);
             return hipSuccess;
         }
     }
     return hipFree(p);
+}
+
+// the block at *p made exportable: one that came from the stream-ordered pool is copied into a hipMalloc block of its own (the
+// device drained first; the caller sees to it that no other host thread uses the block meanwhile) and filed
+hipError_t dm_make_shareable(void **p)
+{
+    if (!*p) return hipSuccess;
+    DevMemCache::Block what{-1, 0, false};
+    {
+        std::lock_guard<std::mutex> lk(g_devmem.mu);
+        auto it = g_devmem.live.find(*p);
+        if (it != g_devmem.live.end()) what = it->second;
+    }
+    if (what.device < 0 || !what.pooled) return hipSuccess;
+    void *q = nullptr;
+    hipError_t e = dm_malloc(&q, what.bytes, true);
+    if (e != hipSuccess) return e;
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(q, *p, what.bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void) dm_free(q);
+        return e;
+    }
+    (void) dm_free(*p);
+    *p = q;
+    return hipSuccess;
 }
 
 int fail(const char *fmt, ...)

@@ -146,6 +146,14 @@ uint64_t        commet_device_cache_trim(int device);
 uint64_t        commet_readset_cache_estimate(commet_ctx *ctx, const commet_readset *rs);
 int             commet_readset_reserve_cache(commet_ctx *ctx, const commet_readset *rs);
 uint64_t        commet_device_cache_bytes(int device);
+/* COMMET_DEVMEM_POOL=1 (off by default): new blocks of 256 MiB or more come from the driver's stream-ordered pool (hipMallocAsync
+ * on a stream of the library's own, drained before the block is used): 0.4-0.9 ms per GiB on every box, where hipMalloc takes
+ * 30-60 ms per GiB on some and nothing on others (tools/exp/alloc_cost*.hip) — but kernels gather ~4 % more slowly from pool
+ * memory and on a box of the second kind the 10-set matrix lost 1.8 s of 10.9 s with it (profiles/r05_pool), hence off.  No HIP
+ * IPC handle exists for such memory: commet_readset_export moves the set's buffers into hipMalloc blocks first (once per set, a
+ * device-to-device copy), and a caller that shares library memory by other means checks here.
+ * commet_device_pooled_bytes(device): bytes of such blocks in use now. */
+uint64_t        commet_device_pooled_bytes(int device);
 
 /* ---- the two kernels ------------------------------------------------------ */
 /* Replaces `new BloomFilter` per chunk (index_and_search.cpp:256-262,

@@ -113,3 +113,67 @@ def test_device_memory_is_kept_for_reuse_and_given_back():
         a, b = commet_amd.ReadSet.from_files(ctx, [b0]), commet_amd.ReadSet.from_files(ctx, [b1])
         tags, stats, _ = ctx.index_and_search(a, [b])
         assert np.array_equal(tags[0], runs[0][0]) and stats[0]["shared"] == runs[0][1]
+
+
+def test_pooled_blocks_and_the_export_of_a_set_that_lies_in_them(tmp_path):
+    """COMMET_DEVMEM_POOL=1: new blocks above a threshold (256 MiB; 8 MiB here, COMMET_DEVMEM_POOL_MIN_MB) come from hipMallocAsync — no IPC handle exists
+    for them: a set whose planes lie in such a block gives the same job results before and after commet_readset_export moved them
+    into a hipMalloc block, a second process imports it and agrees with its own parse, pooled blocks are filed and reused like
+    the others and trimming gives them back.  (A process of its own: the threshold is read once.)"""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(23)
+    b0, b1 = _sets(rng, 2, 260000, 100)                                       # planes of ~10 MB
+    np.save(tmp_path / "b0.npy", b0[0]), np.save(tmp_path / "o0.npy", b0[1])
+    np.save(tmp_path / "b1.npy", b1[0]), np.save(tmp_path / "o1.npy", b1[1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = f'''
+import sys, subprocess, numpy as np
+sys.path.insert(0, {root!r})
+import commet_amd
+d = {str(tmp_path)!r}
+s0 = (np.load(d + "/b0.npy"), np.load(d + "/o0.npy"))
+s1 = (np.load(d + "/b1.npy"), np.load(d + "/o1.npy"))
+'''
+    child = common + '''
+with commet_amd.Context(k=25, t=2) as ctx:
+    got = commet_amd.ReadSet.import_(ctx, open(d + "/set.blob", "rb").read())
+    own, q = commet_amd.ReadSet.from_files(ctx, [s0]), commet_amd.ReadSet.from_files(ctx, [s1])
+    r1, r2 = ctx.index_and_search(got, [q]), ctx.index_and_search(own, [q])
+    assert np.array_equal(r1[0][0], r2[0][0]) and r1[1][0]["shared"] == r2[1][0]["shared"] > 1000
+    np.save(d + "/child_tags.npy", r1[0][0])
+print("imported ok")
+'''
+    open(tmp_path / "child.py", "w").write(child)
+    parent = common + '''
+commet_amd.device_cache_trim()
+with commet_amd.Context(k=25, t=2) as ctx:                      # (a 16 MiB filter: pooled as well)
+    a, q = commet_amd.ReadSet.from_files(ctx, [s0]), commet_amd.ReadSet.from_files(ctx, [s1])
+    pooled = commet_amd.device_pooled_bytes(0)
+    assert pooled >= 2 * 9000000 + (1 << 24), pooled
+    before = ctx.index_and_search(a, [q])
+    filed0, pooled = commet_amd.device_cache_bytes(0), commet_amd.device_pooled_bytes(0)   # (the job took workspaces from the pool too)
+    open(d + "/set.blob", "wb").write(a.export())
+    moved = pooled - commet_amd.device_pooled_bytes(0)
+    assert moved >= 9000000, moved                                # the planes left the pool (the old block is filed)
+    filed1 = commet_amd.device_cache_bytes(0)
+    assert filed1 == filed0 + moved, (filed0, filed1, moved)
+    after = ctx.index_and_search(a, [q])
+    assert np.array_equal(before[0][0], after[0][0]) and before[1][0]["shared"] == after[1][0]["shared"] > 1000
+    pooled = commet_amd.device_pooled_bytes(0)
+    again = a.export()                                            # nothing left to move
+    assert commet_amd.device_pooled_bytes(0) == pooled
+    p = subprocess.run([sys.executable, d + "/child.py"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"imported ok" in p.stdout, p.stdout.decode()[-2000:]
+    assert np.array_equal(np.load(d + "/child_tags.npy"), before[0][0])
+    b = commet_amd.ReadSet.from_files(ctx, [s0])                  # the next set takes the filed (pooled) block of the first one's planes
+    assert commet_amd.device_cache_bytes(0) <= filed1 - moved, (commet_amd.device_cache_bytes(0), filed1, moved)
+assert commet_amd.device_pooled_bytes(0) == 0
+filed = commet_amd.device_cache_bytes(0)
+assert commet_amd.device_cache_trim() == filed > 0 and commet_amd.device_cache_bytes(0) == 0
+print("parent ok")
+'''
+    env = dict(os.environ, COMMET_DEVMEM_POOL="1", COMMET_DEVMEM_POOL_MIN_MB="8")
+    env.pop("COMMET_DEVMEM_CACHE", None)
+    p = subprocess.run([sys.executable, "-c", parent], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"parent ok" in p.stdout, p.stdout.decode()[-3000:]
