@@ -24,6 +24,13 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
     const auto wall0 = std::chrono::steady_clock::now();
     if (n_jobs < 0) return fail("n_jobs must be >= 0");
     commet_job_info sum = commet_job_info();
+    auto lap_t = wall0;                            // host-side phase times of the call (COMMET_JOB_VERBOSE: one line per call on stderr)
+    double ph_plan = 0, ph_launch = 0, ph_wait = 0;
+    auto lap = [&](double &acc) {
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double, std::milli>(now - lap_t).count();
+        lap_t = now;
+    };
     auto one_by_one = [&]() -> int {
         for (int j = 0; j < n_jobs; ++j) {
             commet_job_info ji = commet_job_info();
@@ -123,6 +130,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         if (most <= 2 && tiled_ok(c, search_rs, 2)) fast = false;
     }
     if (!fast) return one_by_one();
+    lap(ph_plan);
 
     // ---- passes: consecutive jobs while their chunks fit the eight slots ---------------------------------------------------------------
     const uint64_t tag_words = bitmap_words(search_rs->n_reads);
@@ -140,10 +148,18 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         HIP_OK(dev_alloc(c, (void **) &c->d_jobcnt, 64 * sizeof(unsigned long long), true));
         c->jobcnt_cap = 64;
     }
-    std::vector<hipEvent_t> evs;
+    struct Tidy {                                  // on every way out: the events destroyed, the context's slot cursor back at 0
+        commet_ctx *c;
+        std::vector<hipEvent_t> evs;
+        ~Tidy()
+        {
+            c->cur_slot = 0;
+            for (hipEvent_t e : evs) (void) hipEventDestroy(e);
+        }
+    } tidy{c, {}};
     auto new_event = [&](hipEvent_t *e) -> int {
         HIP_OK(hipEventCreate(e));
-        evs.push_back(*e);
+        tidy.evs.push_back(*e);
         return 0;
     };
     int rc = 0;
@@ -200,6 +216,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         if (launch_search_group(c, search_rs, g, 8, nullptr, c->d_mtags, c->d_jobcnt, 2, nullptr, ActiveList{nullptr, nullptr}, 0, job_mask, tag_words)) { rc = 1; break; }
         ++sum.search_launches;
         (void) hipEventRecord(ec, c->stream);
+        lap(ph_launch);
         unsigned long long h_cnt[16];
         if (hipMemcpyAsync(h_cnt, c->d_jobcnt, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail("counter copy failed"); break; }
         for (int j = j0; j < j1 && !rc; ++j)
@@ -208,6 +225,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
                 rc = fail("tag copy failed");
         if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail("stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
         c->kclock.collect();
+        lap(ph_wait);
         if (rc) break;
         float ms_i = 0, ms_s = 0;
         (void) hipEventElapsedTime(&ms_i, ea, eb);
@@ -235,9 +253,11 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         }
         j0 = j1;
     }
-    for (hipEvent_t e : evs) (void) hipEventDestroy(e);
     if (rc) return rc;
     sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (c->job_verbose)
+        fprintf(stderr, "[jobs x%d] plans %.2f ms, launches %.2f ms, wait + download %.2f ms; device: index %.2f ms, search %.2f ms\n", n_jobs, ph_plan,
+                ph_launch, ph_wait, sum.index_ms, sum.search_ms);
     if (info) *info = sum;
     return 0;
 }

@@ -1,0 +1,13 @@
+# round 5, call 24: host-side phases of every job call of the configs[3] leg (COMMET_JOB_VERBOSE)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05_phases
+mkdir -p $O
+COMMET_JOB_VERBOSE=1 python3 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-sample 0 --no-probe-count --no-kernel-times > $O/bench.json 2> $O/bench.err
+grep -c "^\[job" $O/bench.err
+python3 - $O/bench.json <<'PY'
+import json, sys
+b = json.load(open(sys.argv[1])); d = b["detail"]
+for n in ("matrix_configs2", "matrix"):
+    m = d[n]; pr = m["per_rank"][0]
+    print(n, "total_s", m.get("total_s"), "jobs_s", m.get("jobs_s"), "set_wait_s", m.get("set_wait_s"), "device_ms", pr.get("device_ms"), "call_ms", pr.get("call_ms"), m.get("error"))
+PY
