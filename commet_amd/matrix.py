@@ -752,10 +752,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         shared = {}                    # (from set, in set) -> reads of `from` found in `in`
         reads_searched = 0
 
+        call_log = os.environ.get("COMMET_MATRIX_CALL_LOG")   # one line per library call: jobs, wall, event-timed device time, python clock
+
         def _acc(inf, n=1):
             prof["jobs"] += n
             prof["call_ms"] += inf["total_ms"]
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
+            if call_log:
+                with open(call_log, "a") as fh:
+                    fh.write(f"{rank} {n} {inf['total_ms']:.3f} {inf['index_ms']:.3f} {inf['search_ms']:.3f} {time.perf_counter():.6f}\n")
 
         # the .bv and .log files of a job are written by two helper threads while the next job runs (6 MB per 50 M-read file: 3-4 ms
         # of a job's ~6 ms of host time at configs[3]); all of them are on disk before the jobs' clock stops
