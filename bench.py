@@ -79,6 +79,11 @@ def parse_args():
     ap.add_argument("--skew", type=float, default=0.0,
                     help="fraction of every set's reads replaced by low-complexity / repeated reads (poly-A, tandem repeats, a shared "
                          "1000-read library): the non-uniform data leg, synth.skew_set")
+    ap.add_argument("--ragged", default="50-150",
+                    help="LO-HI: a second, untimed-from-the-headline leg on RAGGED sets (read lengths uniform in [LO, HI], same copy / mutation rules; "
+                         "50-150 has the bases, k-mers and first-hit windows per read of the 100-bp sets) — one GPU only: the configs[1] step and the "
+                         "10-set matrix of configs[2], reported in detail.ragged; 'none' skips it")
+    ap.add_argument("--ragged-only", action="store_true", help="the headline step itself on ragged sets (A/B runs, profiles): value is then the ragged rate")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, meet at the barriers, print the line's launch fields and leave (no GPU work: the CPU test of the launch path)")
     return ap.parse_args()
@@ -189,20 +194,24 @@ def cpu_full_job(args, b0, b1, gpu_tags, gpu_stats):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def cpu_baseline(args, b0, b1):
-    """Times the reference CPU path on the first `cpu_sample` reads of both sets (rank 0, N=1 only): one copy alone,
-    then one independent copy per host core (P = 1 and P = all, P stated)."""
+def cpu_baseline(args, b0, b1, gpu_info=None):
+    """Times the reference CPU path (rank 0, N=1 only) on two bounded samples of the job, one independent copy per host core
+    (P stated):
+      heavy (the line's `value`): the index set's FIRST CHUNK fed whole (70 % of the set: as many reads as stay under the reference's
+        max_kmer, index_and_search.cpp:73,146 — the filter is then as full as the real job's first filter, 11 % at configs[1]) and
+        every 50th read of the search set searched against it (a quarter of them copies, as in the whole set); the tool's own
+        index / search clocks are scaled to the whole job: index x (reads of the set / reads indexed), search x 50 x (read scans of
+        the whole job, from the GPU's run, / reads of the set);
+      light (secondary, what rounds 1-5 reported): the first `cpu_sample` reads of both sets — filters 1.6 % full and every sampled
+        search read a copy of an indexed one, which flatters the CPU by ~2x."""
     n = min(args.cpu_sample, args.reads)
     if n <= 0:
         return None
+    import numpy as np
     from commet_amd import synth
     L = args.read_len
-    work = tempfile.mkdtemp(prefix="commet_cpu_")
+    work = tempfile.mkdtemp(prefix="commet_cpu_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
     try:
-        synth.write_fasta_fast(os.path.join(work, "s0.fa"), b0[: n * L], n, L)
-        synth.write_fasta_fast(os.path.join(work, "s1.fa"), b1[: n * L], n, L)
-        open(os.path.join(work, "i.txt"), "w").write(f"s0:{work}/s0.fa\n")
-        open(os.path.join(work, "s.txt"), "w").write(f"s1:{work}/s1.fa\n")
         ref = os.path.join(ROOT, "oracle", "_ref", "index_and_search")
         if os.path.exists(ref):
             kind, tool = "reference", ref
@@ -210,13 +219,13 @@ def cpu_baseline(args, b0, b1):
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_build/oracle_cli"], check=True)
             kind, tool = "port", os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
-        def copies(p):
-            """p concurrent copies; returns [(seconds of the hot path, wall seconds)] per copy"""
+        def copies(p, tag):
+            """p concurrent copies on <work>/<tag>_{i,s}.txt; returns [(index s, search s, wall s, log numbers)] per copy"""
             procs, t0 = [], time.time()
             for c in range(p):
-                d = os.path.join(work, f"run{p}_{c}")
+                d = os.path.join(work, f"run_{tag}_{p}_{c}")
                 os.makedirs(d)
-                procs.append((d, subprocess.Popen([tool, "-i", os.path.join(work, "i.txt"), "-s", os.path.join(work, "s.txt"), "-o", "out",
+                procs.append((d, subprocess.Popen([tool, "-i", os.path.join(work, tag + "_i.txt"), "-s", os.path.join(work, tag + "_s.txt"), "-o", "out",
                                                    "-l", "log", "-k", str(args.k), "-t", str(args.t)], cwd=d,
                                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
             out = []
@@ -224,23 +233,56 @@ def cpu_baseline(args, b0, b1):
                 if pr.wait() != 0:
                     raise RuntimeError("CPU baseline tool failed")
                 wall = time.time() - t0
-                hot = None
+                ti = ts = None
+                nums = None
                 if kind == "reference":      # its own clock() around index_reads / search_reads (index_and_search.cpp:252-300)
                     lines = open(os.path.join(d, "log", "s1_in_s0.log")).read().split("\n")
-                    hot = float(lines[0].split()[2]) + float(lines[1].split()[2])
-                out.append((hot if hot else wall, wall))
+                    ti, ts = float(lines[0].split()[2]), float(lines[1].split()[2])
+                    nums = [int(x) for x in re.findall(r"\d+", lines[3])]
+                out.append((ti, ts, wall, nums))
+                shutil.rmtree(d, ignore_errors=True)
             return out
 
-        one = copies(1)[0]
+        def write_sets(tag, idx_reads, srch_ids):
+            """<tag>_i.txt / <tag>_s.txt: the first idx_reads reads of set 0, the reads srch_ids of set 1"""
+            v0 = np.asarray(b0[: idx_reads * L]).reshape(idx_reads, L)
+            synth.write_fasta_fast(os.path.join(work, tag + "0.fa"), v0, idx_reads, L)
+            v1 = np.asarray(b1).reshape(-1, L)[srch_ids]
+            synth.write_fasta_fast(os.path.join(work, tag + "1.fa"), np.ascontiguousarray(v1), len(srch_ids), L)
+            open(os.path.join(work, tag + "_i.txt"), "w").write(f"s0:{work}/{tag}0.fa\n")
+            open(os.path.join(work, tag + "_s.txt"), "w").write(f"s1:{work}/{tag}1.fa\n")
+
         P = host_cores()
-        many = copies(P) if P > 1 else [one]
-        rate_all = sum(n / hot for hot, _ in many)
-        return {"value": round(rate_all, 1), "unit": "reads/s", "cores": P, "kind": kind,
-                "value_1core": round(n / one[0], 1),
-                "sample": f"first {n} reads of each of the 2 synthetic sets ({100.0 * n / args.reads:.0f} % of the job), k={args.k} t={args.t}; "
-                          f"1 copy: {'tool-reported index+search CPU time' if kind == 'reference' else 'wall time'} {one[0]:.2f} s (process wall {one[1]:.2f} s); "
-                          f"{P} independent copies at once (one per host core of this box's cgroup): sum of the copies' own rates, "
-                          f"slowest copy {max(h for h, _ in many):.2f} s, wall {max(w for _, w in many):.2f} s"}
+        # ---- light sample: the first n reads of both sets ----
+        write_sets("light", n, np.arange(n))
+        one = copies(1, "light")[0]
+        hot1 = (one[0] + one[1]) if one[0] is not None else one[2]
+        many = copies(P, "light") if P > 1 else [one]
+        light_all = sum(n / ((a + b) if a is not None else w) for a, b, w, _ in many)
+        light = {"value": round(light_all, 1), "value_1core": round(n / hot1, 1),
+                 "sample": f"first {n} reads of each set ({100.0 * n / args.reads:.0f} % of the job): filters 1.6 % full, every sampled search read a copy of an "
+                           f"indexed one; 1 copy {hot1:.2f} s, {P} copies at once: slowest {max((a + b) if a is not None else w for a, b, w, _ in many):.2f} s"}
+        res = {"value": light["value"], "unit": "reads/s", "cores": P, "kind": kind, "value_1core": light["value_1core"], "sample": light["sample"]}
+        # ---- heavy sample: the first chunk fed whole, a strided sample of the search set ----
+        max_kmer = int(1e9 / 2 ** (33 - args.k)) if args.k <= 33 else int(1e9)
+        per_read = max(1, L - args.k + 1)
+        idx_reads = min(args.reads, int(0.97 * max_kmer / per_read))      # (under max_kmer: ONE chunk, no dropped look-ahead read)
+        if kind == "reference" and gpu_info and idx_reads >= args.reads // 4 and args.reads >= 1_000_000:
+            stride = 50
+            srch = np.arange(0, args.reads, stride)
+            write_sets("heavy", idx_reads, srch)
+            hv = copies(P, "heavy")
+            scans = gpu_info["reads_scanned"]
+            full_s = [a * (args.reads / max(1, nums[0])) + b * stride * (scans / args.reads) for a, b, w, nums in hv]
+            res.update(value=round(sum(args.reads / x for x in full_s), 1), value_1core=None,
+                       sample=(f"{P} independent copies at once (one per host core of this box's cgroup), each: the index set's first chunk fed whole "
+                               f"({idx_reads} reads = {100.0 * idx_reads / args.reads:.0f} % of the set, one filter as full as the real job's first) and every {stride}th read of the "
+                               f"search set ({len(srch)} reads) searched against it; the tool's own clocks (index {min(a for a, *_ in hv):.1f}-{max(a for a, *_ in hv):.1f} s, "
+                               f"search {min(b for _, b, *_ in hv):.2f}-{max(b for _, b, *_ in hv):.2f} s per copy, wall {max(w for _, _, w, _ in hv):.1f} s) scaled to the WHOLE job: "
+                               f"index x {args.reads}/{hv[0][3][0]}, search x {stride} x {scans}/{args.reads} read scans (the GPU run's count) = "
+                               f"{min(full_s):.0f}-{max(full_s):.0f} s per copy; value = sum of the copies' whole-job rates"),
+                       light_sample=light)
+        return res
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -301,6 +343,76 @@ def progress(ranks, msg):
         print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
+def parse_ragged(spec):
+    """'LO-HI' -> (lo, hi), None for 'none' / ''"""
+    if not spec or spec.lower() in ("none", "off", "0"):
+        return None
+    lo, hi = (int(x) for x in spec.split("-"))
+    if not 1 <= lo <= hi:
+        raise SystemExit(f"--ragged {spec}: need 1 <= LO <= HI")
+    return lo, hi
+
+
+def ragged_leg(args, device, fixed):
+    """The configs[1] step on RAGGED sets (one GPU, after the headline; nothing of it is part of `value`): 2 synthetic sets of
+    args.reads reads whose lengths are uniform in [lo, hi] — the same copy / substitution / reverse-complement / N rules as the
+    fixed-length sets — k and t as the headline.  Real inputs are trimmed .fq.gz runs (the reference's README:105-107,
+    fastq_file.h:139-190): what they cost per read and per base beside the fixed-length figure.  `fixed` = the headline's
+    {reads_per_s, bases_per_s, index_kernel_ms, search_kernel_ms}."""
+    import commet_amd
+    from commet_amd import synth
+    lo, hi = parse_ragged(args.ragged)
+    n, k, t = args.reads, args.k, args.t
+    b0, o0 = synth.synth_set_ragged(0, n, lo, hi, base_set=0)
+    b1, o1 = synth.synth_set_ragged(1, n, lo, hi, base_set=0)
+    bases_q = int(o1[-1])
+    ctx = commet_amd.Context(k=k, t=t, device=device)
+    try:
+        irs = commet_amd.ReadSet.from_files(ctx, [(b0, o0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(b1, o1)])
+        ctx.synchronize()
+        t_c = time.perf_counter()
+        ctx.index_and_search(irs, [qrs])                       # (the set's first job: builds what is cached with the sets)
+        ctx.synchronize()
+        first_s = time.perf_counter() - t_c
+        for _ in range(max(0, args.warmup - 1)):
+            ctx.index_and_search(irs, [qrs])
+        acc = dict(index_kernel_ms=0.0, search_ms=0.0)
+        ctx.synchronize()
+        t_c = time.perf_counter()
+        for _ in range(args.steps):
+            _, stats, info = ctx.index_and_search(irs, [qrs])
+            for f in acc:
+                acc[f] += info[f]
+        ctx.synchronize()
+        el = time.perf_counter() - t_c
+        ktimes = None
+        if not args.no_kernel_times:
+            ctx.set_option("kernel_timing", 1)
+            for _ in range(2):
+                ctx.index_and_search(irs, [qrs])
+            ktimes = {name: round(ms / 2, 4) for name, (cnt, ms) in sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][1])}
+            ctx.set_option("kernel_timing", 0)
+        out = {"workload": f"2 synthetic sets x {n} reads of {lo}-{hi} bp (uniform; {bases_q / n:.1f} bp on average), k={k} t={t}, index set 0 + search set 1, inputs resident in HBM",
+               "reads_per_s": round(n * args.steps / el, 1), "bases_per_s": round(bases_q * args.steps / el, 1),
+               "ms_per_step": round(el * 1e3 / args.steps, 3), "steps": args.steps,
+               "index_kernel_ms": round(acc["index_kernel_ms"] / args.steps, 3), "search_kernel_ms": round(acc["search_ms"] / args.steps, 3),
+               "chunks": info["n_chunks"], "kmers_indexed": info["kmers_indexed"], "reads_scanned": info["reads_scanned"], "shared": stats[0]["shared"],
+               "first_job_ms": round(first_s * 1e3, 3), "query_list_bytes": qrs.cache_bytes,
+               "kernel_ms_per_step": ktimes}
+        if fixed:
+            out["vs_fixed_length"] = {"reads_per_s": round(out["reads_per_s"] / fixed["reads_per_s"], 4),
+                                      "bases_per_s": round(out["bases_per_s"] / fixed["bases_per_s"], 4),
+                                      "index_kernel_ms": round(out["index_kernel_ms"] / fixed["index_kernel_ms"], 4) if fixed.get("index_kernel_ms") else None,
+                                      "search_kernel_ms": round(out["search_kernel_ms"] / fixed["search_kernel_ms"], 4) if fixed.get("search_kernel_ms") else None,
+                                      "fixed": fixed}
+        irs.close()
+        qrs.close()
+        return out
+    finally:
+        ctx.close()
+
+
 def matrix_size(args, ranks, root):
     """reads per set of the like-for-like matrix leg: BASELINE configs[3] (10 x 50 M reads) at EVERY N, one GPU included, so that the
     per-N values are one curve; what the host cannot hold as FASTA in the scratch root is cut down (and said so).  Returns (n, note)."""
@@ -320,9 +432,10 @@ def matrix_size(args, ranks, root):
     return n, note
 
 
-def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
+def matrix_leg(args, ranks, n, note=None, fatal_hook=None, ragged=None):
     """The full S x S matrix of S synthetic sets of n reads through the resident N x N driver, split over the ranks; sets written
-    as FASTA to scratch (each rank generates its share), filter + load + jobs all timed by the driver."""
+    as FASTA to scratch (each rank generates its share), filter + load + jobs all timed by the driver.
+    ragged = (lo, hi): read lengths uniform in [lo, hi] instead of args.read_len."""
     from commet_amd import matrix, synth
     root = os.environ.get("COMMET_SCRATCH") or ("/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
     # rank 0 makes the work directory (mkdtemp: a fresh name, mode 0700 — /dev/shm is shared with other users)
@@ -330,17 +443,22 @@ def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
     _WORK_DIRS.append(work)
     S, L = args.matrix_sets, args.read_len
     which = {(10, 10_000_000): "BASELINE configs[2]", (10, 50_000_000): "BASELINE configs[3]"}.get((S, n), "custom size")
+    if ragged:
+        which += f", RAGGED reads of {ragged[0]}-{ragged[1]} bp"
     progress(ranks, f"matrix leg: {S} sets x {n} reads ({which}) over {ranks.world} rank(s): writing the FASTA files under {work}")
     saved_scratch = os.environ.get("COMMET_SCRATCH")
     os.environ["COMMET_SCRATCH"] = work          # the driver's own scratch (descriptors, packed images) inside the work directory:
     try:                                          # whoever removes `work` removes everything this leg ever wrote
         t0 = time.perf_counter()
-        mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
+        if ragged:
+            mine = [(s, n, ragged[0], ragged[1], os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
+        else:
+            mine = [(s, n, L, os.path.join(work, f"set{s}.fa")) for s in range(S) if s % ranks.world == ranks.rank]
         if mine:
             import multiprocessing as mp
             # (a 50 M-read set is ~12 GB of generator state per worker process)
             with mp.get_context("spawn").Pool(min(len(mine), max(1, host_cores() // (2 * ranks.world) if ranks.world > 1 else host_cores() // 2))) as pool:
-                pool.map(synth.write_set_fasta, mine, chunksize=1)
+                pool.map(synth.write_set_fasta_ragged if ragged else synth.write_set_fasta, mine, chunksize=1)
         if ranks.rank == 0:
             with open(os.path.join(work, "sets.txt"), "w") as fh:
                 for s in range(S):
@@ -364,10 +482,14 @@ def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
             ranks.barrier()
         if ranks.failed and ranks.world > 1:
             time.sleep(3.0)                             # (the other ranks notice within a second and are out of their jobs by then)
+        t_rm = time.perf_counter()
         if ranks.rank == 0 or ranks.failed:             # (a failed job: whoever gets here removes what is left)
             shutil.rmtree(work, ignore_errors=True)
         _WORK_DIRS.remove(work)
-    progress(ranks, "matrix leg: done")
+        cleanup_s = time.perf_counter() - t_rm
+    # (the seconds between the last job and this line are the removal of the leg's FASTA files — 56 GB at configs[3] — from the scratch
+    # root, outside total_s: the files are the bench's, not the driver's)
+    progress(ranks, f"matrix leg: done (work directory removed in {cleanup_s:.1f} s)")
     if res is None:
         return None
     keep = ("filter_s", "load_s", "jobs_s", "set_wait_s", "total_s", "reads_searched", "reads_per_s", "reads_per_s_incl_load_and_filter", "world",
@@ -375,13 +497,19 @@ def matrix_leg(args, ranks, n, note=None, fatal_hook=None):
     out = {f: (round(res[f], 4) if isinstance(res[f], float) else res[f]) for f in keep}
     per_rank = [{f: (round(v, 4) if isinstance(v, float) else v) for f, v in p.items()} for p in res["per_rank"]]
     busy = [p["jobs_s"] + p.get("set_wait_s", 0.0) for p in per_rank]
-    out.update(workload=f"{S} synthetic sets x {n} x {L} bp reads, full {S} x {S} matrix ({which}) over {ranks.world} GPU(s): "
+    out.update(workload=f"{S} synthetic sets x {n} x {f'{ragged[0]}-{ragged[1]}' if ragged else L} bp reads, full {S} x {S} matrix ({which}) over {ranks.world} GPU(s): "
                         f"filter_reads + parse/upload + {S * S - 1} Commet.py jobs' worth of work",
                generate_s=round(gen_s, 2), size_note=note,
                handover=sorted({p.get("handover") for p in per_rank}) if ranks.world > 1 else None,
                # how evenly the static cut of the pairs loaded the ranks: slowest / mean of the ranks' job time (1.0 = even),
                # and what the cut predicted for every rank (its share of the pairs' cost) beside what it took
                imbalance=round(max(busy) / (sum(busy) / len(busy)), 4) if busy and sum(busy) > 0 else None,
+               # what the DRIVER charged for device memory during the leg (commet_device_alloc_stats): host time inside hipMalloc on the
+               # slowest rank, bytes asked fresh from the driver over all ranks — box tax, not kernel time
+               alloc_wait_ms=max((p.get("alloc_wait_ms", 0.0) for p in per_rank), default=None),
+               fresh_device_bytes=sum(p.get("fresh_device_bytes", 0) for p in per_rank),
+               device_ms=max((p.get("device_ms", 0.0) for p in per_rank), default=None),
+               remove_work_dir_s=round(cleanup_s, 2),
                predicted_vs_actual_share=[{"rank": p["rank"], "predicted": p.get("predicted_share"),
                                            "actual": round(b / sum(busy), 4) if sum(busy) > 0 else None} for p, b in zip(per_rank, busy)],
                per_rank=per_rank)
@@ -424,7 +552,11 @@ def main():
 
     n, L, k, t = args.reads, args.read_len, args.k, args.t
     # every rank owns one (i, j) job of the N x N matrix: sets (2r, 2r+1)
-    if args.skew > 0:
+    ragged_hl = parse_ragged(args.ragged) if args.ragged_only else None
+    if ragged_hl:
+        b0, o0 = synth.synth_set_ragged(2 * rank, n, ragged_hl[0], ragged_hl[1], base_set=2 * rank)
+        b1, o1 = synth.synth_set_ragged(2 * rank + 1, n, ragged_hl[0], ragged_hl[1], base_set=2 * rank)
+    elif args.skew > 0:
         b0, o0 = synth.synth_set_skewed(2 * rank, n, L, args.skew, base_set=2 * rank)
         b1, o1 = synth.synth_set_skewed(2 * rank + 1, n, L, args.skew, base_set=2 * rank)
     else:
@@ -507,6 +639,20 @@ def main():
     qrs.close()
     ctx.close()
 
+    # ---- the same step on ragged sets (one GPU; nothing of it is part of `value`) ----------------------------------
+    ragged_detail = None
+    if world == 1 and parse_ragged(args.ragged) and not args.ragged_only:
+        progress(ranks, f"ragged leg: 2 sets x {n} reads of {args.ragged} bp")
+        try:
+            ragged_detail = ragged_leg(args, device, {"reads_per_s": round(n * args.steps / elapsed, 1), "bases_per_s": round(float(o1[-1]) * args.steps / elapsed, 1),
+                                                      "index_kernel_ms": round(acc["index_kernel_ms"] / args.steps, 3),
+                                                      "search_kernel_ms": round(acc["search_ms"] / args.steps, 3)})
+            progress(ranks, f"ragged leg: {ragged_detail['ms_per_step']:.3f} ms per step, {ragged_detail['vs_fixed_length']['bases_per_s']:.3f} x the fixed-length bases/s")
+        except Exception as ex:   # the headline measured above must not be lost with this extra leg
+            import traceback
+            traceback.print_exc()
+            ragged_detail = {"error": f"{type(ex).__name__}: {ex}"}
+
     import threading
     emitted = threading.Event()
 
@@ -524,6 +670,9 @@ def main():
                         f"per GPU ({which}), inputs resident in HBM")
             if args.skew > 0:
                 workload += f"; {100 * args.skew:g} % of every set's reads low-complexity / repeated (poly-A, tandem repeats, shared 1000-read library)"
+            if ragged_hl:
+                workload = (f"2 synthetic sets x {n} RAGGED reads of {ragged_hl[0]}-{ragged_hl[1]} bp (uniform), k={k} t={t}, index set 0 + search set 1 "
+                            f"per GPU (custom: --ragged-only), inputs resident in HBM")
             kmers = info["kmers_indexed"]
             idx_ms = acc["index_kernel_ms"] / steps
             srch_ms = acc["search_ms"] / steps
@@ -621,6 +770,11 @@ def main():
                 "metric": "reads/sec searched (index_and_search, k=%d)" % k,
                 "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                # what `value` is, and the figure for ONE pair met for the first time, beside it
+                "value_note": "steady state of the N x N use (a set is searched N-1 times): the search set's query list — derived from the set and (k, t) alone — "
+                              "is cached with the resident set; the index set's filters are rebuilt in every step.  first_job_reads_per_s = one job on a search "
+                              "set never scanned before (list build included, warm context)",
+                "first_job_reads_per_s": round(world * n / first_job_s, 1),
                 "dtype": "u32" if k <= 32 else "u64", "data": "synthetic",
                 "config": {"workload": workload,
                            "reads_per_set": n, "read_len": L, "k": k, "t": t, "jobs": world,
@@ -640,6 +794,7 @@ def main():
                            "upload_and_pack_s": round(upload_s, 3), "upload_second_set_s": round(upload_s - upload_first_s, 3),
                            "end_to_end_reads_per_s_incl_pcie": round(n / (upload_s + elapsed / steps), 1),
                            "end_to_end_reads_per_s_incl_pcie_warm_staging": round(n / (2 * (upload_s - upload_first_s) + elapsed / steps), 1),
+                           "ragged": ragged_detail,
                            "matrix": matrix_detail, "matrix_configs2": matrix_c2},
             }
             if matrix_detail and "error" in matrix_detail:
@@ -650,9 +805,9 @@ def main():
                 # the N x N matrix through the resident driver, everything included — the figure the 1 -> 8 GPU curve is about
                 # (the same workload at every N — BASELINE configs[3] when the host holds it — so the per-N values are one curve)
                 out["matrix"] = {f: matrix_detail[f] for f in ("workload", "world", "reads_per_s_incl_load_and_filter", "reads_per_s", "total_s",
-                                                               "jobs_s", "set_wait_s", "handover", "imbalance", "predicted_vs_actual_share", "size_note")}
+                                                               "jobs_s", "set_wait_s", "alloc_wait_ms", "fresh_device_bytes", "handover", "imbalance", "predicted_vs_actual_share", "size_note")}
             if world == 1:
-                out["cpu_baseline"] = cpu_baseline(args, b0, b1)
+                out["cpu_baseline"] = cpu_baseline(args, b0, b1, info) if not ragged_hl else None
                 if out["cpu_baseline"] is not None and not args.cpu_full:
                     # the whole job was run once on one core (--cpu-full, minutes): quoted from the committed record of that run
                     try:
@@ -711,6 +866,16 @@ def main():
                     matrix_c2 = matrix_leg(args, ranks, 10_000_000)
                 except Exception as ex:
                     matrix_c2 = {"error": f"{type(ex).__name__}: {ex}"}
+            if world == 1 and parse_ragged(args.ragged) and isinstance(ragged_detail, dict) and "error" not in ragged_detail:
+                # ... and the same 10-set matrix on ragged sets (detail.ragged.matrix), beside the fixed-length leg it is to be held against
+                n_r = 10_000_000 if args.matrix_reads is None else args.matrix_reads
+                try:
+                    mr = matrix_leg(args, ranks, n_r, ragged=parse_ragged(args.ragged))
+                    if mr and matrix_c2 and "error" not in matrix_c2 and args.matrix_reads is None:
+                        mr["vs_fixed_length_total_s"] = round(mr["total_s"] / matrix_c2["total_s"], 4)
+                    ragged_detail["matrix"] = mr
+                except Exception as ex:
+                    ragged_detail["matrix"] = {"error": f"{type(ex).__name__}: {ex}"}
             # (a rank whose import of another rank's set hangs ends itself from a watchdog thread: rank 0 prints the line first)
             matrix_detail = matrix_leg(args, ranks, n_m, note, fatal_hook=lambda msg: (emit({"error": msg}, matrix_c2), sys.stdout.flush()))
         except Exception as ex:   # the headline measured above must not be lost with this extra leg

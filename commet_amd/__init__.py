@@ -7,6 +7,6 @@ Only what the path needs lives here:
   synth.py   the synthetic read sets of SURVEY §8d
   build.py   hipcc / g++ build recipes used by __graft_entry__.build()
 """
-from .api import Context, ReadSet, CommetError, device_count, device_cache_trim, device_cache_bytes, device_pooled_bytes  # noqa: F401
+from .api import Context, ReadSet, CommetError, device_count, device_cache_trim, device_cache_bytes, device_pooled_bytes, device_alloc_stats  # noqa: F401
 
-__all__ = ["Context", "ReadSet", "CommetError", "device_count", "device_cache_trim", "device_cache_bytes", "device_pooled_bytes"]
+__all__ = ["Context", "ReadSet", "CommetError", "device_count", "device_cache_trim", "device_cache_bytes", "device_pooled_bytes", "device_alloc_stats"]

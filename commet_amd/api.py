@@ -57,6 +57,14 @@ def device_pooled_bytes(device=0):
     return int(_l.load().commet_device_pooled_bytes(int(device)))
 
 
+def device_alloc_stats(device=-1):
+    """commet_device_alloc_stats: what the library asked the driver for since the process started (blocks reused from its own
+    cache do not count): {"wait_ms": host time inside hipMalloc, "fresh_bytes", "calls"}"""
+    ms, by, n = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    _l.load().commet_device_alloc_stats(int(device), C.byref(ms), C.byref(by), C.byref(n))
+    return {"wait_ms": float(ms.value), "fresh_bytes": int(by.value), "calls": int(n.value)}
+
+
 class Context:
     """commet_ctx: device, k, t, the 4-lane Bloom filter in HBM."""
 

@@ -95,6 +95,19 @@ uint64_t commet_device_pooled_bytes(int device)
     return (uint64_t) dm_pooled_bytes(device);
 }
 
+int commet_device_alloc_stats(int device, double *wait_ms, uint64_t *fresh_bytes, uint64_t *calls)
+{
+    uint64_t ns = 0, by = 0, n = 0;
+    for (int d = 0; d < 16; ++d) {
+        if (device >= 0 && d != device) continue;
+        ns += g_devmem.drv_ns[d].load(), by += g_devmem.drv_bytes[d].load(), n += g_devmem.drv_calls[d].load();
+    }
+    if (wait_ms) *wait_ms = (double) ns * 1e-6;
+    if (fresh_bytes) *fresh_bytes = by;
+    if (calls) *calls = n;
+    return 0;
+}
+
 int commet_cache_stats(commet_ctx *c, uint64_t *bytes, uint64_t *budget_bytes, uint64_t *evictions)
 {
     std::lock_guard<std::mutex> lk(c->ql_mu);

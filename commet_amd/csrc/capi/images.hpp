@@ -165,7 +165,12 @@ int commet_readset_export(const commet_readset *rs, void *blob, uint64_t cap, ui
     HIP_OK(hipStreamSynchronize(c->load_stream));        // the planes are complete
     {   // buffers from the stream-ordered pool have no IPC handle: moved into hipMalloc blocks once, here (state.hpp, dm_make_shareable)
         commet_readset *w = const_cast<commet_readset *>(rs);
-        if (rs->in_job) return fail("read set is part of a running job: export it before or after");
+        bool busy;
+        {
+            std::lock_guard<std::mutex> lk(c->ql_mu);           // (in_job is written under this mutex)
+            busy = rs->in_job;
+        }
+        if (busy) return fail("read set is part of a running job: export it before or after");
         HIP_OK(dm_make_shareable((void **) &w->d_planes));
         if (t.has_goff) HIP_OK(dm_make_shareable((void **) &w->d_goff));
     }

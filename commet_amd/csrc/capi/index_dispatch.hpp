@@ -105,6 +105,44 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     const bool wide = c->k > 32;
     // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
     const bool uni = rs->uniform_len != 0 && d_sel == nullptr && !c->part_no_uni;   // (d_ids: positions in the list of selected reads)
+    // ragged reads (with or without a selection bitmap): the chunk's items written out once, then walked like a fixed-length set
+    // (index_part.hpp, LIST) — where an item's triple, counted from the chunk's first read, fits its 28 bits
+    const uint64_t span_bound = std::min<uint64_t>((rs->n_bases >> 5) + rs->n_reads + 1, count * (((uint64_t) rs->max_len >> 5) + 2));
+    bool list = !uni && rs->uniform_len == 0 && !c->part_no_uni && c->part_list != 1 && span_bound < ITEM_MAX_TRIPLES;
+    const uint32_t *d_items = nullptr, *d_nitems = nullptr;
+    if (list) {
+        const uint64_t nblk = (count + ITEMS_BLOCK - 1) / ITEMS_BLOCK;
+        // items of the chunk at most: every read of it as long as the set's longest / the set's bases in octets plus one per read
+        const uint64_t sel_reads = pos_count ? pos_count : count;
+        const uint64_t need = std::min<uint64_t>(sel_reads * std::max<uint64_t>(1, ((uint64_t) rs->max_len + 7) / 8), rs->n_bases / 8 + rs->n_reads) + 1;
+        if (nblk + 1 >= (1ull << 24) || need >= (1ull << 32)) list = false;
+        if (list && (ws.items_cap < need || ws.itemblk_cap < nblk + 1)) {
+            HIP_OK(hipStreamSynchronize(stream));
+            (void) dm_free(ws.items), (void) dm_free(ws.itemblk);
+            ws.items = ws.itemblk = nullptr, ws.items_cap = ws.itemblk_cap = 0;
+            const uint64_t cap = need + need / 8;
+            if (dev_alloc(c, (void **) &ws.items, cap * sizeof(uint32_t), true) != hipSuccess ||
+                dev_alloc(c, (void **) &ws.itemblk, (nblk + 1 + 1024) * sizeof(uint32_t), true) != hipSuccess) {
+                (void) hipGetLastError();               // no room: the round planner walks the reads, as before
+                (void) dm_free(ws.items), (void) dm_free(ws.itemblk);
+                ws.items = ws.itemblk = nullptr;
+                list = false;
+            } else {
+                ws.items_cap = cap, ws.itemblk_cap = nblk + 1 + 1024;
+            }
+        }
+        if (list) {
+            KScope ks(c, "part_items_kernels", stream);
+            COMMET_LAUNCH(part_items_kernel<false>, dim3((unsigned) nblk), dim3(ITEMS_BLOCK), 0, stream, rs->view(), rs->d_kcnt, d_sel, first, count, c->k,
+                          ws.itemblk, ws.items);
+            COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.itemblk, (uint32_t) nblk);
+            COMMET_LAUNCH(part_items_kernel<true>, dim3((unsigned) nblk), dim3(ITEMS_BLOCK), 0, stream, rs->view(), rs->d_kcnt, d_sel, first, count, c->k,
+                          ws.itemblk, ws.items);
+            HIP_OK(hipGetLastError());
+            d_items = ws.items, d_nitems = ws.itemblk + nblk;
+        }
+    }
+    const int mode = uni ? 1 : list ? 2 : 0;
     HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
     // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
     const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
@@ -112,10 +150,12 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         const unsigned grid = (grid1 + 1) / 2;
         const bool full = g.nb <= HIST_MAX_BUCKETS;
         // 32-bit keys (k <= 32): at most 2^15 buckets, the LDS histogram always covers them all (FULL); 64-bit keys: never.
-        // Only those four instantiations exist (tests/test_gpu_zz_dispatch_coverage.py checks that each is reached).
+        // Only those six instantiations exist (tests/test_gpu_zz_dispatch_coverage.py checks that each is reached).
         if (full == wide) return fail("internal error: histogram geometry (k = %d, %u buckets)", c->k, g.nb);
-        const void *fn = wide ? (uni ? (const void *) part_hist_kernel<uint64_t, true, false> : (const void *) part_hist_kernel<uint64_t, false, false>)
-                              : (uni ? (const void *) part_hist_kernel<uint32_t, true, true> : (const void *) part_hist_kernel<uint32_t, false, true>);
+        const void *fn = wide ? (mode == 1 ? (const void *) part_hist_kernel<uint64_t, 1, false> : mode == 2 ? (const void *) part_hist_kernel<uint64_t, 2, false>
+                                                                                                             : (const void *) part_hist_kernel<uint64_t, 0, false>)
+                              : (mode == 1 ? (const void *) part_hist_kernel<uint32_t, 1, true> : mode == 2 ? (const void *) part_hist_kernel<uint32_t, 2, true>
+                                                                                                            : (const void *) part_hist_kernel<uint32_t, 0, true>);
         for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
             const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
@@ -124,7 +164,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             const uint32_t *kc = rs->d_kcnt;
             uint32_t *hist = ws.hist, *bcnt = ws.blockcnt;
             uint32_t nblk = grid1;
-            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt, &d_ids};
+            void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &b_lo, (void *) &n_b, &hist, &nblk, &bcnt, &d_ids, &d_items, &d_nitems};
             KScope ks(c, "part_hist_kernel", stream);
             note_launch(fn);
             HIP_OK(hipLaunchKernel(fn, dim3(grid), dim3(HIST_NT), args, lds, stream));
@@ -148,12 +188,14 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
     // scatter 1 (straight into the final buckets when there is a single level)
     uint32_t *level1_out = g.b2 ? ws.bufA : ws.bufB;
     {
-        const void *fn = wide ? (uni ? (const void *) part_scatter1_kernel<uint64_t, true> : (const void *) part_scatter1_kernel<uint64_t, false>)
-                              : (uni ? (const void *) part_scatter1_kernel<uint32_t, true> : (const void *) part_scatter1_kernel<uint32_t, false>);
+        const void *fn = wide ? (mode == 1 ? (const void *) part_scatter1_kernel<uint64_t, 1> : mode == 2 ? (const void *) part_scatter1_kernel<uint64_t, 2>
+                                                                                                          : (const void *) part_scatter1_kernel<uint64_t, 0>)
+                              : (mode == 1 ? (const void *) part_scatter1_kernel<uint32_t, 1> : mode == 2 ? (const void *) part_scatter1_kernel<uint32_t, 2>
+                                                                                                          : (const void *) part_scatter1_kernel<uint32_t, 0>);
         ReadsView rv = rs->view();
         const uint32_t *kc = rs->d_kcnt;
         const unsigned long long *boff = ws.blockoff;
-        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out, &d_ids};
+        void *args[] = {&rv, &kc, &d_sel, &first, &count, &g, &boff, &level1_out, &d_ids, &d_items, &d_nitems};
         KScope ks(c, "part_scatter1_kernel", stream);
         note_launch(fn);
         HIP_OK(hipLaunchKernel(fn, dim3(grid1), dim3(S1_NT), args, 0, stream));

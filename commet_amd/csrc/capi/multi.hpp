@@ -10,7 +10,7 @@
 // search_group8_kernel runs job by job (kernels.hpp, job_mask).  Every job's result is what commet_index_and_search gives for it
 // alone — tested against exactly that, and against the CPU checker through the N x N driver.
 //
-// The fast path takes what the N x N driver's jobs are: fixed-length index sets whose chunks (at most eight per job) take the bucketed
+// The fast path takes what the N x N driver's jobs are: index sets whose chunks (at most eight per job) take the bucketed
 // construction, a search set that is visited whole and qualifies for the register-mask kernel.  Anything else — and n_jobs = 1 — is
 // run job by job through commet_index_and_search itself.
 #pragma once
@@ -56,6 +56,22 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         if (index_rs[j] == search_rs) return fail("a set cannot be searched against itself in one call");
     }
     HIP_OK(hipSetDevice(c->device));
+    // the sets of this call keep their cached query lists, and are not exported, while it runs (as in commet_index_and_search; the jobs
+    // that run one by one mark their own sets again: the flag is a flag, the outer scope clears it last)
+    struct InJobs {
+        commet_ctx *c;
+        const commet_readset *const *irs;
+        const commet_readset *srs;
+        int n;
+        void mark(bool v) const
+        {
+            std::lock_guard<std::mutex> lk(c->ql_mu);
+            srs->in_job = v;
+            for (int i = 0; i < n; ++i) irs[i]->in_job = v;
+        }
+        InJobs(commet_ctx *c_, const commet_readset *const *i_, const commet_readset *s_, int n_) : c(c_), irs(i_), srs(s_), n(n_) { mark(true); }
+        ~InJobs() { mark(false); }
+    } in_jobs(c, index_rs, search_rs, n_jobs);
     // ---- does the fast path take the call? ---------------------------------------------------------------------------------------
     const uint8_t *ssel = search_select;
     if (ssel && all_ones(ssel, search_rs->n_reads)) ssel = nullptr;
@@ -74,7 +90,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         Job &job = jobs[(size_t) j];
         job.sel = index_select ? index_select[j] : nullptr;
         if (job.sel && all_ones(job.sel, rs->n_reads)) job.sel = nullptr;
-        if (!rs->n_reads || rs->uniform_len == 0 || c->part_no_uni || !plan_blocks_ok(rs->files, job.sel, rs->empty_reads, max_kmer)) {
+        if (!rs->n_reads || c->part_no_uni || !plan_blocks_ok(rs->files, job.sel, rs->empty_reads, max_kmer)) {
             fast = false;
             break;
         }
@@ -131,6 +147,15 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
     }
     if (!fast) return one_by_one();
     lap(ph_plan);
+    // no room for what a shared pass needs (eight filter slots + their interleaved A planes are 20 GiB at k = 32): the jobs one after the
+    // other, as the header promises — commet_index_and_search itself degrades to groups of four, then one.  Nothing a caller depends on
+    // has been written by then that the jobs do not write again.
+    auto no_room = [&]() -> int {
+        (void) hipGetLastError();
+        c->cur_slot = 0;
+        sum = commet_job_info();
+        return one_by_one();
+    };
 
     // ---- passes: consecutive jobs while their chunks fit the eight slots ---------------------------------------------------------------
     const uint64_t tag_words = bitmap_words(search_rs->n_reads);
@@ -138,7 +163,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         HIP_OK(hipStreamSynchronize(c->stream));
         (void) dm_free(c->d_mtags);
         c->d_mtags = nullptr, c->mtags_cap = 0;
-        HIP_OK(dev_alloc(c, (void **) &c->d_mtags, 8 * tag_words * sizeof(uint64_t), true));
+        if (dev_alloc(c, (void **) &c->d_mtags, 8 * tag_words * sizeof(uint64_t), true) != hipSuccess) return no_room();
         c->mtags_cap = 8 * tag_words;
     }
     if (c->jobcnt_cap < 16) {
@@ -166,7 +191,7 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
     for (int j0 = 0; j0 < n_jobs && !rc;) {
         int j1 = j0, g = 0;
         while (j1 < n_jobs && g + (int) jobs[(size_t) j1].plan.chunks.size() <= 8) g += (int) jobs[(size_t) j1].plan.chunks.size(), ++j1;
-        if (ensure_slots(c, g, 8)) { rc = 1; break; }
+        if (ensure_slots(c, g, 8)) return no_room();
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (new_event(&ea) || new_event(&eb) || new_event(&ec)) { rc = 1; break; }
         (void) hipEventRecord(ea, c->stream);
@@ -181,14 +206,21 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
                 // the job's selected reads as a list (index_part.hpp, sel_ids_kernel); the chunks of every job are built on the one
                 // stream, one after the other, so the list buffer of the context serves job after job
                 if (upload_bits(c, rs->d_sel, job.plan.indexed_bits.data(), rs->n_reads)) { rc = 1; break; }
+            }
+            if (!job.plan.dense && rs->uniform_len != 0) {      // (ragged sets: the bucketed build lists the chunk's items itself, from the bitmap)
                 const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
                 if (c->ids_cap < job.plan.indexed_reads || c->idblk_cap < nb + 1) {
                     HIP_OK(hipStreamSynchronize(c->stream));
                     (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
                     c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
                     const uint64_t cap = std::max<uint64_t>(job.plan.indexed_reads, rs->n_reads / 2);
-                    HIP_OK(dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true));
-                    HIP_OK(dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true));
+                    if (dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true) != hipSuccess ||
+                        dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true) != hipSuccess) {
+                        (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
+                        c->d_ids = c->d_idblk = nullptr;
+                        (void) hipStreamSynchronize(c->stream);      // (chunks of earlier jobs of the pass may be under way)
+                        return no_room();
+                    }
                     c->ids_cap = cap, c->idblk_cap = nb + 1;
                 }
                 KScope ks(c, "sel_ids_kernels", c->stream);

@@ -25,7 +25,7 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     hipError_t e = dev_alloc(c, (void **) &rs->d_planes, triples * 3 * sizeof(uint32_t), false);
     if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_goff, (max_reads + 1) * sizeof(uint64_t), false);
     if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_kcnt, (max_reads + 1) * sizeof(uint32_t), false);
-    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_lenmm, 3 * sizeof(uint32_t), false);
+    if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_lenmm, 8 * sizeof(uint32_t), false)   /* [0..2] shortest / longest read, largest k-mer count; [4..5] one 64-bit sum (finalize) */;
     if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_sel, bw * 8, false);
     if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_tags, bw * 8, false);
     if (e == hipSuccess) e = dev_alloc(c, (void **) &rs->d_found, bw * 8, false);
@@ -404,6 +404,25 @@ int commet_readset_finalize(commet_readset *rs)
         HIP_OK(hipMemcpy(mm, rs->d_lenmm, sizeof mm, hipMemcpyDeviceToHost));
     }
     rs->max_kcnt = rs->n_reads ? mm[2] : 0;
+    // first-hit windows of the set for this context's (k, t) — the records its query list can hold at most (tile_search.hpp): n x
+    // (len - t k + 1) for reads of one length; summed over the reads on the device otherwise (sizing the list of a ragged set by its
+    // LONGEST read kept 50-150 bp sets out of the tiled search: 7 GB estimated for a 2.3 GB list)
+    {
+        const int64_t tk = (int64_t) std::min<uint64_t>((uint64_t) c->t, (uint64_t) rs->max_len / (uint64_t) c->k + 1) * c->k;   // (t_eff, search_dispatch.hpp)
+        if (!rs->n_reads) rs->fhw_total = 0;
+        else if (rs->uniform_len) rs->fhw_total = rs->n_reads * (uint64_t) std::max<int64_t>(0, (int64_t) rs->uniform_len - tk + 1);
+        else {
+            unsigned long long *d_sum = (unsigned long long *) (rs->d_lenmm + 4);
+            HIP_OK(hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), c->load_stream));
+            COMMET_LAUNCH(first_hit_windows_kernel, dim3((unsigned) std::min<uint64_t>((rs->n_reads + 255) / 256, 1u << 16)), dim3(256), 0, c->load_stream,
+                          rs->view(), (uint32_t) std::min<int64_t>(tk, 0x7FFFFFFF), d_sum);
+            HIP_OK(hipGetLastError());
+            unsigned long long h_sum = 0;
+            HIP_OK(hipMemcpyAsync(&h_sum, d_sum, sizeof h_sum, hipMemcpyDeviceToHost, c->load_stream));
+            HIP_OK(hipStreamSynchronize(c->load_stream));
+            rs->fhw_total = h_sum;
+        }
+    }
     std::sort(rs->empty_reads.begin(), rs->empty_reads.end());
     // the staging buffers are no longer needed: give the memory back
     for (int i = 0; i < 2; ++i) {

@@ -224,11 +224,12 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
     if (rs->n_reads >= (1ull << 32)) return false;
-    if (rs->n_reads * (uint64_t) first_hit_windows >= (1ull << 32)) return false;   // record numbers are 32 bits (forced mode, too)
+    // (rs->fhw_total: the set's first-hit windows summed over its reads — n x first_hit_windows for reads of one length, less for ragged sets)
+    if (rs->fhw_total >= (1ull << 32)) return false;   // record numbers are 32 bits (forced mode, too)
     if (c->tiled_mode == 2) return true;
     // auto: sets of a million reads or more whose query list (8 bytes per first-hit window) stays under 4 GiB.  Measured
     // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
-    const uint64_t est = rs->n_reads * (uint64_t) first_hit_windows * 8;
+    const uint64_t est = rs->fhw_total * 8;
     // (a list above the cap when its memory was set aside beforehand, commet_readset_reserve_cache: the allocation is then not on this job's path)
     if (rs->n_reads < (1ull << 20) || (est > c->ql_max_list && !rs->ql_reserved.load())) return false;
     // A list of more than 4 GiB (sets of 15 M reads and up) is built for a set's SECOND such scan: a set that is scanned once —
@@ -378,7 +379,7 @@ bool query_list_blocks(const commet_ctx *c, const commet_readset *rs, uint64_t o
     const int t = t_eff(c, rs);
     const int64_t fhw = (int64_t) rs->max_len - (int64_t) t * c->k + 1;
     if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || fhw < 1 || fhw > TQ_MAX_WIN || rs->n_reads < (1ull << 20) || rs->n_reads >= (1ull << 32)) return false;
-    const uint64_t records = rs->n_reads * (uint64_t) fhw;
+    const uint64_t records = rs->fhw_total;                   // (an upper bound: windows with a non-ACGT base make no record)
     if (records >= (1ull << 32)) return false;
     int sbits = TQ_SBITS;
     if (c->tq_sbits) sbits = std::max(c->k - 10, std::min(c->k - 1, c->tq_sbits));

@@ -69,6 +69,13 @@ struct DevMemCache {
     hipStream_t pool_stream[16] = {nullptr};                       // the stream the stream-ordered allocations are ordered on (always drained before use)
     int on = -1, pool_on = -1;
     size_t pool_min = 0;                                           // COMMET_DEVMEM_POOL_MIN_MB (tests: a set of a few MB in pooled blocks); never below 8 MiB
+    // what the DRIVER was asked for, per device (commet_device_alloc_stats): time the calling thread spent inside hipMalloc /
+    // hipMallocAsync, bytes and calls — a box that charges for a process's first use of device memory shows here, not in kernel time
+    std::atomic<uint64_t> drv_ns[16], drv_bytes[16], drv_calls[16];
+    DevMemCache()
+    {
+        for (int d = 0; d < 16; ++d) drv_ns[d] = 0, drv_bytes[d] = 0, drv_calls[d] = 0;
+    }
     bool enabled()
     {
         if (on < 0) {
@@ -92,7 +99,19 @@ DevMemCache g_devmem;
 constexpr size_t DEVMEM_MIN_FILED = (size_t) 8 << 20;
 
 // one block from the driver: stream-ordered from 256 MiB on unless an IPC handle will be asked for it
+hipError_t dm_driver_alloc_untimed(void **p, size_t bytes, int dev, bool shareable, bool *pooled);
 hipError_t dm_driver_alloc(void **p, size_t bytes, int dev, bool shareable, bool *pooled)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = dm_driver_alloc_untimed(p, bytes, dev, shareable, pooled);
+    if (dev >= 0 && dev < 16) {
+        g_devmem.drv_ns[dev] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        g_devmem.drv_calls[dev] += 1;
+        if (e == hipSuccess) g_devmem.drv_bytes[dev] += bytes;
+    }
+    return e;
+}
+hipError_t dm_driver_alloc_untimed(void **p, size_t bytes, int dev, bool shareable, bool *pooled)
 {
     *pooled = false;
     if (!shareable && g_devmem.pooling() && bytes >= g_devmem.pool_min) {
@@ -179,9 +198,16 @@ size_t dm_pooled_bytes(int device)
 hipError_t dm_malloc(void **p, size_t bytes, bool shareable = false)
 {
     *p = nullptr;
-    if (!g_devmem.enabled()) return hipMalloc(p, bytes);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipMalloc(p, bytes);
+    if (!g_devmem.enabled()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipMalloc(p, bytes);
+        g_devmem.drv_ns[dev] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        g_devmem.drv_calls[dev] += 1;
+        if (e == hipSuccess) g_devmem.drv_bytes[dev] += bytes;
+        return e;
+    }
     if (bytes >= DEVMEM_MIN_FILED) {
         std::lock_guard<std::mutex> lk(g_devmem.mu);
         for (auto it = g_devmem.filed[dev].lower_bound(bytes); it != g_devmem.filed[dev].end() && it->first <= bytes + bytes / 4; ++it) {
@@ -237,9 +263,12 @@ hipError_t dm_free(void *p)
             if (it != g_devmem.live.end()) what = it->second, g_devmem.live.erase(it);
         }
         if (what.device >= 0) {
+            const int d = what.device;
+            int cur = d;
+            const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+            if (have_cur && cur != d) (void) hipSetDevice(d);      // (the block's device, whatever device the calling thread is on)
             (void) hipDeviceSynchronize();                         // what hipFree does: no kernel still reads the block when somebody else gets it
             std::vector<std::pair<void *, bool>> over;             // kept within the cap (other processes may share the device): largest first
-            const int d = what.device;
             {
                 std::lock_guard<std::mutex> lk(g_devmem.mu);
                 g_devmem.filed[d].emplace(what.bytes, std::make_pair(p, what.pooled));
@@ -258,6 +287,7 @@ hipError_t dm_free(void *p)
                 }
             }
             for (auto &q : over) dm_driver_free(q.first, d, q.second);
+            if (have_cur && cur != d) (void) hipSetDevice(cur);
             return hipSuccess;
         }
     }
@@ -342,6 +372,7 @@ struct commet_ctx {
     int part_b1 = 0;                  // override of the level-1 radix bits (0 = default split)
     int part_packed = 1;              // option: final buckets as groups of three 19-bit keys in 8 bytes (index_part.hpp)
     int part_no_uni = 0;              // option: never take the uniform-length fast path of hist / scatter1 (tests, A/B timing)
+    int part_list = 0;                // option: 0 = ragged sets take the item list in hist / scatter1 (index_part.hpp, LIST), 1 = never (the round planner)
     int s2_swizzle = 128;             // scatter2 slab order: number of interleaved slab ranges (index_part.hpp), 0 = dispatch order
     uint64_t part_min_kmers = 8ull << 20;
     // workspaces of the bucketed construction (index_part.hpp): two, so that the chunks of a group can be built on two
@@ -353,11 +384,13 @@ struct commet_ctx {
         uint64_t *off = nullptr, *goff = nullptr;   // bucket offsets in keys / in 8-byte groups (packed final level)
         unsigned long long *cur2 = nullptr, *blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
         uint32_t *blockcnt = nullptr;                              // keys per [scatter1 workgroup][coarse bucket]
+        uint32_t *items = nullptr, *itemblk = nullptr;             // ragged sets: the chunk's item list and the builder's block sums (index_part.hpp, LIST)
+        uint64_t items_cap = 0, itemblk_cap = 0;
         uint32_t nb = 0;
         void release()
         {
             (void) dm_free(bufA); (void) dm_free(bufB); (void) dm_free(hist); (void) dm_free(wl); (void) dm_free(off); (void) dm_free(goff);
-            (void) dm_free(cur2); (void) dm_free(blockoff); (void) dm_free(blockcnt);
+            (void) dm_free(cur2); (void) dm_free(blockoff); (void) dm_free(blockcnt); (void) dm_free(items); (void) dm_free(itemblk);
             *this = PartWs();
         }
     } part[2];
@@ -513,6 +546,7 @@ struct commet_readset {
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
     uint32_t max_len = 0, min_len = 0;
+    uint64_t fhw_total = 0;                    // first-hit windows of all reads for the context's (k, t): sum of max(0, len - t k + 1) (finalize)
     // query list of the tiled search (tile_search.hpp): the set's lane-a addresses sorted by address slice, made on first use
     struct QueryList {
         unsigned long long *d_tile_off = nullptr;

@@ -469,6 +469,68 @@ __global__ __launch_bounds__(64) void sel_ids_kernel(const uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Item list of a chunk of RAGGED reads (round 6).  Real inputs are trimmed reads of many lengths (fastq_file.h:139-190): item i of a
+// piece is then no arithmetic function of i, and the round planner (plan_round: per round two block scans, three barriers, the
+// counts, the selection and two offsets of every read it looks at fetched on the spot, the item's words fetched behind them) made
+// hist and scatter1 twice as expensive per read as on fixed-length sets.  Instead the chunk's items are written out once, one word
+// each, in read order:
+//     item = (triple << 4) | (octet in the word << 2) | min(word index in the read, 3)
+// triple = the item's word triple counted from the chunk's first read (< 2^28: the host checks), and hist / scatter1 walk that list
+// exactly as they walk a fixed-length set (LIST mode below): item i of a piece is items[i0 + i], the descriptor of the round after
+// the coming one fetched a round ahead.  Reads without a complete k-mer (and reads a selection bitmap leaves out) have no items.
+// What a k-mer may span is decided by the validity plane alone in this mode: bits past a read's end are zero in every packer
+// (pack_reads_kernel, host/ingest_pack.hpp), and triples before the read's first are replaced by zeros through the word index.
+// Two launches around a scan of the block sums: count, (sel_scan_kernel), fill.
+// ---------------------------------------------------------------------------
+constexpr uint32_t ITEMS_BLOCK = 1024;                   // reads per workgroup of the builder
+constexpr uint32_t ITEM_MAX_TRIPLES = 1u << 28;
+template <bool FILL>
+__global__ __launch_bounds__(ITEMS_BLOCK) void part_items_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt, const uint64_t *__restrict__ sel,
+                                                                 uint64_t first, uint64_t count, int k, uint32_t *__restrict__ blk,
+                                                                 uint32_t *__restrict__ items)
+{
+    __shared__ uint32_t wsum[ITEMS_BLOCK / 64];
+    const uint64_t i = (uint64_t) blockIdx.x * ITEMS_BLOCK + threadIdx.x, r = first + i;
+    uint32_t n = 0, len = 0;
+    uint64_t t0 = 0;
+    if (i < count) {
+        const bool on = !sel || ((sel[r >> 6] >> (r & 63)) & 1ull);
+        if (on && kcnt[r]) {
+            read_extent(rv, r, t0, len);
+            n = octets_of(len, k);
+        }
+    }
+    uint32_t tot;
+    const uint32_t ex = block_scan<ITEMS_BLOCK>(n, wsum, &tot);
+    if (!FILL) {
+        if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+        return;
+    }
+    if (!n) return;
+    uint64_t tb;
+    uint32_t l0;
+    read_extent(rv, first, tb, l0);
+    const uint32_t trel = (uint32_t) (t0 - tb), q_first = (uint32_t) (k - 1) >> 3;
+    uint32_t at = blk[blockIdx.x] + ex;
+    for (uint32_t q = q_first; q < q_first + n; ++q) items[at++] = ((trel + (q >> 2)) << 4) | ((q & 3u) << 2) | min(q >> 2, 3u);
+}
+
+// an item of the list -> what the key loops take: p = the read's first triple as far as they may look back (at most three words),
+// q = the octet's number from there; the read's length is not known here (0xFFFFFFFF: the validity plane decides)
+struct ListItem {
+    const uint32_t *p;
+    uint32_t q;
+};
+__device__ __forceinline__ ListItem list_item(const uint32_t *chunk_planes, uint32_t d)
+{
+    const uint32_t wc = d & 3u;
+    ListItem it;
+    it.p = chunk_planes + 3ull * ((uint64_t) (d >> 4) - wc);
+    it.q = 4u * wc + ((d >> 2) & 3u);
+    return it;
+}
+
+// ---------------------------------------------------------------------------
 // hist: bucket histogram of the chunk, buckets [b_lo, b_lo + n_b) in LDS
 // ---------------------------------------------------------------------------
 // UNI: every read has rv.uniform_len bases and no selection bitmap applies.  Item i of a block's read range is then
@@ -479,15 +541,19 @@ __global__ __launch_bounds__(64) void sel_ids_kernel(const uint64_t *__restrict_
 // coarse-bucket counts in blockcnt[j * nb1 + c]: scatter1 then knows where each of its runs goes without reserving
 // space with global atomics (their round trip used to sit in every round).
 // FULL: the LDS histogram covers every bucket (b_lo == 0, n_b == nb; always the case for k <= 32): no range test.
-template <typename W, bool UNI, bool FULL>
+// MODE: 0 = rounds planned over the reads (any set, any selection), 1 = UNI, 2 = LIST: the chunk's item list (part_items_kernel;
+// items[0 .. *n_items)), cut into n_blk1 pieces of equal ITEM counts
+template <typename W, int MODE, bool FULL>
 __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                             const uint64_t *__restrict__ sel, uint64_t first,
                                                             uint64_t count, PartGeom g, uint32_t b_lo, uint32_t n_b,
                                                             uint32_t *__restrict__ hist, uint32_t n_blk1,
-                                                            uint32_t *__restrict__ blockcnt, const uint32_t *__restrict__ ids)
+                                                            uint32_t *__restrict__ blockcnt, const uint32_t *__restrict__ ids,
+                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ n_items)
 {
     // UNI with ids != nullptr: [first, first + count) are POSITIONS in the list of selected reads (sel_ids_kernel)
     constexpr int NT = HIST_NT;
+    constexpr bool UNI = MODE == 1, LIST = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *h = smem;                            // n_b counters
     uint32_t *istart = h + n_b;                    // NT + 4
@@ -497,7 +563,15 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
     uint64_t *rd_t0 = (uint64_t *) (sh_n + 4);     // NT
     for (uint32_t i = threadIdx.x; i < n_b; i += NT) h[i] = 0;
     __syncthreads();
-    const uint64_t per1 = (count + n_blk1 - 1) / n_blk1;
+    const uint64_t l_total = LIST ? (uint64_t) *n_items : 0;
+    const uint64_t per1 = ((LIST ? l_total : count) + n_blk1 - 1) / n_blk1;
+    const uint32_t *l_planes = rv.planes;                 // LIST: the chunk's first triple
+    if (LIST) {
+        uint64_t tb;
+        uint32_t l0;
+        read_extent(rv, first, tb, l0);
+        l_planes += 3 * tb;
+    }
     const uint32_t nsub = 1u << g.b2, c_lo = b_lo >> g.b2, n_c = n_b >> g.b2;   // coarse buckets of this pass
     uint32_t prev = 0;   // thread c < n_c: keys of coarse bucket c_lo + c counted before this half
     uint32_t planes = 0;  // planes with buckets in [b_lo, b_lo + n_b)
@@ -525,7 +599,19 @@ __global__ __launch_bounds__(HIST_NT) void part_hist_kernel(ReadsView rv, const 
         if (j >= n_blk1) break;   // uniform
         uint64_t r = min(first + count, first + j * per1);
         const uint64_t r_end = min(first + count, r + per1);
-        if (UNI) {
+        if (LIST) {
+            const uint64_t i0 = min(l_total, j * per1), i1 = min(l_total, i0 + per1);
+            uint64_t id = i0 + threadIdx.x;
+            uint32_t d = id < i1 ? items[id] : 0u;
+            for (; id < i1; id += NT) {
+                const uint32_t dn = id + NT < i1 ? items[id + NT] : 0u;      // (the next item's descriptor travels while this one's keys are counted)
+                const ListItem li = list_item(l_planes, d);
+                if constexpr (ROLL) for_each_bucket32(li.p, 0xFFFFFFFFu, li.q, g.k, add_bucket);
+                else if constexpr (ROLL64) for_each_bucket64(li.p, 0xFFFFFFFFu, li.q, g.k, planes, add_bucket_rel);
+                else for_each_key<W, true>(li.p, 0xFFFFFFFFu, li.q, g.k, add, planes);
+                d = dn;
+            }
+        } else if (UNI) {
             const uint32_t L = rv.uniform_len;
             const uint32_t opr = max(octets_of(L, g.k), 1u), q_first = (uint32_t) (g.k - 1) >> 3;
             const uint64_t total = (r < r_end && L >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
@@ -696,15 +782,18 @@ __global__ __launch_bounds__(512) void part_blockoff_kernel(const uint32_t *__re
 // ---------------------------------------------------------------------------
 // UNI (see part_hist_kernel): items come from arithmetic instead of plan_round, and the read words of the NEXT round's
 // item are loaded right after this round's keys are made, so their latency hides behind the sort and the write-out.
-template <typename W, bool UNI>
+// MODE as in part_hist_kernel; UNI below = "items come without planning" (modes 1 and 2), LIST = mode 2
+template <typename W, int MODE>
 __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, const uint32_t *__restrict__ kcnt,
                                                               const uint64_t *__restrict__ sel, uint64_t first,
                                                               uint64_t count, PartGeom g,
                                                               const unsigned long long *__restrict__ blockoff,
-                                                              uint32_t *__restrict__ out, const uint32_t *__restrict__ ids)
+                                                              uint32_t *__restrict__ out, const uint32_t *__restrict__ ids,
+                                                              const uint32_t *__restrict__ items, const uint32_t *__restrict__ n_items)
 {
-    // UNI with ids != nullptr: [first, first + count) are POSITIONS in the list of selected reads (sel_ids_kernel)
+    // mode 1 with ids != nullptr: [first, first + count) are POSITIONS in the list of selected reads (sel_ids_kernel)
     constexpr int NT = S1_NT;
+    constexpr bool UNI = MODE != 0, LIST = MODE == 2;
     constexpr bool WIDE = sizeof(W) == 8;          // 33 <= k <= 34: keys of 33 / 34 bits
     constexpr uint32_t NTR = WIDE ? 3u : 2u;       // word triples a k-mer window can span
     using T = KeyTraits<W>;
@@ -730,11 +819,23 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
     const uint32_t sA = TILE_BITS + g.b2, nbp = g.nb1 >> 2, pay_mask = (1u << sA) - 1u;
     // UNI: this thread's item of the coming round = octet u_q + q_first of read u_rd
     const uint32_t q_first = (uint32_t) (g.k - 1) >> 3;
-    const uint32_t opr = UNI ? max(octets_of(rv.uniform_len, g.k), 1u) : 1u;
-    const uint64_t u_total = (UNI && r < r_end && rv.uniform_len >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
+    const uint32_t opr = (UNI && !LIST) ? max(octets_of(rv.uniform_len, g.k), 1u) : 1u;
+    // LIST: this workgroup's piece of the chunk's item list = items[l_i0 .. l_i0 + u_total)
+    const uint64_t l_all = LIST ? (uint64_t) *n_items : 0, l_per = (l_all + gridDim.x - 1) / gridDim.x;
+    const uint64_t l_i0 = min(l_all, (uint64_t) blockIdx.x * l_per);
+    const uint32_t *l_planes = rv.planes;                 // LIST: the chunk's first triple
+    if (LIST) {
+        uint64_t tb;
+        uint32_t l0;
+        read_extent(rv, first, tb, l0);
+        l_planes += 3 * tb;
+    }
+    const uint64_t u_total = LIST ? min(l_all, l_i0 + l_per) - l_i0
+                                  : (UNI && r < r_end && rv.uniform_len >= (uint32_t) g.k) ? (r_end - r) * opr : 0;
     const uint32_t u_dpos = NT / opr, u_dq = NT % opr;
     uint64_t u_done = 0, u_rd = r + threadIdx.x / opr;
     uint32_t u_q = threadIdx.x % opr;
+    uint32_t l_cur = 0, l_next = 0;                       // LIST: descriptors of this thread's item of the coming round / of the round after
     auto uni_ptr = [&](uint64_t rd) { return rv.planes + 3 * (((rd * rv.uniform_len) >> 5) + rd); };
     // prefetched word triples w-NTR+1 .. w of the coming item, RAW: no branch and no use between the loads and the
     // claim below, so that they really stay in flight (a triple before the read's first is read as triple 0 and
@@ -768,7 +869,13 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         if (q >= opr) q -= opr, ++rd;
     };
     uint64_t nid = 0;                                    // read number of the item of the round after the coming one
-    if (UNI && u_total) {
+    if (LIST && u_total) {
+        l_cur = threadIdx.x < u_total ? items[l_i0 + threadIdx.x] : 0u;          // (no item: the chunk's first triple, never used)
+        const ListItem li = list_item(l_planes, l_cur);
+        pre_load(li.p, li.q >> 2);
+        pre_claim();
+        l_next = (uint64_t) NT + threadIdx.x < u_total ? items[l_i0 + NT + threadIdx.x] : 0u;
+    } else if (UNI && u_total) {
         const bool in = threadIdx.x < u_total;
         pre_load(uni_ptr(read_no(in ? u_rd : r)), in ? (u_q + q_first) >> 2 : 0u);
         pre_claim();
@@ -789,7 +896,10 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
         bool ion;
         uint32_t iq = 0, ilen = 0;
         const uint32_t *ip = rv.planes;
-        if (UNI) {
+        if (LIST) {
+            ion = u_done + threadIdx.x < u_total;
+            iq = 4u * (l_cur & 3u) + ((l_cur >> 2) & 3u), ilen = 0xFFFFFFFFu;      // (list_item's q: the validity plane knows the read's end)
+        } else if (UNI) {
             ion = u_done + threadIdx.x < u_total;
             iq = u_q + q_first, ilen = rv.uniform_len;
         } else {
@@ -840,7 +950,13 @@ __global__ __launch_bounds__(S1_NT, 4) void part_scatter1_kernel(ReadsView rv, c
                 }
             }
         }
-        if (UNI) {   // next round's item; its words travel while this round is sorted and written
+        if (LIST) {  // next round's item: its words travel while this round is sorted and written, the descriptor of the round after it too
+            u_done += NT;
+            const ListItem li = list_item(l_planes, l_next);
+            pre_load(li.p, li.q >> 2);
+            l_cur = l_next;
+            l_next = u_done + NT + threadIdx.x < u_total ? items[l_i0 + u_done + NT + threadIdx.x] : 0u;
+        } else if (UNI) {   // next round's item; its words travel while this round is sorted and written
             u_done += NT;
             advance(u_rd, u_q);
             const bool in = u_done + threadIdx.x < u_total;

@@ -366,6 +366,22 @@ __global__ __launch_bounds__(256) void kmer_counts_kernel(ReadsView rv, int k, u
     atomicMax(&len_minmax[2], cnt);
 }
 
+// *sum += over the reads of max(0, len - tk + 1): the first-hit windows of a ragged set (tk = t * k), an upper bound on the records of
+// its query list (tile_search.hpp; windows that hold a non-ACGT base make no record)
+__global__ __launch_bounds__(256) void first_hit_windows_kernel(ReadsView rv, uint32_t tk, unsigned long long *__restrict__ sum)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long s = 0;
+    for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < rv.n; r += (uint64_t) gridDim.x * 256ull) {
+        const uint64_t len = rv.goff[r + 1] - rv.goff[r];
+        if (len >= tk) s += len - tk + 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+
 // sums[b] = k-mers of the selected reads (bitmap sel, 64 reads per word) among reads [b * 4096, (b + 1) * 4096):
 // what the host's selection planner walks instead of the reads (read_iter.hpp, plan_index_blocks)
 constexpr uint32_t PLAN_BLOCK_READS = 4096;

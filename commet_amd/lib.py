@@ -68,6 +68,7 @@ SIGNATURES = {
     "commet_device_cache_trim": (C.c_uint64, [C.c_int]),
     "commet_device_cache_bytes": (C.c_uint64, [C.c_int]),
     "commet_device_pooled_bytes": (C.c_uint64, [C.c_int]),
+    "commet_device_alloc_stats": (C.c_int, [C.c_int, C.POINTER(C.c_double), u64p, u64p]),
     "commet_filter_reset": (C.c_int, [C.c_void_p]),
     "commet_index_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, u64p]),
     "commet_search_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64p, u64p]),

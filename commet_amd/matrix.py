@@ -167,6 +167,7 @@ class HipEngine:
 
     def __init__(self, k, t, local_rank):
         import commet_amd
+        self._alloc0 = commet_amd.device_alloc_stats(-1)          # (before the context: its filter and workspaces count as this run's)
         # LOCAL_RANK modulo the devices this process sees (a launcher may give every rank one visible device);
         # COMMET_FORCE_DEVICE: debugging aid to run several ranks on one GPU (never set by the driver)
         self._api = commet_amd
@@ -239,6 +240,13 @@ class HipEngine:
 
     def device_total(self):
         return self.ctx.device_memory()[1]
+
+    def alloc_stats(self):
+        """what this run has asked the DRIVER for so far (commet_device_alloc_stats; blocks reused from the library's own cache do
+        not count): host ms inside hipMalloc, bytes, calls — a box that charges a process for its first use of device memory
+        (15-30 ms per GiB on some of the pool's) shows here, between the kernels, not in any kernel's time"""
+        now = self._api.device_alloc_stats(-1)
+        return {f: now[f] - self._alloc0[f] for f in now}
 
     def kernel_times(self):
         """COMMET_MATRIX_KERNEL_TIMES=1: {kernel: [launches, ms]} of this rank's jobs (a hipEvent pair around every launch; the chunks
@@ -844,6 +852,9 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         jobs_s = time.perf_counter() - t_jobs - set_wait[0]      # (pipelined: without the waits for sets still being loaded)
         prof["jobs_s"] = jobs_s
         prof["set_wait_s"] = set_wait[0]
+        if hasattr(eng, "alloc_stats"):
+            a_ = eng.alloc_stats()
+            prof["alloc_wait_ms"], prof["fresh_device_bytes"], prof["alloc_calls"] = round(a_["wait_ms"], 1), a_["fresh_bytes"], a_["calls"]
         if hasattr(eng, "kernel_times") and eng.kernel_times() is not None:
             prof["kernel_ms"] = eng.kernel_times()
         if loader is not None:

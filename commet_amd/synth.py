@@ -135,3 +135,88 @@ def write_set_fasta(args):
     b, _ = synth_set(s, n, L)
     write_fasta_fast(path, b, n, L)
     return s
+
+
+# ---- ragged sets: trimmed reads of many lengths (what a .fq.gz run really holds, fastq_file.h:139-190) ---------------------
+
+def ragged_lengths(set_id, n_reads, lo, hi, seed_base=1000, copy_frac=0.25, base_set=0):
+    """Read lengths of ragged set `set_id`: uniform in [lo, hi], seeded per set; the copied reads (the first `copy_frac`
+    of a set other than `base_set`) have the lengths of the reads they copy."""
+    lens = np.random.default_rng(seed_base + 5_000_000 + set_id).integers(lo, hi + 1, size=n_reads, dtype=np.int64)
+    if set_id != base_set and copy_frac > 0:
+        ncopy = int(n_reads * copy_frac)
+        if ncopy:
+            lens[:ncopy] = np.random.default_rng(seed_base + 5_000_000 + base_set).integers(lo, hi + 1, size=n_reads, dtype=np.int64)[:ncopy]
+    return lens
+
+
+def synth_set_ragged(set_id, n_reads, lo, hi, seed_base=1000, copy_frac=0.25, sub_rate=0.01, rc_every=20, n_rate=0.001,
+                     base_set=0):
+    """synth_set with read lengths uniform in [lo, hi] — the same copy / substitution / reverse-complement / N rules.
+    Returns (bases uint8[total] ASCII, offsets uint64[n+1])."""
+    lens = ragged_lengths(set_id, n_reads, lo, hi, seed_base, copy_frac, base_set)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:].view(np.int64))
+    total = int(offsets[-1])
+    rng, raw = _raw(seed_base + set_id, total)
+    codes = np.frombuffer(raw, dtype=np.uint8)
+    if set_id != base_set and copy_frac > 0:
+        ncopy = int(n_reads * copy_frac)
+        if ncopy:
+            nb = int(offsets[ncopy])                      # the base set's first ncopy reads have the same lengths: the same bytes
+            _, raw0 = _raw(seed_base + base_set, nb)
+            flat = np.frombuffer(raw0, dtype=np.uint8)
+            nsub = int(rng.binomial(nb, sub_rate))
+            pos = rng.integers(0, nb, size=nsub)
+            delta = rng.integers(1, 4, size=nsub).astype(np.uint8)
+            flat[pos] = (flat[pos] + delta) & 3
+            if rc_every:
+                for i in range(0, ncopy, rc_every):
+                    a, b = int(offsets[i]), int(offsets[i + 1])
+                    flat[a:b] = 3 - (flat[a:b][::-1] & 3)
+            codes[:nb] = flat
+            del flat, raw0
+    lut = np.frombuffer(_FOLD, dtype=np.uint8)
+    for i in range(0, total, 1 << 26):
+        codes[i:i + (1 << 26)] = lut[codes[i:i + (1 << 26)]]
+    nn = int(rng.binomial(total, n_rate)) if n_rate > 0 else 0
+    if nn:
+        codes[rng.integers(0, total, size=nn)] = ord("N")
+    return codes, offsets
+
+
+def write_fasta_ragged(path, bases, offsets, digits=9):
+    """Vectorised writer for ragged sets: header '>%0<digits>d', one sequence line per read."""
+    n = len(offsets) - 1
+    offs = np.asarray(offsets, dtype=np.int64)
+    src = np.asarray(bases, dtype=np.uint8)
+    hdr = 1 + digits + 1                                   # '>' + digits + '\n'
+    block = 1 << 18
+    with open(path, "wb") as fh:
+        for r0 in range(0, n, block):
+            m = min(block, n - r0)
+            o = offs[r0:r0 + m + 1] - offs[r0]
+            lens = np.diff(o)
+            rec0 = o[:-1] + np.arange(m, dtype=np.int64) * (hdr + 1)      # start of record i in the block's image
+            out = np.empty(int(o[-1]) + m * (hdr + 1), dtype=np.uint8)
+            out[rec0] = ord(">")
+            idx = np.arange(r0, r0 + m, dtype=np.int64)
+            for d in range(digits):
+                out[rec0 + (digits - d)] = (idx % 10 + ord("0")).astype(np.uint8)
+                idx //= 10
+            out[rec0 + digits + 1] = ord("\n")
+            out[rec0 + hdr + lens] = ord("\n")
+            # the sequence bytes fill, in order, every place that is not part of a header or a line end
+            seq = np.ones(out.size, dtype=bool)
+            seq[(rec0[:, None] + np.arange(hdr, dtype=np.int64)[None, :]).reshape(-1)] = False
+            seq[rec0 + hdr + lens] = False
+            out[seq] = src[int(offs[r0]):int(offs[r0 + m])]
+            fh.write(out.data)
+
+
+def write_set_fasta_ragged(args):
+    """(set id, reads, lo, hi, path): one ragged synthetic set as FASTA (top-level: a spawn pool runs it)"""
+    s, n, lo, hi, path = args
+    b, o = synth_set_ragged(s, n, lo, hi)
+    write_fasta_ragged(path, b, o)
+    return s

@@ -154,6 +154,12 @@ uint64_t        commet_device_cache_bytes(int device);
  * device-to-device copy), and a caller that shares library memory by other means checks here.
  * commet_device_pooled_bytes(device): bytes of such blocks in use now. */
 uint64_t        commet_device_pooled_bytes(int device);
+/* What the library asked the DRIVER for on `device` (-1: every device) since the process started: host time its threads spent
+ * inside hipMalloc / hipMallocAsync (ms), the bytes they returned and the number of calls — blocks taken from the library's own
+ * cache do not count.  A box that charges a process for its first use of device memory (15-30 ms per GiB) shows
+ * HERE and not in any kernel's time; the N x N driver reports the difference over a matrix leg as alloc_wait_ms / fresh_device_bytes.
+ * Nothing in the reference corresponds to it. */
+int             commet_device_alloc_stats(int device, double *wait_ms, uint64_t *fresh_bytes, uint64_t *calls);
 
 /* ---- the two kernels ------------------------------------------------------ */
 /* Replaces `new BloomFilter` per chunk (index_and_search.cpp:256-262,
@@ -222,7 +228,7 @@ int commet_index_and_search(commet_ctx *ctx,
  * "S_ref in (S_i restricted to J1's result)") and its J3 jobs of a target (Commet.py:233) — in one call: job j indexes index_rs[j]
  * (restricted to index_select[j], may be NULL) and searches search_rs (search_select as above); tags_out[j], stats[j] are what
  * commet_index_and_search(index_rs[j], ..., 1, &search_rs, ...) gives for job j alone, bit for bit.  Where the jobs allow it
- * (fixed-length index sets whose chunks, at most eight per job, take the bucketed construction; a search set that is visited
+ * (index sets whose chunks, at most eight per job, take the bucketed construction; a search set that is visited
  * whole) the chunk filters of several jobs share a pass over the search set: the lane-a gathers of its reads, two thirds of a
  * job's memory requests, are then made once per pass instead of once per job.  Otherwise (and with option "multi_job" = 1) the
  * jobs run one after the other.  info (may be NULL) sums over the jobs. */
@@ -264,7 +270,9 @@ int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_reads
  *                        lane of a wave has a read: 0 = when the host plan visits less than half of the set's reads, 1 = never,
  *                        2 = whenever a selection applies (tests)
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
- *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1
+ *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1 (nor the item list of ragged sets)
+ *   part_list (0/1)      ragged sets (reads of several lengths): 0 = hist / scatter1 walk the chunk's item list (written out once per
+ *                        chunk; the words of the coming round's items prefetched as on fixed-length sets), 1 = the round planner
  *   part_b1, s2_swizzle  radix split / scatter2 slab order of the bucketed construction
  *   kernel_timing (0/1)  time every kernel launch of commet_index_and_search (commet_kernel_times)
  *   max_kmer             TEST HOOK: k-mers per index chunk instead of the reference's constant (0 = reference; the

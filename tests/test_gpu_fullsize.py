@@ -67,6 +67,20 @@ def _cpu_checker_on_sample(k, t, b0, o0, L, chunks, kc, sb):
     return util.bools_from_bits(found, ns)
 
 
+def _cpu_checker_on_ragged_sample(k, t, b0, o0, chunks, kc, sb, so):
+    """_cpu_checker_on_sample for sets of many read lengths: (sb, so) = the sampled search reads as a batch"""
+    ns = len(so) - 1
+    found = np.zeros(ns // 8 + 1, dtype=np.uint8)
+    for (a, e) in chunks:
+        f = ob.Bloom(k)
+        fed = f.index(b0[int(o0[a]): int(o0[e])], o0[a: e + 1] - o0[a])
+        assert fed == int(kc[a:e].sum())
+        fnd, _ = f.search(t, sb, so, ~found)
+        found |= fnd
+        f.close()
+    return util.bools_from_bits(found, ns)
+
+
 def _oracle_main_loop(d, k, t, index_fa, query_fa):
     """ok_index_and_search — the CPU checker's restatement of the tool's own main (set files, FastaFile iteration, the chunk loop
     of index_and_search.cpp:241-277) — with its chunk trace: (rc, results, chunks, k-mers, trace rows, .bv bits)"""
@@ -132,6 +146,31 @@ def cpu_runs(c2, tmp_path_factory):
     out["skew"] = dict(tags=tags[0], stats=stats[0], info=info, tags_atomic=tags_a[0], stats_atomic=stats_a[0], sample=smps,
                        replaced=replaced, chunks=_chunks_from_counts(kcs, ob.max_kmer(32)))
 
+    # (e) configs[1]'s size on RAGGED sets (round 6): read lengths uniform in 50..150 — what a trimmed .fq.gz run looks like
+    #     (fastq_file.h:139-190): the item list of hist / scatter1 (index_part.hpp, LIST), the query list sized by the set's real
+    #     first-hit windows, the replay with three mask words; and the same job with the round planner and the gather kernels
+    rb0, ro0 = synth.synth_set_ragged(0, n, 50, 150)
+    rb1, ro1 = synth.synth_set_ragged(1, n, 50, 150)
+    with commet_amd.Context(k=32, t=t) as ctx:
+        irs = commet_amd.ReadSet.from_files(ctx, [(rb0, ro0)])
+        qrs = commet_amd.ReadSet.from_files(ctx, [(rb1, ro1)])
+        kcr = irs.kmer_counts()
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_and_search(irs, [qrs])
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        cache = qrs.cache_bytes
+        ctx.set_option("part_list", 1)
+        ctx.set_option("tiled_search", 1)
+        tags_p, stats_p, _ = ctx.index_and_search(irs, [qrs])            # round planner, gather search kernels
+    smpr = _sample_of(np.random.default_rng(61), n)
+    lens1 = np.diff(ro1.astype(np.int64))
+    rso = np.zeros(len(smpr) + 1, dtype=np.uint64)
+    np.cumsum(lens1[smpr], out=rso[1:].view(np.int64))
+    rsb = np.concatenate([rb1[int(ro1[i]): int(ro1[i + 1])] for i in smpr])
+    out["ragged"] = dict(tags=tags[0], stats=stats[0], info=info, times=times, cache=cache, tags_plain=tags_p[0], stats_plain=stats_p[0],
+                         sample=smpr, chunks=_chunks_from_counts(kcr, ob.max_kmer(32)), kc=kcr, lens1=lens1)
+
     def pick(b, smp):
         return np.ascontiguousarray(b.reshape(n, L)[smp]).reshape(-1)
 
@@ -142,13 +181,15 @@ def cpu_runs(c2, tmp_path_factory):
     synth.write_fasta_fast(str(md / "s0.fa"), c2["b0"], n, L)
     synth.write_fasta_fast(str(md / "q.fa"), c2["b1"][: m_q * L], m_q, L)
 
-    with ThreadPoolExecutor(4) as pool:
+    with ThreadPoolExecutor(5) as pool:
+        fe = pool.submit(_cpu_checker_on_ragged_sample, 32, t, rb0, ro0, out["ragged"]["chunks"], kcr, rsb, rso)
         fd = pool.submit(_oracle_main_loop, str(md), 32, t, str(md / "s0.fa"), str(md / "q.fa"))
         fa = pool.submit(_cpu_checker_on_sample, 32, t, c2["b0"], c2["o0"], L, ch32, kc32, pick(c2["b1"], smp32))
         fb = pool.submit(_cpu_checker_on_sample, 33, t, c2["b0"], c2["o0"], L, out["k33"]["chunks"], kc33, pick(c2["b1"], smp33))
         fc = pool.submit(_cpu_checker_on_sample, 32, t, sb0, so0, L, out["skew"]["chunks"], kcs, pick(sb1, smps))
         out["c2"]["want"], out["k33"]["want"], out["skew"]["want"] = fa.result(), fb.result(), fc.result()
         out["c2"]["main"] = fd.result()
+        out["ragged"]["want"] = fe.result()
     import os
     os.unlink(md / "s0.fa")
     return out
@@ -245,6 +286,24 @@ def test_c2_sized_skewed_sets_sample_is_bit_exact_against_cpu_checker(c2, cpu_ru
     # the replaced reads are mostly shared (every set holds poly-A reads, the same repeat units, the same library)
     is_rep = np.isin(run["sample"], run["replaced"])
     assert is_rep.sum() >= 4000 and got[is_rep].mean() > 0.6 and got.sum() > 5000
+
+
+def test_c2_sized_ragged_sets_sample_is_bit_exact_against_cpu_checker(c2, cpu_runs):
+    """configs[1]'s size with read lengths uniform in 50..150 bp (the reference's real inputs are trimmed reads, fastq_file.h:139-190):
+    the fast paths that used to be reserved for reads of one length — hist / scatter1 on the chunk's item list, the tiled search on a
+    query list sized by the set's own first-hit windows — bit-exact on a sample replayed by the CPU checker, and equal to the same
+    job through the round planner and the gather kernels"""
+    run, n = cpu_runs["ragged"], c2["n"]
+    assert len(run["chunks"]) == run["info"]["n_chunks"] == 2 and run["info"]["kmers_indexed"] == int(run["kc"].sum()) - int(run["kc"][run["chunks"][0][1]])
+    assert "tq_replay_kernel" in run["times"] and "part_items_kernels" in run["times"] and run["cache"] > 0
+    assert np.array_equal(run["tags_plain"], run["tags"])
+    assert [run["stats_plain"][f] for f in ("indexed", "searched", "shared")] == [run["stats"][f] for f in ("indexed", "searched", "shared")]
+    found = util.bools_from_bits(run["tags"], n)
+    got = found[run["sample"]]
+    assert np.array_equal(got, run["want"])
+    assert got.sum() > 3500 and run["stats"]["shared"] == int(found.sum())
+    # a read shorter than t * k bases cannot hold t non-overlapping k-mers
+    assert not found[run["lens1"] < 64].any() and found[: n // 4][run["lens1"][: n // 4] >= 80].mean() > 0.85
 
 
 @pytest.mark.parametrize("n_index,n_query", [(30000, 30000)])

@@ -332,6 +332,59 @@ def test_bucketed_index_uniform_length_fast_path(commet, k, L):
         assert np.array_equal(out[0][3], f.bytes())
 
 
+@pytest.mark.parametrize("k", [20, 21, 24, 26, 28, 31, 32, 33, 34])
+def test_bucketed_index_ragged_item_list(commet, k):
+    """reads of many lengths take the chunk's item list in hist / scatter1 (index_part.hpp, LIST; round 6): same filter as the
+    round planner (part_list = 1), the atomic kernel and the CPU checker — whole set, ranges that start / end anywhere, a selection
+    bitmap, an additive second call; the reads include what the list must get right without knowing a read's length: reads whose
+    length is a multiple of 32 (the next read's first windows must not look into them), reads shorter than k, reads of N only,
+    non-ACGT bases at a read's ends, reads of 1 base, hot buckets"""
+    rng = np.random.default_rng(4000 + k)
+    reads = util.random_reads(rng, 12000, 1, 300, n_rate=0.004)
+    reads += util.random_reads(rng, 3000, 32, 32, n_rate=0.0) + util.random_reads(rng, 3000, 64, 64, n_rate=0.001) + util.random_reads(rng, 2000, 96, 96)
+    reads += util.random_reads(rng, 500, 128, 128) + util.random_reads(rng, 300, 400, 400, n_rate=0.001)
+    reads += [b"N" * 77] * 50 + [b"A" * 130] * 400 + [(b"ACG" * 50)[:117]] * 300 + [b"C"] * 20 + [b"ACGT" * 8] * 200
+    reads += [b"N" + r[1:-1] + b"N" for r in util.random_reads(rng, 500, 40, 160)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    n = len(reads)
+    bases, offs = util.to_batch(reads)
+    sel = rng.random(n) < 0.6
+    sb = util.bits_from_bools(sel)
+    q = util.related_reads(rng, reads[:4000], 6000, 30, 200, share=0.5)
+    qb, qo = util.to_batch(q)
+    out = []
+    for mode, no_list in ((2, 0), (2, 1), (1, 0)):
+        with commet.Context(k=k, t=2) as ctx:
+            ctx.set_option("index_mode", mode)
+            ctx.set_option("part_list", no_list)
+            rs = commet.ReadSet.from_files(ctx, [(bases, offs)])
+            qs = commet.ReadSet.from_files(ctx, [(qb, qo)])
+            ctx.filter_reset()
+            fed_all = ctx.index_reads(rs)
+            whole = ctx.export_filter_reference() if k <= 28 else None
+            found_all, _, n_all = ctx.search_reads(qs)
+            ctx.filter_reset()
+            fed = ctx.index_reads(rs, 5, n - 2005, sb)
+            fed += ctx.index_reads(rs, n - 1999, 1999)            # additive second call, no selection; reads 0-4 and one more skipped
+            found, _, nfound = ctx.search_reads(qs)
+            out.append((fed_all, n_all, found_all, whole, fed, nfound, found, ctx.export_filter_reference() if k <= 28 else None))
+    for o in out[1:]:
+        for a, b in zip(o, out[0]):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+    if k <= 28:
+        f = ob.Bloom(k)
+        assert f.index(bases, offs) == out[0][0]
+        assert np.array_equal(out[0][3], f.bytes())
+        s2 = sel.copy()
+        s2[:5] = False
+        s2[n - 2000] = False
+        s2[n - 1999:] = True
+        f2 = ob.Bloom(k)
+        assert f2.index(bases, offs, util.bits_from_bools(s2)) == out[0][4]
+        assert np.array_equal(out[0][7], f2.bytes())
+
+
 @pytest.mark.parametrize("k", [30, 32, 33])
 def test_bucketed_index_equals_atomic_index_large_k(commet, k):
     """two-level radix geometry (k >= 26) incl. 64-bit keys; skewed input makes split tiles"""

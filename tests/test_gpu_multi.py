@@ -16,17 +16,20 @@ def _bits(rng, n, frac):
     return out
 
 
-@pytest.mark.parametrize("k,t,L,max_kmer", [(32, 2, 100, 12_000_000), (33, 2, 100, 9_000_000), (26, 2, 130, 15_000_000), (28, 3, 110, 0)])
+@pytest.mark.parametrize("k,t,L,max_kmer", [(32, 2, 100, 12_000_000), (33, 2, 100, 9_000_000), (26, 2, 130, 15_000_000), (28, 3, 110, 0),
+                                             (32, 2, (50, 150), 12_000_000), (33, 2, (60, 140), 9_000_000), (27, 3, (90, 170), 14_000_000)])
 def test_jobs_sharing_a_pass_equal_the_jobs_alone(k, t, L, max_kmer):
+    """L = (lo, hi): ragged sets (round 6: index sets of many read lengths share passes, too)"""
     import commet_amd
     from commet_amd import synth
     rng = np.random.default_rng(k * 100 + t)
     n_i, n_s = 400_000, 600_000
+    make = (lambda s, n: synth.synth_set_ragged(s, n, L[0], L[1])) if isinstance(L, tuple) else (lambda s, n: synth.synth_set(s, n, L))
     with commet_amd.Context(k=k, t=t) as ctx:
         ctx.set_option("index_mode", 2)                  # the bucketed construction whatever a chunk's size (the fast path's condition)
         ctx.set_option("max_kmer", max_kmer)             # several chunks per index set (test hook; both ways chunk alike)
-        srs = commet_amd.ReadSet.from_files(ctx, [synth.synth_set(0, n_s, L)])
-        irs = [commet_amd.ReadSet.from_files(ctx, [synth.synth_set(s, n_i, L)]) for s in (1, 2, 3, 4, 5)]
+        srs = commet_amd.ReadSet.from_files(ctx, [make(0, n_s)])
+        irs = [commet_amd.ReadSet.from_files(ctx, [make(s, n_i)]) for s in (1, 2, 3, 4, 5)]
         sels = [None, _bits(rng, n_i, 0.5), _bits(rng, n_i, 0.2), _bits(rng, n_i, 0.9), None]
         # alone
         alone = [ctx.index_and_search(rs, [srs], index_select=sel) for rs, sel in zip(irs, sels)]
