@@ -110,6 +110,15 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
     return 0;
 }
 
+// mask words (32 first-hit windows each) a read of the set needs per strand and filter in the register-mask kernels
+// (search_group8_kernel, tq_replay_kernel): 2, 3, 4 or 6 — reads of up to 255 bases at k = 32, t = 2 (round 6; 96 windows before)
+constexpr int MASK_MAX_WIN = 192;
+inline int mask_words(const commet_ctx *c, const commet_readset *rs)
+{
+    const int64_t fhw = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
+    return fhw <= 64 ? 2 : fhw <= 96 ? 3 : fhw <= 128 ? 4 : 6;
+}
+
 // one pass of rs over the `g` chunk filters in slots 0..g-1 (A planes already interleaved with stride gs)
 // job_mask != 0 (gs == 8 only): the g filters belong to several jobs, bit i = filter i opens one; job j's tags at d_tags + j * job_tag_words
 int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, const uint64_t *d_sel, uint64_t *d_tags,
@@ -127,23 +136,21 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
         const dim3 grid((unsigned) (((al.ids ? n_launch : rs->n_reads) + 255) / 256)), block(256);
-        const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;   // mask words per strand and filter
+        const int mw = mask_words(c, rs);   // mask words per strand and filter: 2, 3, 4 or 6
         KScope ks(c, "search_group8_kernel", c->stream);
+#define COMMET_G8(W, MW) COMMET_LAUNCH((search_group8_kernel<W, MW>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel, d_tags, d_counters, cstride, al, job_mask, job_tag_words)
         if (c->k <= 32) {
-            if (three)
-                COMMET_LAUNCH((search_group8_kernel<uint32_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
-            else
-                COMMET_LAUNCH((search_group8_kernel<uint32_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
+            if (mw == 2) COMMET_G8(uint32_t, 2);
+            else if (mw == 3) COMMET_G8(uint32_t, 3);
+            else if (mw == 4) COMMET_G8(uint32_t, 4);
+            else COMMET_G8(uint32_t, 6);
         } else {
-            if (three)
-                COMMET_LAUNCH((search_group8_kernel<uint64_t, 3>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
-            else
-                COMMET_LAUNCH((search_group8_kernel<uint64_t, 2>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel,
-                                   d_tags, d_counters, cstride, al, job_mask, job_tag_words);
+            if (mw == 2) COMMET_G8(uint64_t, 2);
+            else if (mw == 3) COMMET_G8(uint64_t, 3);
+            else if (mw == 4) COMMET_G8(uint64_t, 4);
+            else COMMET_G8(uint64_t, 6);
         }
+#undef COMMET_G8
         HIP_OK(hipGetLastError());
         return 0;
     }
@@ -163,12 +170,12 @@ bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
     return c->k >= 2 && nw >= 1 && (uint64_t) g * 2 * nw * 256 * 4 <= (64u << 10);
 }
 
-// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 96 first-hit windows per read in
-// registers (kernels.hpp); the probe-counting builds exist for groups of <= 4 only
+// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 192 first-hit windows per read in
+// registers (kernels.hpp: two to six mask words per strand and filter); the probe-counting builds exist for groups of <= 4 only
 bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 {
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
-    return c->k >= 2 && !c->count_probes && first_hit_windows <= 96;
+    return c->k >= 2 && !c->count_probes && first_hit_windows <= MASK_MAX_WIN;
 }
 
 // ---- sparse passes: the reads of a pass as a list (kernels.hpp, ActiveList) --------------------------------------
@@ -223,6 +230,7 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || g < 1 || g > 2) return false;
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
     if (first_hit_windows < 1 || first_hit_windows > TQ_MAX_WIN) return false;
+    if (rs->max_len >= TQ_MAX_LEN) return false;        // (the replay keeps a piece's read extents in 16 + 16 bits; such reads pass the line above only with t in the hundreds)
     if (rs->n_reads >= (1ull << 32)) return false;
     // (rs->fhw_total: the set's first-hit windows summed over its reads — n x first_hit_windows for reads of one length, less for ragged sets)
     if (rs->fhw_total >= (1ull << 32)) return false;   // record numbers are 32 bits (forced mode, too)
@@ -378,7 +386,7 @@ bool query_list_blocks(const commet_ctx *c, const commet_readset *rs, uint64_t o
 {
     const int t = t_eff(c, rs);
     const int64_t fhw = (int64_t) rs->max_len - (int64_t) t * c->k + 1;
-    if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || fhw < 1 || fhw > TQ_MAX_WIN || rs->n_reads < (1ull << 20) || rs->n_reads >= (1ull << 32)) return false;
+    if (c->k <= TQ_SBITS || c->k > TQ_MAX_K || fhw < 1 || fhw > TQ_MAX_WIN || rs->max_len >= TQ_MAX_LEN || rs->n_reads < (1ull << 20) || rs->n_reads >= (1ull << 32)) return false;
     const uint64_t records = rs->fhw_total;                   // (an upper bound: windows with a non-ACGT base make no record)
     if (records >= (1ull << 32)) return false;
     int sbits = TQ_SBITS;
@@ -409,7 +417,7 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
     // into `parts` runs of pieces; part i's probe and replay go to stream i % 2, every probe waiting for the probe before it
     // (one slice sweep at a time keeps the slice's filter words in L2), so the replay of part i runs beside the probe of
     // part i + 1.  With per-kernel timing on (durations must add up) or a small set: one part, one stream.
-    const bool three = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1 > 64;
+    const int mw = mask_words(c, rs);
     const int t = t_eff(c, rs);
     uint32_t parts = (c->kclock.on || q.n_pieces < 4096) ? 1u : (uint32_t) std::max(1, std::min(16, c->tq_parts));
     const unsigned wpx = c->tq_wpx;
@@ -428,24 +436,22 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
         {
             KScope ks(c, "tq_replay_kernel", st);
             const dim3 grid(p1 - p0), block(TQ_PIECE);
-#define COMMET_TQ_REPLAY(W, GS, MW) COMMET_LAUNCH((tq_replay_kernel<W, GS, MW>), grid, block, 0, st, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride, p0)
+#define COMMET_TQ_REPLAY(W, GS, MW) COMMET_LAUNCH((tq_replay_kernel<W, GS, MW>), grid, block, 0, st, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride, p0, (uint32_t) std::min<int>(c->tq_hit_cap, TQ_HIT_CAP))
+#define COMMET_TQ_REPLAY_MW(W, GS)                 \
+    do {                                           \
+        if (mw == 2) COMMET_TQ_REPLAY(W, GS, 2);   \
+        else if (mw == 3) COMMET_TQ_REPLAY(W, GS, 3); \
+        else if (mw == 4) COMMET_TQ_REPLAY(W, GS, 4); \
+        else COMMET_TQ_REPLAY(W, GS, 6);           \
+    } while (0)
             if (c->k <= 32) {
-                if (g == 1) {
-                    if (three) COMMET_TQ_REPLAY(uint32_t, 1, 3);
-                    else COMMET_TQ_REPLAY(uint32_t, 1, 2);
-                } else {
-                    if (three) COMMET_TQ_REPLAY(uint32_t, 2, 3);
-                    else COMMET_TQ_REPLAY(uint32_t, 2, 2);
-                }
+                if (g == 1) COMMET_TQ_REPLAY_MW(uint32_t, 1);
+                else COMMET_TQ_REPLAY_MW(uint32_t, 2);
             } else {
-                if (g == 1) {
-                    if (three) COMMET_TQ_REPLAY(uint64_t, 1, 3);
-                    else COMMET_TQ_REPLAY(uint64_t, 1, 2);
-                } else {
-                    if (three) COMMET_TQ_REPLAY(uint64_t, 2, 3);
-                    else COMMET_TQ_REPLAY(uint64_t, 2, 2);
-                }
+                if (g == 1) COMMET_TQ_REPLAY_MW(uint64_t, 1);
+                else COMMET_TQ_REPLAY_MW(uint64_t, 2);
             }
+#undef COMMET_TQ_REPLAY_MW
 #undef COMMET_TQ_REPLAY
         }
         HIP_OK(hipGetLastError());

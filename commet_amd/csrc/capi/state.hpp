@@ -470,6 +470,7 @@ struct commet_ctx {
     uint64_t ql_totals_cap = 0;
     uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
     uint64_t qres_cap = 0;
+    int tq_hit_cap = TQ_HIT_CAP;      // option "tq_hit_cap" (tests): full hits a piece of the replay may post before its scans walk their own candidates
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
     // environment knobs of A/B runs, read ONCE in commet_create (nothing on the launch path calls getenv)
     int tq_sbits = 0;                 // COMMET_TQ_SBITS: log2 bits per address slice of the query list (0 = TQ_SBITS)

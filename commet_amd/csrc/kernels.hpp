@@ -656,16 +656,17 @@ __global__ __launch_bounds__(256) COMMET_SGPRS void search_group_kernel(ReadsVie
     const uint64_t r = me.r;
     const int lane = threadIdx.x & 63;
     const bool active = me.active;
-    // the read of another thread of the workgroup (the cooperative tails): thread x of the bitmap form has read block * 256 + x
-    __shared__ uint32_t wg_read[256];
-    if (al.ids) wg_read[threadIdx.x] = (uint32_t) r;
-    auto read_of = [&](uint32_t owner) -> uint64_t { return al.ids ? (uint64_t) wg_read[owner] : blockIdx.x * 256ull + owner; };
     bool found = false;
     int found_chunk = -1;
     uint32_t probes = 0;
     uint64_t t0 = 0;
     uint32_t len = 0;
     if (r < rv.n) read_extent(rv, r, t0, len);
+    // every thread's read extent, for the threads that fetch its tail windows (the cooperative tails): on a set of many read lengths
+    // the owner's extent is otherwise two more loads (goff) in front of each such fetch
+    __shared__ unsigned long long wg_t0[256];
+    __shared__ uint32_t wg_len[256];
+    wg_t0[threadIdx.x] = t0, wg_len[threadIdx.x] = len;      // (first read behind a barrier)
     const uint32_t *p = rv.planes + 3 * t0;
     const int sh = T::BITS - k;
     const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
@@ -781,11 +782,8 @@ __global__ __launch_bounds__(256) COMMET_SGPRS void search_group_kernel(ReadsVie
                     for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += 256) {
                         const uint32_t rq = tail_req[pr / GROUP_TAIL_WIN], owner = rq & 255u, wi = pr % GROUP_TAIL_WIN;
                         const int q = (int) (rq >> 8) + (int) wi;
-                        uint64_t ot0;
-                        uint32_t olen;
-                        read_extent(rv, read_of(owner), ot0, olen);
-                        if (q >= (int) olen) continue;
-                        const uint32_t *op = rv.planes + 3 * ot0;
+                        if (q >= (int) wg_len[owner]) continue;
+                        const uint32_t *op = rv.planes + 3 * wg_t0[owner];
                         ItemWords<W> it;
                         it.load_with([&](uint32_t x) -> uint32_t { return staged ? rw[x * 256u + owner] : op[x]; }, (uint32_t) q >> 5);
                         W wh, wl;
@@ -922,7 +920,7 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     __shared__ uint32_t tail_req[256], tail_bits[256];
     __shared__ uint32_t tail_n;
     // the first-hit candidates of a scan are probed by the whole workgroup as well (see (2) below)
-    __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (7 bits: <= 96 first-hit windows)
+    __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (8 bits: <= 192 first-hit windows)
     __shared__ uint32_t full_hit[MW][256];
     __shared__ uint32_t cand_n;
     const bool multi = job_mask != 0;
@@ -931,20 +929,21 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     const bool active = me.active;
     __shared__ unsigned int wg_cnt[2 * GS];
     int job = -1, job_first = 0;
-    // the read of another thread of the workgroup (candidate sweeps, tails): thread x of the bitmap form has read block * 256 + x
-    __shared__ uint32_t wg_read[256];
-    if (al.ids) wg_read[threadIdx.x] = (uint32_t) r;
-    auto read_of = [&](uint32_t owner) -> uint64_t { return al.ids ? (uint64_t) wg_read[owner] : blockIdx.x * 256ull + owner; };
     bool found = false;
     int found_chunk = -1;
     uint64_t t0 = 0;
     uint32_t len = 0;
     if (r < rv.n) read_extent(rv, r, t0, len);
+    // every thread's read extent, for the threads that probe its candidates and tail windows: on a set of many read lengths the owner's
+    // extent is otherwise two more loads (goff) in front of each of those probes' chains
+    __shared__ unsigned long long wg_t0[256];
+    __shared__ uint32_t wg_len[256];
+    wg_t0[threadIdx.x] = t0, wg_len[threadIdx.x] = len;      // (first read behind a barrier)
     const uint32_t *p = rv.planes + 3 * t0;
     const int sh = T::BITS - k;
     const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
     const int last = (int) len - 1;
-    const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW
+    const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW (MW = 2, 3, 4 or 6: mask_words, capi/search_dispatch.hpp)
     const int q0 = k - 1;
     uint32_t fm[MW][GS], rm[MW][GS];       // [word of the 32 * MW relative positions][filter]
 #pragma unroll
@@ -1061,11 +1060,8 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
                         const uint32_t e = cand[ci];
                         owner[u] = e & 255u, wq[u] = e >> 8;
                         const int q = q0 + (int) wq[u];
-                        uint64_t ot0;
-                        uint32_t olen;
-                        read_extent(rv, read_of(owner[u]), ot0, olen);
                         ItemWords<W> it;
-                        it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                        it.load(rv.planes + 3 * wg_t0[owner[u]], (uint32_t) q >> 5);
                         W wh, wl;
                         (void) it.window((uint32_t) q & 31u, k, mask, wh, wl);   // complete: the gather saw it
                         if (strand == 0) ka[u] = T::brev(wh) >> sh, kb[u] = T::brev(wl) >> sh;
@@ -1120,12 +1116,9 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
                 for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += 256) {
                     const uint32_t rq = tail_req[pr / GROUP8_TAIL_WIN], owner = rq & 255u, w = pr % GROUP8_TAIL_WIN;
                     const int q = (int) (rq >> 8) + (int) w;
-                    uint64_t ot0;
-                    uint32_t olen;
-                    read_extent(rv, read_of(owner), ot0, olen);
-                    if (q >= (int) olen) continue;
+                    if (q >= (int) wg_len[owner]) continue;
                     ItemWords<W> it;
-                    it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                    it.load(rv.planes + 3 * wg_t0[owner], (uint32_t) q >> 5);
                     W wh, wl;
                     if (!it.window((uint32_t) q & 31u, k, mask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
                     const W ka = strand ? (W) (~wh & mask) : (W) (T::brev(wh) >> sh);

@@ -41,13 +41,20 @@ namespace commet {
 #ifndef COMMET_TQ_PIECE
 #define COMMET_TQ_PIECE 256
 #endif
+#ifndef TQ_PASS_LIST
+#define TQ_PASS_LIST 1   // replay: full hits of the light scans posted as a list and ORed into the masks array behind the sweep (0: a second mask array)
+#endif
+#ifndef TQ_HIT_CAP
+#define TQ_HIT_CAP 1024  // ... of at most this many hits per piece; more: every scan of the piece walks its own candidates
+#endif
 constexpr uint32_t TQ_PIECE = COMMET_TQ_PIECE;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1] in round 2; round 5: 256 / 128 / 64: 4.54 / 4.87 / 5.51)
-constexpr int      TQ_MAX_WIN = 96;       // first-hit windows per read (three mask words)
+constexpr uint32_t TQ_MAX_LEN = 8000;     // reads of a set that takes the tiled search are shorter: 256 x (len / 32 + 2) triples of a piece < 2^16 (rd_ext)
+constexpr int      TQ_MAX_WIN = 192;      // first-hit windows per read (up to six mask words; qwho has eight bits for the window)
 
 struct QueryListView {
     const unsigned long long *tile_off;   // n_slices * n_pieces + 1
     const uint32_t *qaddr;
-    const uint16_t *qwho;                 // read within piece (8 bits) | window << 8
+    const uint16_t *qwho;                 // read within piece (8 bits) | window << 8 (8 bits)
     const uint32_t *tstart;               // piece-major copy of the tile bounds for the replay: tstart[piece * n_slices + slice]
     const uint16_t *tlen;                 //   = first record / number of records of tile (slice, piece)
     uint32_t n_slices, n_pieces;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
 }
 
 // piece-major copy of the tile bounds (the replay reads all slices of ONE piece: 256 strided 8-byte loads become two short
-// contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 96).
+// contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 192 windows).
 __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long *__restrict__ tile_off, uint32_t n_slices, uint32_t n_pieces,
                                                         uint32_t *__restrict__ tstart, uint16_t *__restrict__ tlen)
 {
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
                                                       uint32_t rpr, const uint32_t *__restrict__ tstart,
                                                       uint32_t *__restrict__ qaddr, uint16_t *__restrict__ qwho)
 {
-    static_assert(TQ_PIECE <= 256 && TQ_MAX_WIN <= 128, "qwho packs the read in 8 bits and the window in 7");
+    static_assert(TQ_PIECE <= 256 && TQ_MAX_WIN <= 256, "qwho packs the read in 8 bits and the window in 8");
     extern __shared__ uint32_t fl[];
     uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *dstb = fill + n_slices;   // n_slices each
     uint32_t *rec_a = dstb + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
@@ -228,15 +235,15 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
                 const uint32_t s = (uint32_t) (addr >> sbits);
                 const uint32_t at = base[s] + atomicAdd(&fill[s], 1u);
                 rec_a[at] = ((uint32_t) addr & smask) | (selfp ? 0x80000000u : 0u);
-                rec_w[at] = i | (win << 8) | (s << 15);                  // read (8 bits) | window (7) | slice (<= 10)
+                rec_w[at] = i | (win << 8) | (s << 16);                  // read (8 bits) | window (8) | slice (<= 10)
             });
         __syncthreads();
         const uint32_t total = base[n_slices - 1] + cnt[n_slices - 1];
         for (uint32_t j = threadIdx.x; j < total; j += 256) {
-            const uint32_t w = rec_w[j], s = w >> 15;
+            const uint32_t w = rec_w[j], s = w >> 16;
             const uint32_t dst = dstb[s] + (j - base[s]);
             qaddr[dst] = rec_a[j];
-            qwho[dst] = (uint16_t) (w & 0x7FFFu);
+            qwho[dst] = (uint16_t) (w & 0xFFFFu);
         }
         __syncthreads();
         for (uint32_t s = threadIdx.x; s < n_slices; s += 256) dstb[s] += cnt[s];
@@ -316,8 +323,9 @@ template <typename W, int GS, int MW>
 __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsView rv, QueryListView ql, const uint8_t *__restrict__ qres,
                                                              FilterGroupView fg, int k, int t, const uint64_t *__restrict__ sel,
                                                              uint64_t *__restrict__ tags, unsigned long long *__restrict__ counters,
-                                                             uint32_t cstride, uint32_t piece0)
+                                                             uint32_t cstride, uint32_t piece0, uint32_t hit_cap)
 {
+    // hit_cap <= TQ_HIT_CAP: full hits of light scans a piece may post (tests set it to 0: every piece with a hit overflows)
     const uint32_t piece = blockIdx.x + piece0;          // (the launch covers pieces piece0 .. piece0 + gridDim.x - 1)
     __shared__ uint32_t masks[GS * 2 * MW * TQ_PIECE];   // [chunk][strand][word][read]
     auto mask_at = [&](int c, int strand, int h, uint32_t rd) -> uint32_t & { return masks[(((c * 2 + strand) * MW) + h) * TQ_PIECE + rd]; };
@@ -398,13 +406,30 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
     // (prefix sums of the masks' popcounts) and thread f takes candidates f, f + 1024, ...: one plane-B probe per lane and
     // round, all lanes busy.  Survivors (A & B) are collected in a second mask array and go through planes C and D the same
     // way; what is left are the full four-lane hits.
-    __shared__ uint32_t pass[GS * 2 * MW * TQ_PIECE];
+    // The full hits (A & B & C & D) of the light scans are found by whichever thread the sweep hands the candidate to, and are few (chance
+    // hits; reads that share sequence are heavy scans and walk their own candidates).  PASS_LIST: they are posted as a list of
+    // TQ_HIT_CAP words and, behind the sweep, ORed into the masks array itself, which nobody reads any more by then — the second
+    // mask array (12 KiB with three mask words: five workgroups per CU instead of eight, 6.4 against 4.5 ms per configs[1]-sized
+    // step on 50-150-bp reads) is gone.  A piece with more hits than the list holds lets every scan walk its own candidates, as
+    // heavy scans do: exact, only slower.
+    constexpr bool PASS_LIST = TQ_PASS_LIST != 0;
+    __shared__ uint32_t pass_arr[PASS_LIST ? 1 : GS * 2 * MW * TQ_PIECE];
+    __shared__ uint32_t hits[PASS_LIST ? TQ_HIT_CAP : 1];
+    __shared__ uint32_t hit_n;
+    uint32_t *const pass = PASS_LIST ? masks : pass_arr;
+    // where every read of the piece lies and how long it is: (first triple - the piece's first triple) | length << 16.  A candidate is
+    // probed by whichever thread the sweep hands it to, a tail window by whichever thread its number falls on, and on a set of many read
+    // lengths the owner's extent is two more loads (goff) in front of every such probe's chain; the piece's 256 extents fit 1 KiB
+    // (reads of a set that takes the tiled search have fewer than 2^13 bases: TQ_MAX_WIN first-hit windows)
+    __shared__ uint32_t rd_ext[TQ_PIECE];
+    __shared__ unsigned long long piece_t0;
     __shared__ uint32_t pre[TQ_PIECE];
     __shared__ uint32_t scan_ws[TQ_PIECE / 64];
     __shared__ unsigned int wg_cnt[2 * GS];
     constexpr int NS = 2 * GS;                           // scan index = chunk * 2 + strand
     auto word_at = [&](uint32_t *arr, int i, int h, uint32_t rd) -> uint32_t & { return arr[((i * MW) + h) * TQ_PIECE + rd]; };
     if (threadIdx.x < 2 * GS) wg_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) hit_n = 0;
     const uint64_t r = (uint64_t) piece * TQ_PIECE + threadIdx.x;
     const uint64_t word = r >> 6;
     const int lane = threadIdx.x & 63;
@@ -415,6 +440,10 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
         if (tags) tagw = tags[word];
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
+    uint64_t my_t0 = 0;
+    uint32_t my_len = 0;
+    if (r < rv.n) read_extent(rv, r, my_t0, my_len);
+    if (threadIdx.x == 0) piece_t0 = my_t0;                          // (the piece's first read exists: the grid covers pieces of the set only)
     using T = KeyTraits<W>;
     const int sh = T::BITS - k;
     const W kmask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
@@ -423,9 +452,10 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
 #pragma unroll
         for (int h = 0; h < MW; ++h) {
             if (!active || (i >> 1) >= fg.g) word_at(masks, i, h, threadIdx.x) = 0;   // reads that are not searched have no candidates
-            word_at(pass, i, h, threadIdx.x) = 0;
+            if (!PASS_LIST) word_at(pass, i, h, threadIdx.x) = 0;
         }
     __syncthreads();
+    rd_ext[threadIdx.x] = (r < rv.n) ? ((uint32_t) (my_t0 - piece_t0) & 0xFFFFu) | (my_len << 16) : 0u;   // (first read before the sweep's first barrier)
     // A read that shares sequence with the index set has a lane-a bit on (nearly) every window of one strand; the
     // reference leaves it after t hits, i.e. after ~4 t probes.  Such "heavy" scans (more than TQ_HEAVY candidates) keep
     // their masks in registers and their thread walks them itself in step (3), stopping at t; probing all their windows
@@ -447,12 +477,10 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
     }
     const bool heavy = hv != 0;
     // words of another read of the piece around window end q
+    const uint32_t *const piece_planes = rv.planes + 3 * piece_t0;
     auto keys_of = [&](uint32_t owner, int strand, int q, W &ka, W &kb) {
-        uint64_t t0;
-        uint32_t len;
-        read_extent(rv, (uint64_t) piece * TQ_PIECE + owner, t0, len);
         ItemWords<W> it;
-        it.load(rv.planes + 3 * t0, (uint32_t) q >> 5);
+        it.load(piece_planes + 3u * (rd_ext[owner] & 0xFFFFu), (uint32_t) q >> 5);
         W wh, wl;
         (void) it.window((uint32_t) q & 31u, k, kmask, wh, wl);           // complete: only complete windows are in the list
         if (strand) ka = ~wh & kmask, kb = ~wl & kmask;
@@ -537,8 +565,30 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
               [&](uint32_t owner, int i, int h, uint32_t b, W ka, W kb) {
                   const uint32_t *pc = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + 2 * fg.plane_words, *pd = pc + fg.plane_words;
                   const uint32_t vc = pc[(ka ^ kb) >> 5], vd = pd[(ka | kb) >> 5];
-                  if ((vc >> ((uint32_t) (ka ^ kb) & 31u)) & (vd >> ((uint32_t) (ka | kb) & 31u)) & 1u) atomicOr(&word_at(pass, i, h, owner), 1u << b);
+                  if ((vc >> ((uint32_t) (ka ^ kb) & 31u)) & (vd >> ((uint32_t) (ka | kb) & 31u)) & 1u) {
+                      if (PASS_LIST) {
+                          const uint32_t at = atomicAdd(&hit_n, 1u);
+                          if (at < hit_cap) hits[at] = owner | ((uint32_t) i << 8) | ((uint32_t) h << 12) | (b << 16);
+                      } else {
+                          atomicOr(&word_at(pass, i, h, owner), 1u << b);
+                      }
+                  }
               });
+    }
+    bool all_self = false;              // PASS_LIST: the list overflowed — every scan walks its own lane-a candidates (am[])
+    if (PASS_LIST) {                    // (behind the sweep's last barrier: nobody reads the masks any more)
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int h = 0; h < MW; ++h) word_at(masks, i, h, threadIdx.x) = 0;
+        __syncthreads();
+        const uint32_t nh = hit_n;
+        all_self = nh > hit_cap;
+        for (uint32_t e = threadIdx.x; e < min(nh, hit_cap); e += TQ_PIECE) {
+            const uint32_t x = hits[e];
+            atomicOr(&word_at(masks, (int) ((x >> 8) & 15u), (int) ((x >> 12) & 15u), x & 255u), 1u << (x >> 16));
+        }
+        __syncthreads();
     }
     // (3) the reference's control flow (search_reads.h:45-83) on the full hits of this thread's read: per chunk, strand 0
     // then strand 1; greedy non-overlapping hits; the windows behind the first-hit ones are probed only for a scan that
@@ -547,15 +597,15 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
     // round trip and ~50 instructions per window with every lane busy, where a thread fetching its own 32 windows
     // (a rolling window, four batches of eight loads) kept the other lanes of its wave waiting through
     // ~1500 instructions and four round trips (1.8 ms of this kernel's 6.1 on configs[1]).
-    __shared__ uint32_t tail_req[TQ_PIECE], tail_bits[TQ_PIECE];
+    // (PASS_LIST: the hit list is dead by now; the tails' request / answer arrays take its place)
+    static_assert(!PASS_LIST || TQ_HIT_CAP >= 2 * TQ_PIECE, "the tails' arrays alias the hit list");
+    __shared__ uint32_t tail_arr[PASS_LIST ? 1 : 2 * TQ_PIECE];
+    uint32_t *const tail_req = PASS_LIST ? hits : tail_arr, *const tail_bits = tail_req + TQ_PIECE;
     __shared__ uint32_t tail_n;
     int found_chunk = -1;
     {
-        uint64_t t0 = 0;
-        uint32_t len = 0;
-        if (r < rv.n) read_extent(rv, r, t0, len);
-        const uint32_t *p = rv.planes + 3 * t0;
-        const int last = (int) len - 1;
+        const uint32_t *p = rv.planes + 3 * my_t0;
+        const int last = (int) my_len - 1;
         const int pe = last - (t - 1) * k;
         const int q0 = k - 1;
         const bool scanning = active && !(COMMET_TQ_ABLATE & (1024 | 8192));
@@ -567,7 +617,7 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
             int seen = 0, next_ok = 0;
             bool dead = !scanning || found;
             for (int h = 0; h < MW && !found && !dead; ++h) {
-                const bool hscan = (hv >> i) & 1u;
+                const bool hscan = ((hv >> i) & 1u) || all_self;
                 uint32_t m = pass[((i * MW) + h) * TQ_PIECE + threadIdx.x];    // light scans: full hits (step 2)
                 if (hscan) {                                                     // heavy scans: lane-a candidates, probed here
                     m = 0;
@@ -620,12 +670,10 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
                 for (uint32_t pr = threadIdx.x; pr < n_pairs; pr += TQ_PIECE) {
                     const uint32_t rq = tail_req[pr >> 5], owner = rq & 255u, w = pr & 31u;
                     const int q = (int) (rq >> 8) + (int) w;
-                    uint64_t ot0;
-                    uint32_t olen;
-                    read_extent(rv, (uint64_t) piece * TQ_PIECE + owner, ot0, olen);
-                    if (q >= (int) olen) continue;
+                    const uint32_t oext = rd_ext[owner];
+                    if (q >= (int) (oext >> 16)) continue;
                     ItemWords<W> it;
-                    it.load(rv.planes + 3 * ot0, (uint32_t) q >> 5);
+                    it.load(piece_planes + 3u * (oext & 0xFFFFu), (uint32_t) q >> 5);
                     W wh, wl;
                     if (!it.window((uint32_t) q & 31u, k, kmask, wh, wl)) continue;   // a base that is not ACGT: no k-mer here
                     const W ka = strand ? (W) (~wh & kmask) : (W) (T::brev(wh) >> sh);

@@ -491,6 +491,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             w0 = time.perf_counter()
             rs = eng.parse(files[s])
             prof["parse_s"] += time.perf_counter() - w0
+            prof.setdefault("parse_log", []).append([s, round(time.perf_counter() - w0, 4)])
             prof["sets_parsed"] += 1
             leave_filters(s, rs)
             if s in needed_by_others:
@@ -719,6 +720,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                             w0 = time.perf_counter()
                             sets[s] = eng.parse(files[s])
                             prof["parse_s"] += time.perf_counter() - w0
+                            prof.setdefault("parse_log", []).append([s, round(time.perf_counter() - w0, 4)])
                             prof["sets_parsed"] += 1
                             leave_filters(s, sets[s])
                         elif s not in sets and not fetch(s):
@@ -762,10 +764,15 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
 
         call_log = os.environ.get("COMMET_MATRIX_CALL_LOG")   # one line per library call: jobs, wall, event-timed device time, python clock
 
-        def _acc(inf, n=1):
+        job_log = prof.setdefault("job_log", [])   # one row per library call: [kind, search set or reference, [the other sets], index ms, search ms, call ms]
+                                                   # (what tools/schedule_sim.py replays on the pair cut of N ranks)
+
+        def _acc(inf, n=1, what=None):
             prof["jobs"] += n
             prof["call_ms"] += inf["total_ms"]
             prof["device_ms"] += inf["index_ms"] + inf["search_ms"]
+            if what is not None:
+                job_log.append([what[0], what[1], list(what[2]), round(inf["index_ms"], 3), round(inf["search_ms"], 3), round(inf["total_ms"], 3)])
             if call_log:
                 with open(call_log, "a") as fh:
                     fh.write(f"{rank} {n} {inf['total_ms']:.3f} {inf['index_ms']:.3f} {inf['search_ms']:.3f} {time.perf_counter():.6f}\n")
@@ -781,7 +788,7 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         def out_log(*a):
             written.append(writer.submit(_log, *a))
 
-        def jobs_on_one_search_set(index_ids, search_id, selections):
+        def jobs_on_one_search_set(index_ids, search_id, selections, kind="J2"):
             """Jobs that search the SAME set — the J2 jobs of a reference set, the J3 jobs of a target (Commet.py:220, 233) — in one call
             where the engine has one (commet_index_many_and_search: their chunk filters share passes over the search set: the lane-a
             gathers of its reads, two thirds of such a job's memory requests, are made once per pass instead of once per job);
@@ -790,12 +797,12 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 return []
             if hasattr(eng, "index_many_and_search") and len(index_ids) > 1:
                 tags, st, inf = eng.index_many_and_search([sets[x] for x in index_ids], sets[search_id], selections, sel[search_id])
-                _acc(inf, len(index_ids))
+                _acc(inf, len(index_ids), (kind, search_id, index_ids))
                 return [(tags[j], st[j], inf["index_ms"] / len(index_ids)) for j in range(len(index_ids))]
             out = []
             for x, sl in zip(index_ids, selections):
                 tags, st, inf = eng.index_and_search(sets[x], [sets[search_id]], sl, [sel[search_id]])
-                _acc(inf)
+                _acc(inf, 1, (kind, search_id, [x]))
                 out.append((tags[0], st[0], inf["index_ms"]))
             return out
 
@@ -803,46 +810,67 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
         # together (they all search S_ref); the J3 jobs — (ref, i) searches S_i — are kept back and run target by target at the end, so
         # that the J3 jobs of a target share passes as well.  The files a job writes do not depend on when it runs.
         t_jobs = time.perf_counter()
-        kept_T2 = {}                   # (ref, i) -> J2's result, the index selection of J3(ref, i)
-        for ref in refs:
-            wait_for(ref)
-            pending = [i for (r, i) in mine if r == ref]
-            while pending:
-                # J1 of `ref` against the targets that are resident by now — all of them as a rule; at the start of a run with several
-                # ranks whichever have arrived, the others in a second call (one more index build of S_ref instead of an idle GPU)
-                targets = [i for i in pending if loader is None or ready[i].is_set()]
-                if not targets:
-                    wait_for(pending[0])
-                    continue
-                pending = [i for i in pending if i not in targets]
-                for s_need in targets:
-                    wait_for(s_need)                             # (resident: raises what the loader raised, if it did)
-                w0 = time.perf_counter()
-                tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
-                prof["j1_builds"] += 1
-                reads_searched += sum(considered[i] for i in targets)
-                _acc(inf1)
-                # J2 of every target: X_i = S_i restricted to (S_i in S_ref); S_ref in X_i
-                for i, (T2, st2, index_ms) in zip(targets, jobs_on_one_search_set(targets, ref, list(tags1))):
-                    for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
-                        out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-                    out_log(out_dir, names[ref], names[i], st2, index_ms, time.perf_counter() - w0)
-                    shared[(ref, i)] = st2["shared"]
-                    kept_T2[(ref, i)] = T2
-                    reads_searched += considered[ref]
-            note(f"J1 and J2 jobs of set {ref} done ({prof['jobs']} so far)")
-        # J3 of every pair: S_i in (S_ref restricted to J2's result) — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233) — target by target
-        for i in sorted({i for (_, i) in mine}):
+        kept_T2 = {}                   # (ref, i) -> J2's result, the index selection of J3(ref, i); freed as J3 consumes it
+        refs_left = {}                 # target -> reference sets of this rank's pairs that have not been through J2 yet
+        for (r_, i_) in mine:
+            refs_left[i_] = refs_left.get(i_, 0) + 1
+
+        def j3_of(i):
+            """J3 of every pair of target i: S_i in (S_ref restricted to J2's result) — overwrites J1's <F>_in_<S_ref>.bv (Commet.py:233)"""
+            nonlocal reads_searched
             w0 = time.perf_counter()
             wait_for(i)
             of_i = [r for (r, t_) in mine if t_ == i]
-            for ref, (T3, st3, index_ms) in zip(of_i, jobs_on_one_search_set(of_i, i, [kept_T2.pop((r, i)) for r in of_i])):
+            for ref, (T3, st3, index_ms) in zip(of_i, jobs_on_one_search_set(of_i, i, [kept_T2.pop((r, i)) for r in of_i], "J3")):
                 for f, c, b in zip(files[i], counts[i], split_bits(T3, counts[i])):
                     out_bv(out_dir + os.path.basename(f) + "_in_" + names[ref] + ".bv", f + " in " + names[ref], c, b)
                 out_log(out_dir, names[i], names[ref], st3, index_ms, time.perf_counter() - w0)
                 shared[(i, ref)] = st3["shared"]
                 reads_searched += considered[i]
             note(f"J3 jobs of set {i} done ({prof['jobs']} so far)")
+
+        try:
+            for ref in refs:
+                wait_for(ref)
+                pending = [i for (r, i) in mine if r == ref]
+                done_here = list(pending)
+                while pending:
+                    # J1 of `ref` against the targets that are resident by now — all of them as a rule; at the start of a run with several
+                    # ranks whichever have arrived, the others in a second call (one more index build of S_ref instead of an idle GPU)
+                    targets = [i for i in pending if loader is None or ready[i].is_set()]
+                    if not targets:
+                        wait_for(pending[0])
+                        continue
+                    pending = [i for i in pending if i not in targets]
+                    for s_need in targets:
+                        wait_for(s_need)                             # (resident: raises what the loader raised, if it did)
+                    w0 = time.perf_counter()
+                    tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
+                    prof["j1_builds"] += 1
+                    reads_searched += sum(considered[i] for i in targets)
+                    _acc(inf1, 1, ("J1", ref, targets))
+                    # J2 of every target: X_i = S_i restricted to (S_i in S_ref); S_ref in X_i
+                    for i, (T2, st2, index_ms) in zip(targets, jobs_on_one_search_set(targets, ref, list(tags1))):
+                        for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
+                            out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
+                        out_log(out_dir, names[ref], names[i], st2, index_ms, time.perf_counter() - w0)
+                        shared[(ref, i)] = st2["shared"]
+                        kept_T2[(ref, i)] = T2
+                        reads_searched += considered[ref]
+                note(f"J1 and J2 jobs of set {ref} done ({prof['jobs']} so far)")
+                # The J3 jobs — (ref, i) searches S_i — are kept back so that the J3 jobs of a target share passes as well, but no longer than
+                # needed: a target's batch runs as soon as the last of its reference sets on this rank has been through J2 (its J2 bitmaps are
+                # freed with it, its files are on disk: a late failure loses little).  The files a job writes do not depend on when it runs.
+                for i in done_here:
+                    refs_left[i] -= 1
+                for i in sorted(done_here):
+                    if refs_left[i] == 0:
+                        j3_of(i)
+            for i in sorted(i_ for i_, n_ in refs_left.items() if n_ > 0):     # (never: every target's references are in `refs`)
+                j3_of(i)
+        except BaseException:
+            writer.shutdown(wait=False, cancel_futures=True)
+            raise
         eng.synchronize()
         if loader is not None:
             jobs_done.set()                                      # (no list memory is set aside for jobs that are over)

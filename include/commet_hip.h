@@ -248,7 +248,7 @@ int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_reads
  *                        its VALU-bound phases run beside the first chunk's HBM-bound ones; 0 = both chunks start together
  *   drop_workspaces      frees the scatter workspaces (the next bucketed index build allocates them again)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
- *                        for read sets with at most 96 first-hit windows per read, else 4)
+ *                        for read sets with at most 192 first-hit windows per read — reads of up to 255 bases at k = 32, t = 2 —, else 4)
  *   tiled_search (0/1/2) large search sets against 1 or 2 chunk filters (25 <= k <= 34): lane-a gathers served from L2 slice
  *                        by slice from the set's cached query list; 0 = sets of 2^20 reads or more whose list fits 4 GiB,
  *                        1 = never, 2 = whenever possible
@@ -269,6 +269,8 @@ int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_reads
  *                        others) walks the list of the selected, not yet tagged reads instead of the set's bitmap, so that every
  *                        lane of a wave has a read: 0 = when the host plan visits less than half of the set's reads, 1 = never,
  *                        2 = whenever a selection applies (tests)
+ *   tq_hit_cap           TEST HOOK of the tiled search's replay: full hits a piece of 256 reads may post for its owners (default and
+ *                        at most 1024; beyond it every scan of the piece walks its own candidates — same bits, slower); 0 forces that path
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)
  *   part_no_uni (0/1)    1 = never take the fixed-read-length fast path of hist / scatter1 (nor the item list of ragged sets)
  *   part_list (0/1)      ragged sets (reads of several lengths): 0 = hist / scatter1 walk the chunk's item list (written out once per

@@ -143,20 +143,29 @@ def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 # search_group8_kernel: three mask words (65..96 first-hit windows) and 64-bit keys, more than four chunks each
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k,t,L,max_kmer,n_idx", [
-    (20, 1, 110, 0, 9000),          # 91 first-hit windows -> <u32, 3>; the reference's own chunk size (122 070 k-mers)
-    (24, 2, 140, 60000, 6000),      # 93 windows -> <u32, 3>
-    (33, 2, 100, 50000, 6000),      # 35 windows -> <u64, 2>
-    (34, 1, 128, 60000, 5000),      # 95 windows -> <u64, 3>
-    (33, 3, 150, 40000, 4000),      # 52 windows, t = 3 -> <u64, 2>
+@pytest.mark.parametrize("k,t,L,max_kmer,n_idx,lo", [
+    (20, 1, 110, 0, 9000, None),          # 91 first-hit windows -> <u32, 3>; the reference's own chunk size (122 070 k-mers)
+    (24, 2, 140, 60000, 6000, None),      # 93 windows -> <u32, 3>
+    (33, 2, 100, 50000, 6000, None),      # 35 windows -> <u64, 2>
+    (34, 1, 128, 60000, 5000, None),      # 95 windows -> <u64, 3>
+    (33, 3, 150, 40000, 4000, None),      # 52 windows, t = 3 -> <u64, 2>
+    # round 6: four and six mask words (97..128, 129..192 first-hit windows: reads of up to 255 bases at k = 32, t = 2), ragged sets
+    (20, 1, 140, 0, 11000, 40),           # 121 windows -> <u32, 4>
+    (24, 2, 230, 60000, 4000, 60),        # 183 windows -> <u32, 6>
+    (33, 1, 150, 40000, 4000, 50),        # 118 windows -> <u64, 4>
+    (34, 2, 250, 60000, 3000, 70),        # 183 windows -> <u64, 6>
+    (32, 2, 250, 60000, 3000, 250),       # 187 windows, reads of one length -> <u32, 6>
 ])
-def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx):
+def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx, lo):
     """max_kmer != 0 uses the library's test hook (k-mers per chunk) so that k >= 33 gets more than four chunks from a
-    few thousand reads; the CPU checker is then chunked with the same constant."""
+    few thousand reads; the CPU checker is then chunked with the same constant.  lo: read lengths uniform in [lo, L]
+    (None: all reads of L bases)."""
     import commet_amd
     rng = np.random.default_rng(1000 * k + L)
-    idx_reads = util.random_reads(rng, n_idx, L, L, n_rate=0.002)
-    q_reads = util.related_reads(rng, idx_reads, 12000, L, L, share=0.5, n_rate=0.002)
+    lo = L if lo is None else lo
+    idx_reads = util.random_reads(rng, n_idx, lo, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 12000, lo, L, share=0.5, n_rate=0.002)
+    q_reads[0] = (q_reads[1] * 8)[:L]                                      # (the set's longest read has L bases whatever the draw)
     ib, io = util.to_batch(idx_reads)
     qb, qo = util.to_batch(q_reads)
     with commet_amd.Context(k=k, t=t) as ctx:
@@ -342,31 +351,44 @@ def test_probe_counting_group_kernels_with_64_bit_keys(k, t, L, max_kmer, group)
     assert res[1][1][0]["shared"] > 500
 
 
-@pytest.mark.parametrize("k,t,L,max_kmer", [(26, 1, 110, 90000), (33, 1, 120, 90000)])
-def test_tiled_replay_three_mask_words_two_filters(k, t, L, max_kmer):
-    """tq_replay_kernel<W, 2, 3>: 65..96 first-hit windows per read (three mask words) against a group of two chunk filters"""
+@pytest.mark.parametrize("k,t,L,max_kmer,lo,words", [(26, 1, 110, 90000, 110, 3), (33, 1, 120, 90000, 120, 3),
+                                                      (26, 1, 150, 90000, 60, 4), (33, 1, 155, 90000, 155, 4),
+                                                      (28, 2, 240, 120000, 80, 6), (34, 1, 220, 120000, 90, 6), (32, 2, 250, 150000, 100, 6)])
+def test_tiled_replay_three_to_six_mask_words(k, t, L, max_kmer, lo, words):
+    """tq_replay_kernel<W, 1 | 2, 3 | 4 | 6>: 65..96 / 97..128 / 129..192 first-hit windows per read (three, four, six mask words; round 6:
+    reads of up to 255 bases at k = 32, t = 2 keep the tiled search) against groups of two chunk filters and against single ones;
+    lo < L: ragged sets"""
     import commet_amd
     rng = np.random.default_rng(11 * k)
-    idx_reads = util.random_reads(rng, 4000, L, L, n_rate=0.002)
-    q_reads = util.related_reads(rng, idx_reads, 6000, L, L, share=0.5, n_rate=0.002)
+    idx_reads = util.random_reads(rng, 4000, lo, L, n_rate=0.002)
+    q_reads = util.related_reads(rng, idx_reads, 6000, lo, L, share=0.5, n_rate=0.002)
+    q_reads[0] = (q_reads[1] * 8)[:L]                                      # (the set's longest read has L bases whatever the draw)
     ib, io = util.to_batch(idx_reads)
     qb, qo = util.to_batch(q_reads)
+    fhw = L - t * k + 1
+    assert words == (2 if fhw <= 64 else 3 if fhw <= 96 else 4 if fhw <= 128 else 6)
+    got = {}
     with commet_amd.Context(k=k, t=t) as ctx:
         ctx.set_option("max_kmer", max_kmer)
         ctx.set_option("tiled_search", 2)
-        ctx.set_option("chunk_group", 2)
         irs = commet_amd.ReadSet.from_files(ctx, [(ib, io)])
         qrs = commet_amd.ReadSet.from_files(ctx, [(qb, qo)])
         kc = irs.kmer_counts()
-        ctx.set_option("kernel_timing", 1)
-        tags, stats, info = ctx.index_and_search(irs, [qrs])
-        assert "tq_replay_kernel" in ctx.kernel_times() and qrs.cache_bytes > 0
+        for group in (2, 1):
+            ctx.set_option("chunk_group", group)
+            ctx.set_option("kernel_timing", 1)
+            got[group] = ctx.index_and_search(irs, [qrs])
+            times = ctx.kernel_times()
+            ctx.set_option("kernel_timing", 0)
+            assert "tq_replay_kernel" in times and "search_kernel" not in times and "search_group_kernel" not in times and qrs.cache_bytes > 0
     chunks = oracle_pool.chunks_from_counts(kc, max_kmer)
-    assert len(chunks) >= 4 and 64 < L - t * k + 1 <= 96
+    assert len(chunks) >= 4
     found, searched_last = _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, len(q_reads))
-    assert np.array_equal(tags[0], found)
-    assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum()))
-    assert stats[0]["shared"] > 1000
+    for group in (2, 1):
+        tags, stats, info = got[group]
+        assert np.array_equal(tags[0], found), group
+        assert (stats[0]["searched"], stats[0]["shared"]) == (searched_last, int(util.bools_from_bits(found, len(q_reads)).sum()))
+    assert got[2][1][0]["shared"] > 1000
 
 
 def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
