@@ -91,16 +91,24 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         HIP_OK(dev_alloc(c, (void **) &ws.cur2, g.nb * sizeof(unsigned long long), true));
         ws.nb = g.nb;
     }
-    if (ws.cap_keys < total) {
+    // bufA: one word per key.  bufB: the same when the final level holds plain keys; in the packed geometry 8-byte groups of three keys,
+    // every (scatter2 slab, final bucket) run rounded up to a whole group (part_scan_kernel: a bucket of c keys gets c / 3 + the slabs
+    // that overlap its coarse bucket + 1 groups): two words x (total / 3 + 2^b2 x (total / S2_KEYS + 3 x 2^b1)) — 0.73 words per key
+    // at k = 32, where a full word per key was 2.3 GB per workspace asked from the driver for nothing
+    const bool packed_b = g.packed && g.b2 && (1u << g.b2) <= S2P_MAX_SUB;
+    auto words_b = [&](uint64_t keys) -> uint64_t {
+        return packed_b ? 2 * (keys / 3 + ((uint64_t) 1 << g.b2) * (keys / S2_KEYS + 3ull * g.nb1)) + 4096 : keys;
+    };
+    if (ws.cap_keys < total || ws.cap_b < words_b(total)) {
         HIP_OK(hipStreamSynchronize(stream));
         (void) dm_free(ws.bufA); (void) dm_free(ws.bufB);
         ws.bufA = ws.bufB = nullptr;
-        ws.cap_keys = 0;
-        const uint64_t cap = total + total / 16 + (1ull << 20);   // bufB, packed: 2/3 + nsub/4096 words per key + a constant
+        ws.cap_keys = 0, ws.cap_b = 0;
+        const uint64_t cap = total + total / 16 + (1ull << 20);
         // (touched there, too: a first touch inside the first scatter launch cost 15.6 instead of 2.5 ms)
         HIP_OK(alloc_workspace(c, (void **) &ws.bufA, cap * sizeof(uint32_t), stream));
-        HIP_OK(alloc_workspace(c, (void **) &ws.bufB, cap * sizeof(uint32_t), stream));
-        ws.cap_keys = cap;
+        HIP_OK(alloc_workspace(c, (void **) &ws.bufB, words_b(cap) * sizeof(uint32_t), stream));
+        ws.cap_keys = cap, ws.cap_b = words_b(cap);
     }
     const bool wide = c->k > 32;
     // every read of one length and no selection bitmap: items by arithmetic, no round planning (index_part.hpp, UNI)
@@ -121,6 +129,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
             (void) dm_free(ws.items), (void) dm_free(ws.itemblk);
             ws.items = ws.itemblk = nullptr, ws.items_cap = ws.itemblk_cap = 0;
             const uint64_t cap = need + need / 8;
+            ws.items_set = 0;
             if (dev_alloc(c, (void **) &ws.items, cap * sizeof(uint32_t), true) != hipSuccess ||
                 dev_alloc(c, (void **) &ws.itemblk, (nblk + 1 + 1024) * sizeof(uint32_t), true) != hipSuccess) {
                 (void) hipGetLastError();               // no room: the round planner walks the reads, as before
@@ -131,7 +140,13 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
                 ws.items_cap = cap, ws.itemblk_cap = nblk + 1 + 1024;
             }
         }
-        if (list) {
+        // the list of an UNSELECTED read range is a function of the set alone: a workspace that still holds it (the same chunk of the same
+        // set indexed again: the reference set of a rank's J1 calls, a benchmark's steady state) does not write it again
+        const bool held = list && !d_sel && ws.items_set == rs->uid && ws.items_first == first && ws.items_count == count && ws.items_nblk == (uint32_t) nblk;
+        if (held) {
+            d_items = ws.items, d_nitems = ws.itemblk + nblk;
+        } else if (list) {
+            ws.items_set = d_sel ? 0 : rs->uid, ws.items_first = first, ws.items_count = count, ws.items_nblk = (uint32_t) nblk;
             KScope ks(c, "part_items_kernels", stream);
             COMMET_LAUNCH(part_items_kernel<false>, dim3((unsigned) nblk), dim3(ITEMS_BLOCK), 0, stream, rs->view(), rs->d_kcnt, d_sel, first, count, c->k,
                           ws.itemblk, ws.items);

@@ -14,6 +14,8 @@ commet_readset *commet_readset_create(commet_ctx *c, uint64_t max_reads, uint64_
     }
     HIP_OK_NULL(hipSetDevice(c->device));
     commet_readset *rs = new commet_readset;
+    static std::atomic<uint64_t> next_uid{1};
+    rs->uid = next_uid.fetch_add(1);
     rs->ctx = c;
     rs->max_reads = max_reads;
     rs->max_bases = max_bases;

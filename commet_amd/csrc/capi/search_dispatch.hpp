@@ -49,11 +49,19 @@ int ensure_slots(commet_ctx *c, int g, int gs)
     if (c->n_slots < g) {
         HIP_OK(hipStreamSynchronize(c->stream));
         uint32_t *nf = nullptr;
-        hipError_t e = dev_alloc(c, (void **) &nf, (size_t) g * c->filter_bytes, true);
+        // a whole group's worth at once (2, 4 or 8 slots): a job of seven chunks followed by one of eight (the N x N driver's J1, then its
+        // shared J2 passes) used to take 14 GiB and then 16 GiB from the driver at k = 32; if that does not fit, what is needed now
+        int want = std::max(g, gs);
+        hipError_t e = dev_alloc(c, (void **) &nf, (size_t) want * c->filter_bytes, true);
+        if (e != hipSuccess && want > g) {
+            (void) hipGetLastError();
+            want = g;
+            e = dev_alloc(c, (void **) &nf, (size_t) want * c->filter_bytes, true);
+        }
         if (e != hipSuccess) return fail("cannot allocate %d filter slots: %s", g, hipGetErrorString(e));
         (void) dm_free(c->filter);
         c->filter = nf;
-        c->n_slots = g;
+        c->n_slots = want;
     }
     if (c->il_stride < gs) {
         HIP_OK(hipStreamSynchronize(c->stream));

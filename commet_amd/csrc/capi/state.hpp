@@ -84,6 +84,15 @@ struct DevMemCache {
         }
         return on != 0;
     }
+    int verb = -1;
+    bool verbose()                                                 // COMMET_DEVMEM_VERBOSE=1: one line on stderr per block asked from or returned to the driver
+    {
+        if (verb < 0) {
+            const char *e = getenv("COMMET_DEVMEM_VERBOSE");
+            verb = e && atoi(e) != 0;
+        }
+        return verb != 0;
+    }
     bool pooling()
     {
         if (pool_on < 0) {
@@ -194,10 +203,24 @@ size_t dm_pooled_bytes(int device)
     return n;
 }
 
+// Size classes: a block of 8 MiB or more is asked for in steps of 1/16 .. 1/32 of its size (a request of 8.5 GB becomes one of 8.6 GB).
+// The objects a context makes — scatter workspaces sized by a chunk's k-mer count, a set's planes, a query list — come out a few
+// hundred bytes apart from one set to the next; filed under their exact sizes, a block that was 100 bytes short served nobody and
+// the next context asked the driver for the same 17 GB again (the first process on a box that charges for fresh device memory pays
+// 30 ms per GiB for that, DESIGN section 4: bench.py's matrix legs, commet_device_alloc_stats).
+inline size_t dm_size_class(size_t bytes)
+{
+    if (bytes < DEVMEM_MIN_FILED) return bytes;
+    const int lg = 63 - __builtin_clzll((unsigned long long) bytes);
+    const size_t granule = (size_t) 1 << (lg - 4);
+    return (bytes + granule - 1) & ~(granule - 1);
+}
+
 // `shareable`: the block may be exported to another process (commet_readset_export), so it comes from hipMalloc
 hipError_t dm_malloc(void **p, size_t bytes, bool shareable = false)
 {
     *p = nullptr;
+    if (g_devmem.enabled()) bytes = dm_size_class(bytes);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipMalloc(p, bytes);
     if (!g_devmem.enabled()) {
@@ -220,6 +243,10 @@ hipError_t dm_malloc(void **p, size_t bytes, bool shareable = false)
         }
     }
     bool pooled = false;
+    if (g_devmem.verbose()) {
+        std::lock_guard<std::mutex> lk(g_devmem.mu);
+        fprintf(stderr, "[devmem] driver alloc %.1f MiB (filed: %.1f GiB in %zu blocks)\n", bytes / 1048576.0, g_devmem.filed_bytes[dev] / 1073741824.0, g_devmem.filed[dev].size());
+    }
     hipError_t e = dm_driver_alloc(p, bytes, dev, shareable, &pooled);
     if (e == hipErrorOutOfMemory && dm_trim(dev)) {
         (void) hipGetLastError();
@@ -237,6 +264,7 @@ hipError_t dm_malloc(void **p, size_t bytes, bool shareable = false)
 hipError_t dm_reserve(size_t bytes)
 {
     if (!g_devmem.enabled() || bytes < DEVMEM_MIN_FILED) return hipSuccess;
+    bytes = dm_size_class(bytes);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     void *p = nullptr;
@@ -286,6 +314,7 @@ hipError_t dm_free(void *p)
                     g_devmem.filed[d].erase(last);
                 }
             }
+            if (!over.empty() && g_devmem.verbose()) fprintf(stderr, "[devmem] over the cap of %.1f GiB: %zu block(s) back to the driver\n", g_devmem.cap[d] / 1073741824.0, over.size());
             for (auto &q : over) dm_driver_free(q.first, d, q.second);
             if (have_cur && cur != d) (void) hipSetDevice(cur);
             return hipSuccess;
@@ -379,13 +408,15 @@ struct commet_ctx {
     // streams at once (the compute-bound hist / scatter1 of one chunk overlap the HBM-bound scatter2 / build of another)
     struct PartWs {
         uint32_t *bufA = nullptr, *bufB = nullptr;
-        uint64_t cap_keys = 0;
+        uint64_t cap_keys = 0, cap_b = 0;                          // bufA in keys; bufB in words (fewer in the packed geometry)
         uint32_t *hist = nullptr, *wl = nullptr;
         uint64_t *off = nullptr, *goff = nullptr;   // bucket offsets in keys / in 8-byte groups (packed final level)
         unsigned long long *cur2 = nullptr, *blockoff = nullptr;   // final-bucket cursors; scatter1 start positions [workgroup][coarse bucket]
         uint32_t *blockcnt = nullptr;                              // keys per [scatter1 workgroup][coarse bucket]
         uint32_t *items = nullptr, *itemblk = nullptr;             // ragged sets: the chunk's item list and the builder's block sums (index_part.hpp, LIST)
         uint64_t items_cap = 0, itemblk_cap = 0;
+        uint64_t items_set = 0, items_first = 0, items_count = 0;  // whose list the buffer holds: (set uid, read range), no selection — 0 = nobody's
+        uint32_t items_nblk = 0;
         uint32_t nb = 0;
         void release()
         {
@@ -547,6 +578,7 @@ struct commet_readset {
     uint32_t uniform_len = 0;
     uint32_t max_kcnt = 0;
     uint32_t max_len = 0, min_len = 0;
+    uint64_t uid = 0;                          // unique per read set of the process (a pointer may come back; a uid does not)
     uint64_t fhw_total = 0;                    // first-hit windows of all reads for the context's (k, t): sum of max(0, len - t k + 1) (finalize)
     // query list of the tiled search (tile_search.hpp): the set's lane-a addresses sorted by address slice, made on first use
     struct QueryList {

@@ -10,15 +10,18 @@
 //
 // Extra (non-reference) controls: env COMMET_DEVICE=<n> picks the GPU.
 
+#include <dirent.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/un.h>
+#include <sys/wait.h>
 #include <cerrno>
 #include <csignal>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -29,8 +32,11 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/commet_hip.h"
@@ -699,6 +705,274 @@ static int serve(const char *sock_path)
     return 0;
 }
 
+
+// ---- resident mode on several GPUs --------------------------------------------------------------------------------------------
+// `index_and_search --serve SOCKET --devices N` (N = a number, or "all" = the render nodes under /dev/dri; COMMET_SERVER_DEVICES
+// does the same): the process forks one single-device server per GPU BEFORE anything in it has touched the GPU — child d serves
+// SOCKET.d with the loop above on device d (COMMET_SERVER_DEVICE_LIST="0,0,1": the device of every child, for rehearsals on fewer
+// GPUs) — and becomes a ROUTER that never makes a HIP call: it accepts the clients' requests on SOCKET, reads the job's two set
+// configs (-i / -s, relative to the client's directory) and hands the request to the device on which most of the job's files are
+// resident already; a job none of whose files it has seen goes to the device with the fewest requests in flight, then the fewest
+// files.  One thread per client: jobs on different devices run at the same time — what Commet.py does with --sge, and what any
+// caller that starts jobs in parallel gets; per device they queue, as on one GPU.  The reply's bytes are relayed unchanged.
+// Commet.py's local mode starts its jobs one after the other (os.system): it gains the node's MEMORY from this (N x 96 GB of
+// resident sets), not its kernels; the N x N driver (commet_amd/matrix.py) is the way to use all GPUs for one matrix.
+struct Router {
+    std::string sock;
+    std::vector<std::string> child_sock;
+    std::vector<pid_t> child_pid;
+    std::mutex mu;
+    std::map<std::string, std::set<int>> where;       // file (absolute path) -> devices it has been routed to
+    std::vector<uint64_t> inflight, files_on, served;
+    uint64_t requests = 0, routed_by_residency = 0;
+
+    static std::string absolute(const std::string &cwd, const std::string &p) { return (!p.empty() && p[0] == '/') ? p : cwd + "/" + p; }
+
+    // the files of the job's index and search sets (what a request's -i / -s name), as far as they can be read here
+    static std::vector<std::string> job_files(const std::vector<std::string> &strs)
+    {
+        std::vector<std::string> out;
+        for (size_t i = 2; i + 1 < strs.size(); ++i) {
+            if (strs[i] != "-i" && strs[i] != "-s") continue;
+            std::ifstream in(absolute(strs[0], strs[i + 1]).c_str());
+            std::string line;
+            while (in.good() && std::getline(in, line)) {
+                const size_t colon = line.find(':');
+                if (colon != std::string::npos) line = line.substr(colon + 1);
+                std::stringstream ss(line);
+                std::string item;
+                while (std::getline(ss, item, ';')) {
+                    const size_t comma = item.find(',');
+                    if (comma != std::string::npos) item = item.substr(0, comma);
+                    trim_spaces(item);
+                    if (!item.empty()) out.push_back(absolute(strs[0], item));
+                }
+            }
+        }
+        return out;
+    }
+
+    int pick(const std::vector<std::string> &files)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const int n = (int) child_sock.size();
+        std::vector<int> have(n, 0);
+        for (const std::string &f : files) {
+            auto it = where.find(f);
+            if (it != where.end())
+                for (int d : it->second) ++have[d];
+        }
+        int best = 0;
+        for (int d = 1; d < n; ++d) {
+            if (have[d] != have[best]) {
+                if (have[d] > have[best]) best = d;
+            } else if (inflight[d] != inflight[best]) {
+                if (inflight[d] < inflight[best]) best = d;
+            } else if (files_on[d] < files_on[best]) {
+                best = d;
+            }
+        }
+        if (have[best] > 0) ++routed_by_residency;
+        for (const std::string &f : files)
+            if (where[f].insert(best).second) ++files_on[best];
+        ++inflight[best], ++served[best], ++requests;
+        return best;
+    }
+};
+
+static bool send_request(int fd, const std::vector<std::string> &strs)
+{
+    const uint32_t n = (uint32_t) strs.size();
+    bool ok = write_all(fd, &n, 4);
+    for (const std::string &x : strs) {
+        const uint32_t len = (uint32_t) x.size();
+        ok = ok && write_all(fd, &len, 4) && (len == 0 || write_all(fd, x.data(), len));
+    }
+    return ok;
+}
+
+static int connect_to(const std::string &path)
+{
+    const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    if (fd < 0 || path.size() >= sizeof addr.sun_path) return -1;
+    strcpy(addr.sun_path, path.c_str());
+    if (connect(fd, (sockaddr *) &addr, sizeof addr) != 0) {
+        close(fd);
+        return -1;
+    }
+    return fd;
+}
+
+// one request through child `d`: the reply (exit code, stdout, stderr) as raw bytes
+static bool ask_child(const Router &r, int d, const std::vector<std::string> &strs, int32_t &code, std::string &so, std::string &se)
+{
+    const int fd = connect_to(r.child_sock[(size_t) d]);
+    if (fd < 0) return false;
+    uint64_t lo = 0, le = 0;
+    bool ok = send_request(fd, strs) && read_all(fd, &code, 4) && read_all(fd, &lo, 8) && lo < (1ull << 32);
+    if (ok) so.resize(lo), ok = lo == 0 || read_all(fd, &so[0], lo);
+    ok = ok && read_all(fd, &le, 8) && le < (1ull << 32);
+    if (ok) se.resize(le), ok = le == 0 || read_all(fd, &se[0], le);
+    close(fd);
+    return ok;
+}
+
+static int count_render_nodes()
+{
+    int n = 0;
+    if (DIR *d = opendir("/dev/dri")) {
+        while (dirent *e = readdir(d))
+            if (!strncmp(e->d_name, "renderD", 7)) ++n;
+        closedir(d);
+    }
+    return n;
+}
+
+static int serve_multi(const char *sock_path, int n_dev)
+{
+    signal(SIGPIPE, SIG_IGN);
+    Router r;
+    r.sock = sock_path;
+    std::vector<int> dev_of((size_t) n_dev);
+    for (int d = 0; d < n_dev; ++d) dev_of[(size_t) d] = d;
+    if (const char *lst = getenv("COMMET_SERVER_DEVICE_LIST")) {      // rehearsals: which device every child takes
+        std::stringstream ss(lst);
+        std::string item;
+        for (int d = 0; d < n_dev && std::getline(ss, item, ','); ++d) dev_of[(size_t) d] = atoi(item.c_str());
+    }
+    // the children first: nothing in this process has touched the GPU yet (no HIP call is ever made by the router)
+    for (int d = 0; d < n_dev; ++d) {
+        const std::string cs = std::string(sock_path) + "." + std::to_string(d);
+        const pid_t pid = fork();
+        if (pid < 0) {
+            std::cerr << "Error: cannot start the server of device " << d << "\n";
+            for (pid_t p : r.child_pid) kill(p, SIGTERM);
+            return 1;
+        }
+        if (pid == 0) {
+            setenv("COMMET_DEVICE", std::to_string(dev_of[(size_t) d]).c_str(), 1);
+            _exit(serve(cs.c_str()));
+        }
+        r.child_sock.push_back(cs), r.child_pid.push_back(pid);
+    }
+    r.inflight.assign((size_t) n_dev, 0), r.files_on.assign((size_t) n_dev, 0), r.served.assign((size_t) n_dev, 0);
+    const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sun_family = AF_UNIX;
+    bool up = ls >= 0 && strlen(sock_path) < sizeof addr.sun_path;
+    if (up) {
+        strcpy(addr.sun_path, sock_path);
+        unlink(sock_path);
+        // (the clients' socket appears once every child listens on its own: a client that finds it may send at once)
+        for (int d = 0; d < n_dev && up; ++d) {
+            struct stat sb;
+            int tries = 0;
+            while (stat(r.child_sock[(size_t) d].c_str(), &sb) != 0 && tries++ < 1200) {
+                int st = 0;
+                if (waitpid(r.child_pid[(size_t) d], &st, WNOHANG) > 0) { up = false; break; }
+                usleep(50000);
+            }
+            up = up && stat(r.child_sock[(size_t) d].c_str(), &sb) == 0;
+        }
+        up = up && bind(ls, (sockaddr *) &addr, sizeof addr) == 0 && listen(ls, 64) == 0;
+    }
+    if (!up) {
+        std::cerr << "Error: cannot serve on " << sock_path << " with " << n_dev << " device(s)\n";
+        for (pid_t p : r.child_pid) kill(p, SIGTERM);
+        return 1;
+    }
+    std::cerr << "index_and_search: serving on " << sock_path << " with " << n_dev << " device servers\n";
+    std::atomic<int> active{0};                                     // client threads under way (detached: a server lives for days)
+    bool stop = false;
+    while (!stop) {
+        const int fd = accept(ls, nullptr, nullptr);
+        if (fd < 0) {
+            if (errno != EINTR) usleep(20000);
+            continue;
+        }
+        uint32_t n = 0;
+        std::vector<std::string> strs;
+        bool ok = read_all(fd, &n, 4) && n >= 2 && n < 4096;
+        for (uint32_t i = 0; ok && i < n; ++i) {
+            uint32_t len = 0;
+            ok = read_all(fd, &len, 4) && len < (1u << 20);
+            if (!ok) break;
+            std::string x(len, '\0');
+            ok = len == 0 || read_all(fd, &x[0], len);
+            strs.push_back(x);
+        }
+        if (!ok) {
+            close(fd);
+            continue;
+        }
+        if (strs.size() == 3 && strs[2] == "--server-stop") {
+            close(fd);
+            stop = true;
+            break;
+        }
+        if (strs.size() == 3 && strs[2] == "--server-stats") {      // the children's lines, then the router's own
+            std::string so, se;
+            for (int d = 0; d < n_dev; ++d) {
+                int32_t c = 0;
+                std::string o, e;
+                if (ask_child(r, d, strs, c, o, e)) so += "device server " + std::to_string(d) + ": " + o;
+            }
+            {
+                std::lock_guard<std::mutex> lk(r.mu);
+                std::ostringstream os;
+                os << "router: requests " << r.requests << ", routed to a device that held files of the job " << r.routed_by_residency << ", per device";
+                for (int d = 0; d < n_dev; ++d) os << " " << r.served[(size_t) d];
+                os << "\n";
+                so += os.str();
+            }
+            const int32_t c32 = 0;
+            const uint64_t lo = so.size(), le = 0;
+            (void) (write_all(fd, &c32, 4) && write_all(fd, &lo, 8) && write_all(fd, so.data(), lo) && write_all(fd, &le, 8));
+            close(fd);
+            continue;
+        }
+        ++active;
+        std::thread([&r, &active, fd, strs]() {
+            const int d = r.pick(Router::job_files(strs));
+            int32_t code = 1;
+            std::string so, se;
+            if (!ask_child(r, d, strs, code, so, se)) {
+                code = 1;
+                se = "Error: the index_and_search server of device " + std::to_string(d) + " did not answer\n";
+                so.clear();
+            }
+            {
+                std::lock_guard<std::mutex> lk(r.mu);
+                --r.inflight[(size_t) d];
+            }
+            const uint64_t lo = so.size(), le = se.size();
+            (void) (write_all(fd, &code, 4) && write_all(fd, &lo, 8) && write_all(fd, so.data(), lo) && write_all(fd, &le, 8) &&
+                    write_all(fd, se.data(), le));
+            close(fd);
+            --active;
+        }).detach();
+    }
+    while (active.load() > 0) usleep(10000);                        // (requests under way finish first)
+    for (int d = 0; d < n_dev; ++d) {
+        const int fd = connect_to(r.child_sock[(size_t) d]);
+        if (fd >= 0) {
+            (void) send_request(fd, {"/", "index_and_search", "--server-stop"});
+            close(fd);
+        }
+    }
+    for (pid_t p : r.child_pid) {
+        int st = 0;
+        (void) waitpid(p, &st, 0);
+    }
+    close(ls);
+    unlink(sock_path);
+    return 0;
+}
+
 // forwards this invocation to a resident server; -1 = no server there (run locally)
 static int forward(const char *sock_path, int argc, char **argv)
 {
@@ -742,7 +1016,19 @@ static int forward(const char *sock_path, int argc, char **argv)
 
 int main(int argc, char **argv)
 {
-    if (argc == 3 && !strcmp(argv[1], "--serve")) return serve(argv[2]);
+    if (argc >= 3 && !strcmp(argv[1], "--serve")) {
+        const char *nd = (argc == 5 && !strcmp(argv[3], "--devices")) ? argv[4] : (argc == 3 ? getenv("COMMET_SERVER_DEVICES") : nullptr);
+        if (argc != 3 && !nd) {
+            std::cerr << "Usage : ./index_and_search --serve <socket> [--devices <n>|all]\n";
+            return 1;
+        }
+        const int n_dev = !nd ? 1 : !strcmp(nd, "all") ? count_render_nodes() : atoi(nd);
+        if (nd && n_dev < 1) {
+            std::cerr << "Error: --devices " << nd << ": no device\n";
+            return 1;
+        }
+        return nd ? serve_multi(argv[2], n_dev) : serve(argv[2]);
+    }
     if (const char *srv = getenv("COMMET_SERVER")) {
         const int rc = forward(srv, argc, argv);
         if (rc >= 0) return rc;

@@ -66,3 +66,41 @@ def test_jobs_sharing_a_pass_equal_the_jobs_alone(k, t, L, max_kmer):
             assert np.array_equal(t3[j], a[0][0]) and s3[j]["shared"] == a[1][0]["shared"] and s3[j]["searched"] == a[1][0]["searched"]
         t4, s4, _ = ctx.index_many_and_search(irs[:1], srs, index_selects=sels[:1])
         assert np.array_equal(t4[0], tags[0]) and s4[0]["shared"] == stats[0]["shared"]
+
+
+def test_shared_passes_fall_back_to_the_jobs_alone_when_eight_slots_do_not_fit():
+    """commet_index_many_and_search on a device that has no room for the eight filter slots of a shared pass (16 GiB + 4 GiB of
+    interleaved A planes at k = 32): the jobs run one after the other, as include/commet_hip.h promises — commet_index_and_search
+    itself degrades the same way.  The device is filled with a read set of the right capacity (its planes are one allocation)."""
+    import commet_amd
+    from commet_amd import synth
+    k, t, L, n_i, n_s = 32, 2, 100, 300_000, 400_000
+    rng = np.random.default_rng(5)
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("index_mode", 2)
+        ctx.set_option("max_kmer", 9_000_000)
+        srs = commet_amd.ReadSet.from_files(ctx, [synth.synth_set(0, n_s, L)])
+        irs = [commet_amd.ReadSet.from_files(ctx, [synth.synth_set(s, n_i, L)]) for s in (1, 2, 3)]
+        sels = [None, _bits(rng, n_i, 0.5), None]
+        alone = [ctx.index_and_search(rs, [srs], index_select=sel) for rs, sel in zip(irs, sels)]      # (two slots, workspaces: allocated now)
+        commet_amd.device_cache_trim(ctx.device)
+        free, total = ctx.device_memory()
+        hog_bytes = free - (9 << 30)                     # leaves less than the 20 GiB a shared pass asks for
+        assert hog_bytes > (64 << 30)
+        hog = commet_amd.ReadSet(ctx, 1, int(hog_bytes / 0.375))      # 12 bytes of planes per 32 bases
+        try:
+            before = commet_amd.device_alloc_stats(ctx.device)
+            tags, stats, info = ctx.index_many_and_search(irs, srs, index_selects=sels)
+            assert info["search_launches"] >= len(irs)                 # no shared pass: every job searched on its own
+            for j, a in enumerate(alone):
+                assert np.array_equal(tags[j], a[0][0]), j
+                assert {f: stats[j][f] for f in ("indexed", "searched", "shared")} == {f: a[1][0][f] for f in ("indexed", "searched", "shared")}, j
+            assert commet_amd.device_alloc_stats(ctx.device)["calls"] > before["calls"]      # the driver WAS asked (and said no)
+        finally:
+            hog.close()
+        # with the memory back the same call shares passes again
+        ctx.set_option("kernel_timing", 1)
+        t2, s2, i2 = ctx.index_many_and_search(irs, srs, index_selects=sels)
+        assert "search_group8_kernel" in ctx.kernel_times() and i2["search_launches"] < len(irs)
+        for j in range(len(irs)):
+            assert np.array_equal(t2[j], tags[j])

@@ -99,3 +99,66 @@ def test_full_mode_and_changed_file(server, tmp_path):
     line3 = [ln for ln in r3.stdout.decode().splitlines() if ln.startswith("[indexed")][-1]
     assert line3.startswith("[indexed 100,") and line3 != line1
     assert _stats()["loads"] == s2["loads"] + 1
+
+
+def test_multi_device_server_routes_by_resident_sets_and_runs_devices_side_by_side(tmp_path):
+    """`--serve SOCKET --devices 2`: the process forks one single-device server per GPU before it touches the GPU and routes the clients'
+    requests (round 6).  Rehearsed on ONE GPU (COMMET_SERVER_DEVICE_LIST=0,0: both children on device 0): jobs started in parallel are
+    answered with the bytes of the plain tool, a job goes back to the device server that holds its files, and both servers get work."""
+    import numpy as np  # noqa: F401
+    import util
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(12)
+    d = tmp_path / "w"
+    os.makedirs(d)
+    pools = [util.random_reads(rng, 400, 40, 120) for _ in range(4)]
+    for i, pool in enumerate(pools):
+        util.write_fasta(str(d / f"a{i}.fa"), pool)
+        util.write_fasta(str(d / f"b{i}.fa"), util.related_reads(rng, pool, 300, 40, 120, share=0.6))
+        (d / f"i{i}.txt").write_text(f"A{i}:a{i}.fa\n")
+        (d / f"s{i}.txt").write_text(f"B{i}:b{i}.fa\n")
+    env0 = {k: v for k, v in os.environ.items() if k != "COMMET_SERVER"}
+
+    def cmd(i, out):
+        return [cli.TOOL, "-i", f"i{i}.txt", "-s", f"s{i}.txt", "-o", out, "-l", out, "-k", "20", "-t", "2"]
+
+    plain = []
+    for i in range(4):                                             # the plain tool, one process per job
+        r = subprocess.run(cmd(i, f"p{i}"), cwd=str(d), env=env0, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0
+        plain.append([ln for ln in r.stdout.decode().splitlines() if ln.startswith("[indexed")][-1])
+    sock = str(tmp_path / "m.sock")
+    env_srv = dict(env0, COMMET_SERVER_DEVICE_LIST="0,0")
+    p = subprocess.Popen([cli.TOOL, "--serve", sock, "--devices", "2"], env=env_srv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        for _ in range(1200):
+            if os.path.exists(sock) or p.poll() is not None:
+                break
+            time.sleep(0.1)
+        assert p.poll() is None and os.path.exists(sock), "the multi-device server did not come up"
+        env_c = dict(env0, COMMET_SERVER=sock)
+
+        def job(i, rnd):
+            r = subprocess.run(cmd(i, f"m{rnd}_{i}"), cwd=str(d), env=env_c, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()
+            return [ln for ln in r.stdout.decode().splitlines() if ln.startswith("[indexed")][-1]
+
+        for rnd in range(3):                                       # four jobs at a time, three rounds
+            with ThreadPoolExecutor(4) as pool:
+                got = list(pool.map(lambda i: job(i, rnd), range(4)))
+            assert got == plain
+            for i in range(4):
+                a = open(d / f"p{i}" / f"b{i}.fa_in_A{i}.bv", "rb").read()
+                b = open(d / f"m{rnd}_{i}" / f"b{i}.fa_in_A{i}.bv", "rb").read()
+                assert a == b
+        out = subprocess.run([cli.TOOL, "--server-stats"], env=env_c, stdout=subprocess.PIPE, check=True).stdout.decode()
+        per_dev = [dict((k, int(v)) for k, v in re.findall(r"(requests|cache hits|loads) (\d+)", ln)) for ln in out.splitlines() if ln.startswith("device server")]
+        router = [ln for ln in out.splitlines() if ln.startswith("router:")][0]
+        assert len(per_dev) == 2 and all(x["requests"] >= 1 for x in per_dev)                 # both device servers got jobs
+        assert sum(x["requests"] for x in per_dev) == 12
+        assert sum(x["loads"] for x in per_dev) == 8 and sum(x["cache hits"] for x in per_dev) == 16   # every set parsed ONCE: rounds 2 and 3 went where the files were
+        assert int(re.search(r"held files of the job (\d+)", router).group(1)) == 8
+    finally:
+        subprocess.run([cli.TOOL, "--server-stop"], env=dict(env0, COMMET_SERVER=sock), timeout=120)
+        p.wait(timeout=120)
+    assert not os.path.exists(sock) and not os.path.exists(sock + ".0")

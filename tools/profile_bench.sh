@@ -10,7 +10,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --no-matrix "$@" > $O/bench.json 2> $O/bench.err
 # one index lane here: with two, kernels of both lanes run at once and their durations are not additive
-B="--cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix"
+# (the counter passes time ONE workload: no ragged leg beside it — pass --ragged-only to profile the ragged step itself)
+B="--cpu-sample 0 --no-probe-count --no-kernel-times --no-matrix --ragged none"
 COMMET_INDEX_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 $B "$@" > $O/kt.log 2>&1
 COMMET_INDEX_LANES=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pf.log 2>&1
 COMMET_INDEX_LANES=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $O/pw.log 2>&1
