@@ -830,40 +830,57 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
             note(f"J3 jobs of set {i} done ({prof['jobs']} so far)")
 
         try:
-            for ref in refs:
-                wait_for(ref)
-                pending = [i for (r, i) in mine if r == ref]
-                done_here = list(pending)
-                while pending:
-                    # J1 of `ref` against the targets that are resident by now — all of them as a rule; at the start of a run with several
-                    # ranks whichever have arrived, the others in a second call (one more index build of S_ref instead of an idle GPU)
-                    targets = [i for i in pending if loader is None or ready[i].is_set()]
-                    if not targets:
-                        wait_for(pending[0])
-                        continue
-                    pending = [i for i in pending if i not in targets]
-                    for s_need in targets:
-                        wait_for(s_need)                             # (resident: raises what the loader raised, if it did)
+            # Which reference set next (round 6): the first of the rank's list that is resident TOGETHER with one of its targets — a rank of a
+            # node starts on whatever pair has arrived instead of waiting for the first reference set of its list (tools/schedule_sim.py on
+            # configs[3]: 2.69 -> 2.53 s at eight ranks, 4.24 -> 3.97 s at four).  A reference set some of whose targets are still on their way
+            # is taken up again later (one more index build of S_ref instead of an idle GPU, as before).  One rank, or everything loaded
+            # first: the list's own order.
+            def there(s_):
+                return loader is None or ready[s_].is_set()
+
+            left = {ref: [i for (r, i) in mine if r == ref] for ref in refs}
+            while left:
+                ref = next((r_ for r_ in refs if r_ in left and there(r_) and any(there(i) for i in left[r_])), None)
+                if ref is None:                                      # nothing can start: until some set arrives (errors of the loader / the filters / another rank end the wait)
                     w0 = time.perf_counter()
-                    tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
-                    prof["j1_builds"] += 1
-                    reads_searched += sum(considered[i] for i in targets)
-                    _acc(inf1, 1, ("J1", ref, targets))
-                    # J2 of every target: X_i = S_i restricted to (S_i in S_ref); S_ref in X_i
-                    for i, (T2, st2, index_ms) in zip(targets, jobs_on_one_search_set(targets, ref, list(tags1))):
-                        for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
-                            out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
-                        out_log(out_dir, names[ref], names[i], st2, index_ms, time.perf_counter() - w0)
-                        shared[(ref, i)] = st2["shared"]
-                        kept_T2[(ref, i)] = T2
-                        reads_searched += considered[ref]
-                note(f"J1 and J2 jobs of set {ref} done ({prof['jobs']} so far)")
+                    polls = 0
+                    while not any(there(r_) and any(there(i) for i in left[r_]) for r_ in left):
+                        if filter_err:
+                            raise filter_err[0]
+                        if load_err:
+                            raise load_err[0]
+                        polls += 1
+                        if world > 1 and polls % 125 == 0 and hasattr(ranks, "check"):
+                            ranks.check()
+                        time.sleep(0.002)
+                    set_wait[0] += time.perf_counter() - w0
+                    continue
+                targets = [i for i in left[ref] if there(i)]
+                left[ref] = [i for i in left[ref] if i not in targets]
+                for s_need in [ref] + targets:
+                    wait_for(s_need)                                 # (resident: raises what the loader raised, if it did)
+                w0 = time.perf_counter()
+                tags1, st1, inf1 = eng.index_and_search(sets[ref], [sets[i] for i in targets], sel[ref], [sel[i] for i in targets])
+                prof["j1_builds"] += 1
+                reads_searched += sum(considered[i] for i in targets)
+                _acc(inf1, 1, ("J1", ref, targets))
+                # J2 of every target: X_i = S_i restricted to (S_i in S_ref); S_ref in X_i
+                for i, (T2, st2, index_ms) in zip(targets, jobs_on_one_search_set(targets, ref, list(tags1))):
+                    for f, c, b in zip(files[ref], counts[ref], split_bits(T2, counts[ref])):
+                        out_bv(out_dir + os.path.basename(f) + "_in_" + names[i] + ".bv", f + " in " + names[i], c, b)
+                    out_log(out_dir, names[ref], names[i], st2, index_ms, time.perf_counter() - w0)
+                    shared[(ref, i)] = st2["shared"]
+                    kept_T2[(ref, i)] = T2
+                    reads_searched += considered[ref]
+                if not left[ref]:
+                    del left[ref]
+                    note(f"J1 and J2 jobs of set {ref} done ({prof['jobs']} so far)")
                 # The J3 jobs — (ref, i) searches S_i — are kept back so that the J3 jobs of a target share passes as well, but no longer than
                 # needed: a target's batch runs as soon as the last of its reference sets on this rank has been through J2 (its J2 bitmaps are
                 # freed with it, its files are on disk: a late failure loses little).  The files a job writes do not depend on when it runs.
-                for i in done_here:
+                for i in targets:
                     refs_left[i] -= 1
-                for i in sorted(done_here):
+                for i in sorted(targets):
                     if refs_left[i] == 0:
                         j3_of(i)
             for i in sorted(i_ for i_, n_ in refs_left.items() if n_ > 0):     # (never: every target's references are in `refs`)
