@@ -43,6 +43,8 @@ def fuzz_one(seed):
             ctx.set_option("count_probes", int(counting))
             ctx.set_option("index_mode", mode)
             ctx.set_option("chunk_group", 1 + seed % 8)
+            # (round 6) ragged sets: hist / scatter1 on the chunk's item list, or — one seed in five — on the round planner
+            ctx.set_option("part_list", int(seed % 5 == 3))
             if not counting and seed % 3 == 1:
                 ctx.set_option("sparse_search", 2)     # passes over a selection walk the list of their reads (kernels.hpp, ActiveList)
             if forced:
@@ -54,6 +56,7 @@ def fuzz_one(seed):
                 ctx.set_option("slice_wide_words", [0, 8][(seed // 3) % 2])  # ... in one pass or in passes of 256 chunks
                 ctx.set_option("max_kmer", max_kmer)
                 ctx.set_option("tiled_search", 2 if seed % 2 == 0 else 1)
+                ctx.set_option("tq_hit_cap", [1024, 0, 2][(seed // 2) % 3])  # (round 6) the replay's bounded hit list, and pieces that overflow it
                 ctx.set_option("chunk_group", 1 + seed % 3)
             irs, isel = load_set(commet_amd, ctx, scn.sets[scn.index_name], scn.dir)
             names = sorted(scn.search_names)
