@@ -247,7 +247,8 @@ bool tiled_ok(const commet_ctx *c, const commet_readset *rs, int g)
     // against the fused kernels: configs[1] search 9.4 -> 8.6 ms, configs[2] jobs 1.92-1.96 -> 1.84 s.
     const uint64_t est = rs->fhw_total * 8;
     // (a list above the cap when its memory was set aside beforehand, commet_readset_reserve_cache: the allocation is then not on this job's path)
-    if (rs->n_reads < (1ull << 20) || (est > c->ql_max_list && !rs->ql_reserved.load())) return false;
+    const bool set_aside = rs->ql_reserved.load() && rs->ql_reserved_at.load() == g_devmem.trims.load();   // (no trim since: the blocks are still filed)
+    if (rs->n_reads < (1ull << 20) || (est > c->ql_max_list && !set_aside)) return false;
     // A list of more than 4 GiB (sets of 15 M reads and up) is built for a set's SECOND such scan: a set that is scanned once —
     // every target of a rank that holds few pairs of a large matrix — would pay 12 ms of kernels and an 11 GB allocation for a
     // 7.6 ms gain (one J2 / J3 job of configs[3]: 54.7 against 62.3 ms), a set that is scanned again and again — every set of a
@@ -648,10 +649,12 @@ int commet_readset_reserve_cache(commet_ctx *c, const commet_readset *rs)
     uint64_t b[6];
     {
         std::lock_guard<std::mutex> lk(c->ql_mu);
-        if (rs->ql.built || rs->ql_reserved.load() || !g_devmem.enabled() || !query_list_blocks(c, rs, b)) return 0;
+        const bool still = rs->ql_reserved.load() && rs->ql_reserved_at.load() == g_devmem.trims.load();
+        if (rs->ql.built || still || !g_devmem.enabled() || !query_list_blocks(c, rs, b)) return 0;
     }
     for (int i = 0; i < 6; ++i)
         if (b[i] && dm_reserve((size_t) b[i]) != hipSuccess) return 0;      // no room: the set keeps the cap's rule
+    rs->ql_reserved_at.store(g_devmem.trims.load());
     rs->ql_reserved.store(true);
     return 0;
 }

@@ -72,6 +72,7 @@ struct DevMemCache {
     // what the DRIVER was asked for, per device (commet_device_alloc_stats): time the calling thread spent inside hipMalloc /
     // hipMallocAsync, bytes and calls — a box that charges for a process's first use of device memory shows here, not in kernel time
     std::atomic<uint64_t> drv_ns[16], drv_bytes[16], drv_calls[16];
+    std::atomic<uint64_t> trims{0};                                // times filed blocks went back to the driver (dm_trim): what was set aside before is gone
     DevMemCache()
     {
         for (int d = 0; d < 16; ++d) drv_ns[d] = 0, drv_bytes[d] = 0, drv_calls[d] = 0;
@@ -161,6 +162,7 @@ void dm_driver_free(void *q, int dev, bool pooled)
 // gives every filed block of `device` (-1: all) back to the driver; returns the bytes released
 size_t dm_trim(int device)
 {
+    g_devmem.trims += 1;
     std::vector<std::pair<int, std::pair<void *, bool>>> drop;
     size_t bytes = 0;
     {
@@ -598,6 +600,7 @@ struct commet_readset {
     };
     mutable QueryList ql;
     mutable uint32_t ql_wanted = 0;                 // scans that would have taken the tiled search had the set's (large) list existed (tiled_ok)
+    mutable std::atomic<uint64_t> ql_reserved_at{0};  // g_devmem.trims when the memory was set aside: a trim since then has given it back
     mutable std::atomic<bool> ql_reserved{false};   // the memory of the set's list waits in the library's device cache (commet_readset_reserve_cache): a list above the cap may be built
     mutable bool in_job = false;                    // part of the commet_index_and_search call that is running: its list stays
     bool host_packed = false;                  // some reads were packed on the host (host/ingest_pack.hpp): counts come from kmer_counts_kernel

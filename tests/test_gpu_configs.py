@@ -396,7 +396,7 @@ def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
     sixteen; when most of those are found there (reads that will be found early whatever the plan) the job goes on with
     the narrow tables, group by group, else with the wide rows.  Either way the CPU checker's bits."""
     import commet_amd
-    k, t, L, n_chunks = 16, 2, 80, 4200
+    k, t, L, n_chunks = 16, 2, 80, 2200       # (round 6: 4200 before; nine groups of 256 chunk filters still, half the CPU checker's time)
     rng = np.random.default_rng(99)
     idx_reads = util.random_reads(rng, 2 * n_chunks, L, L, n_rate=0.002)
     early = [idx_reads[int(i)] for i in rng.integers(0, 500, size=4000)]        # copies of reads of the first 250 chunks
@@ -413,7 +413,7 @@ def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
             tags, stats, info = ctx.index_and_search(irs, [qrs])
             times = ctx.kernel_times()
         chunks = oracle_pool.chunks_from_counts(kc, 1)
-        assert info["n_chunks"] == len(chunks) > 4000
+        assert info["n_chunks"] == len(chunks) > 2000
         groups = (len(chunks) + 255) // 256
         # the probe is one launch of the narrow kernel; then either every group with it, or one wide pass
         if kernel == "search_sliced_kernel":
