@@ -158,7 +158,12 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
         }
     }
     const int mode = uni ? 1 : list ? 2 : 0;
-    HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
+    // TIMING BOUND ONLY (COMMET_HIST_REUSE=1, never set by the product): a workspace that counted this very chunk last time keeps its
+    // histogram — what the index costs without the counting pass, measured on a benchmark's steady state
+    static const bool hist_reuse_on = getenv("COMMET_HIST_REUSE") && atoi(getenv("COMMET_HIST_REUSE")) != 0;
+    const bool hist_held = hist_reuse_on && !d_sel && !d_ids && ws.hist_set == rs->uid && ws.hist_first == first && ws.hist_count == count;
+    ws.hist_set = (d_sel || d_ids) ? 0 : rs->uid, ws.hist_first = first, ws.hist_count = count;
+    if (!hist_held) HIP_OK(hipMemsetAsync(ws.hist, 0, (g.nb + 1) * sizeof(uint32_t), stream));
     // scatter1's grid fixes how the read range is cut; hist counts with the same cut, two ranges per workgroup
     const uint32_t grid1 = (uint32_t) std::min<uint64_t>(S1_GRID_MAX, (count + 63) / 64);
     {
@@ -171,7 +176,7 @@ int launch_index_partitioned(commet_ctx *c, const commet_readset *rs, uint64_t f
                                                                                                              : (const void *) part_hist_kernel<uint64_t, 0, false>)
                               : (mode == 1 ? (const void *) part_hist_kernel<uint32_t, 1, true> : mode == 2 ? (const void *) part_hist_kernel<uint32_t, 2, true>
                                                                                                             : (const void *) part_hist_kernel<uint32_t, 0, true>);
-        for (uint32_t b_lo = 0; b_lo < g.nb; b_lo += HIST_MAX_BUCKETS) {
+        for (uint32_t b_lo = 0; b_lo < g.nb && !hist_held; b_lo += HIST_MAX_BUCKETS) {
             const uint32_t n_b = std::min<uint32_t>(HIST_MAX_BUCKETS, g.nb - b_lo);
             const size_t lds = ((size_t) n_b + 2 * HIST_NT + 24) * 4 + (size_t) HIST_NT * 8;
             HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));

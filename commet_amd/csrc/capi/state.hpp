@@ -419,6 +419,7 @@ struct commet_ctx {
         uint64_t items_cap = 0, itemblk_cap = 0;
         uint64_t items_set = 0, items_first = 0, items_count = 0;  // whose list the buffer holds: (set uid, read range), no selection — 0 = nobody's
         uint32_t items_nblk = 0;
+        uint64_t hist_set = 0, hist_first = 0, hist_count = 0;     // (timing bound COMMET_HIST_REUSE only: whose histogram the workspace holds)
         uint32_t nb = 0;
         void release()
         {
