@@ -18,8 +18,8 @@ for step in "$@"; do
   case $kind in
     env:*) export "${step#env:}";;
     tests) timeout -k 10 1100 python3 -m pytest -m gpu -x -q --durations=10 ${arg:-tests} > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }; tail -3 $O/tests.log;;
-    bench) nb=$((nb+1)); f=$O/bench$([ $nb -gt 1 ] && echo _$nb); python3 bench.py $arg > $f.json 2> $f.err || { tail -20 $f.err; exit 1; }; tail -2 $f.err;;
-    profile) bash tools/profile_bench.sh $N/profile $arg > $O/profile.log 2>&1 || { tail -30 $O/profile.log; exit 1; }; tail -1 $O/profile.log | cut -c1-300;;
+    bench) nb=$((nb+1)); f=$O/bench$([ $nb -gt 1 ] && echo _$nb || true); python3 bench.py $arg > $f.json 2> $f.err || { tail -20 $f.err; exit 1; }; tail -2 $f.err;;
+    profile) bash tools/profile_bench.sh $N/profile $arg > $O/profile.log 2>&1 || { tail -30 $O/profile.log; exit 1; }; (tail -1 $O/profile.log | cut -c1-300) || true;;
     fuzz) n=${arg%%:*}; s=${arg#*:}; timeout -k 10 1100 python3 tools/fuzz_gpu.py $s $n > $O/fuzz_$s.log 2>&1 || { tail -20 $O/fuzz_$s.log; exit 1; }; tail -2 $O/fuzz_$s.log;;
     *) echo "unknown step $step"; exit 2;;
   esac
