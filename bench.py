@@ -207,6 +207,8 @@ def cpu_baseline(args, b0, b1, gpu_info=None):
     n = min(args.cpu_sample, args.reads)
     if n <= 0:
         return None
+    if gpu_info and gpu_info.get("n_chunks", 0) > 64:
+        n = min(n, 50_000)       # (a job of thousands of chunk filters — configs[4] — searches the sample against every one of them: minutes per 1 M reads on a core)
     import numpy as np
     from commet_amd import synth
     L = args.read_len
@@ -619,7 +621,7 @@ def main():
     # ---- untimed extras (rank 0): P_ref, per-kernel times, the random-gather ceiling ---------------------------
     probes, ktimes, gather_ceiling = None, None, None
     if rank == 0:
-        if not args.no_probe_count:
+        if not args.no_probe_count and info["n_chunks"] <= 256:   # (the counting builds replay every chunk one by one: minutes at configs[4]'s 10 421 chunks)
             ctx.set_option("count_probes", 1)     # P_ref of the reference's control flow, detail only
             _, _, inf = ctx.index_and_search(irs, [qrs])
             probes = inf["probes"]
