@@ -119,12 +119,12 @@ int launch_search_group_t(commet_ctx *c, const commet_readset *rs, const FilterG
 }
 
 // mask words (32 first-hit windows each) a read of the set needs per strand and filter in the register-mask kernels
-// (search_group8_kernel, tq_replay_kernel): 2, 3, 4 or 6 — reads of up to 255 bases at k = 32, t = 2 (round 6; 96 windows before)
-constexpr int MASK_MAX_WIN = 192;
+// (search_group8_kernel, tq_replay_kernel): 2, 3, 4, 6 or 8 — reads of up to 318 bases at k = 32, t = 2 (round 6; 96 windows before)
+constexpr int MASK_MAX_WIN = 255;      // (= TQ_MAX_WIN)
 inline int mask_words(const commet_ctx *c, const commet_readset *rs)
 {
     const int64_t fhw = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
-    return fhw <= 64 ? 2 : fhw <= 96 ? 3 : fhw <= 128 ? 4 : 6;
+    return fhw <= 64 ? 2 : fhw <= 96 ? 3 : fhw <= 128 ? 4 : fhw <= 192 ? 6 : 8;
 }
 
 // one pass of rs over the `g` chunk filters in slots 0..g-1 (A planes already interleaved with stride gs)
@@ -144,19 +144,21 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
         const dim3 grid((unsigned) (((al.ids ? n_launch : rs->n_reads) + 255) / 256)), block(256);
-        const int mw = mask_words(c, rs);   // mask words per strand and filter: 2, 3, 4 or 6
+        const int mw = mask_words(c, rs);   // mask words per strand and filter: 2, 3, 4, 6 or 8
         KScope ks(c, "search_group8_kernel", c->stream);
 #define COMMET_G8(W, MW) COMMET_LAUNCH((search_group8_kernel<W, MW>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel, d_tags, d_counters, cstride, al, job_mask, job_tag_words)
         if (c->k <= 32) {
             if (mw == 2) COMMET_G8(uint32_t, 2);
             else if (mw == 3) COMMET_G8(uint32_t, 3);
             else if (mw == 4) COMMET_G8(uint32_t, 4);
-            else COMMET_G8(uint32_t, 6);
+            else if (mw == 6) COMMET_G8(uint32_t, 6);
+            else COMMET_G8(uint32_t, 8);
         } else {
             if (mw == 2) COMMET_G8(uint64_t, 2);
             else if (mw == 3) COMMET_G8(uint64_t, 3);
             else if (mw == 4) COMMET_G8(uint64_t, 4);
-            else COMMET_G8(uint64_t, 6);
+            else if (mw == 6) COMMET_G8(uint64_t, 6);
+            else COMMET_G8(uint64_t, 8);
         }
 #undef COMMET_G8
         HIP_OK(hipGetLastError());
@@ -178,8 +180,8 @@ bool group_searchable(const commet_ctx *c, const commet_readset *rs, int g)
     return c->k >= 2 && nw >= 1 && (uint64_t) g * 2 * nw * 256 * 4 <= (64u << 10);
 }
 
-// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 192 first-hit windows per read in
-// registers (kernels.hpp: two to six mask words per strand and filter); the probe-counting builds exist for groups of <= 4 only
+// groups of 5..8 chunk filters: search_group8_kernel keeps the gathered bits of at most 255 first-hit windows per read in
+// registers (kernels.hpp: two to eight mask words per strand and filter); the probe-counting builds exist for groups of <= 4 only
 bool group8_ok(const commet_ctx *c, const commet_readset *rs)
 {
     const int64_t first_hit_windows = (int64_t) rs->max_len - (int64_t) t_eff(c, rs) * c->k + 1;
@@ -451,7 +453,8 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
         if (mw == 2) COMMET_TQ_REPLAY(W, GS, 2);   \
         else if (mw == 3) COMMET_TQ_REPLAY(W, GS, 3); \
         else if (mw == 4) COMMET_TQ_REPLAY(W, GS, 4); \
-        else COMMET_TQ_REPLAY(W, GS, 6);           \
+        else if (mw == 6) COMMET_TQ_REPLAY(W, GS, 6); \
+        else COMMET_TQ_REPLAY(W, GS, 8);           \
     } while (0)
             if (c->k <= 32) {
                 if (g == 1) COMMET_TQ_REPLAY_MW(uint32_t, 1);

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     __shared__ uint32_t tail_req[256], tail_bits[256];
     __shared__ uint32_t tail_n;
     // the first-hit candidates of a scan are probed by the whole workgroup as well (see (2) below)
-    __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (8 bits: <= 192 first-hit windows)
+    __shared__ uint16_t cand[256 * G8_HEAVY];            // thread (8 bits) | window (8 bits: <= 255 first-hit windows)
     __shared__ uint32_t full_hit[MW][256];
     __shared__ uint32_t cand_n;
     const bool multi = job_mask != 0;
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     const int sh = T::BITS - k;
     const W mask = (k == T::BITS) ? ~(W) 0 : (((W) 1 << k) - 1);
     const int last = (int) len - 1;
-    const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW (MW = 2, 3, 4 or 6: mask_words, capi/search_dispatch.hpp)
+    const int pe = last - (t - 1) * k;     // last window that can be a first hit; the host guarantees pe - (k-1) < 32 * MW (MW = 2, 3, 4, 6 or 8: mask_words, capi/search_dispatch.hpp)
     const int q0 = k - 1;
     uint32_t fm[MW][GS], rm[MW][GS];       // [word of the 32 * MW relative positions][filter]
 #pragma unroll

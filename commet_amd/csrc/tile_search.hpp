@@ -49,7 +49,8 @@ namespace commet {
 #endif
 constexpr uint32_t TQ_PIECE = COMMET_TQ_PIECE;   // reads per piece = threads of the replay workgroup (1024: 9.5 ms, 512: 7.1, 256: 6.8 on configs[1] in round 2; round 5: 256 / 128 / 64: 4.54 / 4.87 / 5.51)
 constexpr uint32_t TQ_MAX_LEN = 8000;     // reads of a set that takes the tiled search are shorter: 256 x (len / 32 + 2) triples of a piece < 2^16 (rd_ext)
-constexpr int      TQ_MAX_WIN = 192;      // first-hit windows per read (up to six mask words; qwho has eight bits for the window)
+constexpr int      TQ_MAX_WIN = 255;      // first-hit windows per read (up to eight mask words; qwho has eight bits for the window, and a tile — one slice's share
+                                          // of a piece of 256 reads, all of it when the reads are poly-A — must stay below 2^16 records: tlen is 16 bits)
 
 struct QueryListView {
     const unsigned long long *tile_off;   // n_slices * n_pieces + 1
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
 }
 
 // piece-major copy of the tile bounds (the replay reads all slices of ONE piece: 256 strided 8-byte loads become two short
-// contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 192 windows).
+// contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 255 windows).
 __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long *__restrict__ tile_off, uint32_t n_slices, uint32_t n_pieces,
                                                         uint32_t *__restrict__ tstart, uint16_t *__restrict__ tlen)
 {
@@ -218,15 +219,45 @@ __global__ __launch_bounds__(256) void tq_fill_kernel(ReadsView rv, int k, int t
     uint32_t *cnt = fl, *base = cnt + n_slices, *fill = base + n_slices, *dstb = fill + n_slices;   // n_slices each
     uint32_t *rec_a = dstb + n_slices, *rec_w = rec_a + TQ_FILL_CAP;
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t pw[TQ_PIECE + 1];      // exclusive prefix of the reads' first-hit windows (len - t k + 1: an upper bound on their records)
     // where this piece's share of every slice starts (n_slices <= 1024 consecutive words)
     for (uint32_t i = threadIdx.x; i < n_slices; i += 256) dstb[i] = tstart[(uint64_t) blockIdx.x * n_slices + i];
     const uint64_t r0 = (uint64_t) blockIdx.x * TQ_PIECE;
     const uint32_t smask = (1u << sbits) - 1u;
-    for (uint32_t rr = 0; rr < TQ_PIECE; rr += rpr) {
+    // Rounds: as many consecutive reads as keep their first-hit windows within TQ_FILL_CAP records, by the reads' OWN lengths (round 6:
+    // cut by the set's longest read, a piece of 50-150-bp reads took three rounds where its 9.7 k records need two, one for 100-bp reads);
+    // at most rpr reads (the host's bound for reads of the longest length: the same cut as before on sets of one read length)
+    {
+        uint32_t w = 0;
+        if (threadIdx.x < TQ_PIECE && r0 + threadIdx.x < rv.n) {
+            uint64_t t0;
+            uint32_t len;
+            read_extent(rv, r0 + threadIdx.x, t0, len);
+            const uint32_t tk = (uint32_t) t * (uint32_t) k;
+            w = len >= tk ? len - tk + 1 : 0;
+        }
+        uint32_t tot;
+        const uint32_t ex = block_scan<256>(w, wsum, &tot);
+        if (threadIdx.x < TQ_PIECE) pw[threadIdx.x] = ex;
+        if (threadIdx.x == 0) pw[TQ_PIECE] = tot;
+        __syncthreads();
+    }
+    (void) rpr;
+    for (uint32_t rr = 0, hi = 0; rr < TQ_PIECE; rr = hi) {
+        {   // hi = the largest h in (rr, TQ_PIECE] with pw[h] - pw[rr] <= TQ_FILL_CAP (a single read never exceeds the cap: TQ_MAX_WIN windows)
+            uint32_t lo = rr + 1, up = TQ_PIECE;
+            const uint32_t lim = pw[rr] + TQ_FILL_CAP;
+            while (lo < up) {
+                const uint32_t mid = (lo + up + 1) >> 1;
+                if (pw[mid] <= lim) lo = mid;
+                else up = mid - 1;
+            }
+            hi = lo;
+        }
         for (uint32_t i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0, fill[i] = 0;
         __syncthreads();
         const uint32_t i = rr + threadIdx.x;
-        const bool mine = threadIdx.x < rpr && i < TQ_PIECE && r0 + i < rv.n;
+        const bool mine = i < hi && r0 + i < rv.n;
         if (mine) tq_for_each_window<W>(rv, r0 + i, k, t, [&](uint32_t, W addr, bool) { atomicAdd(&cnt[(uint32_t) (addr >> sbits)], 1u); });
         __syncthreads();
         lds_scan<256>(cnt, base, n_slices, wsum);

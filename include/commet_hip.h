@@ -248,7 +248,7 @@ int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_reads
  *                        its VALU-bound phases run beside the first chunk's HBM-bound ones; 0 = both chunks start together
  *   drop_workspaces      frees the scatter workspaces (the next bucketed index build allocates them again)
  *   chunk_group (1..8)   chunk filters searched per pass over a set (1 = the reference's order; 5..8 only
- *                        for read sets with at most 192 first-hit windows per read — reads of up to 255 bases at k = 32, t = 2 —, else 4)
+ *                        for read sets with at most 255 first-hit windows per read — reads of up to 318 bases at k = 32, t = 2 —, else 4)
  *   tiled_search (0/1/2) large search sets against 1 or 2 chunk filters (25 <= k <= 34): lane-a gathers served from L2 slice
  *                        by slice from the set's cached query list; 0 = sets of 2^20 reads or more whose list fits 4 GiB,
  *                        1 = never, 2 = whenever possible

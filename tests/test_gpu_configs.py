@@ -155,6 +155,8 @@ def test_c3_pair_chain_sample_is_bit_exact_against_cpu_checker(c3, tmp_path):
     (33, 1, 150, 40000, 4000, 50),        # 118 windows -> <u64, 4>
     (34, 2, 250, 60000, 3000, 70),        # 183 windows -> <u64, 6>
     (32, 2, 250, 60000, 3000, 250),       # 187 windows, reads of one length -> <u32, 6>
+    (32, 2, 300, 80000, 2500, 120),       # 237 windows (MiSeq-length reads) -> <u32, 8>
+    (33, 2, 318, 80000, 2500, 318),       # 253 windows -> <u64, 8>
 ])
 def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx, lo):
     """max_kmer != 0 uses the library's test hook (k-mers per chunk) so that k >= 33 gets more than four chunks from a
@@ -353,11 +355,12 @@ def test_probe_counting_group_kernels_with_64_bit_keys(k, t, L, max_kmer, group)
 
 @pytest.mark.parametrize("k,t,L,max_kmer,lo,words", [(26, 1, 110, 90000, 110, 3), (33, 1, 120, 90000, 120, 3),
                                                       (26, 1, 150, 90000, 60, 4), (33, 1, 155, 90000, 155, 4),
-                                                      (28, 2, 240, 120000, 80, 6), (34, 1, 220, 120000, 90, 6), (32, 2, 250, 150000, 100, 6)])
-def test_tiled_replay_three_to_six_mask_words(k, t, L, max_kmer, lo, words):
-    """tq_replay_kernel<W, 1 | 2, 3 | 4 | 6>: 65..96 / 97..128 / 129..192 first-hit windows per read (three, four, six mask words; round 6:
-    reads of up to 255 bases at k = 32, t = 2 keep the tiled search) against groups of two chunk filters and against single ones;
-    lo < L: ragged sets"""
+                                                      (28, 2, 240, 120000, 80, 6), (34, 1, 220, 120000, 90, 6), (32, 2, 250, 150000, 100, 6),
+                                                      (32, 2, 300, 150000, 150, 8), (33, 1, 287, 200000, 287, 8)])
+def test_tiled_replay_three_to_eight_mask_words(k, t, L, max_kmer, lo, words):
+    """tq_replay_kernel<W, 1 | 2, 3 | 4 | 6 | 8>: 65..96 / 97..128 / 129..192 / 193..255 first-hit windows per read (three to eight mask
+    words; round 6: reads of up to 318 bases at k = 32, t = 2 keep the tiled search) against groups of two chunk filters and against
+    single ones; lo < L: ragged sets"""
     import commet_amd
     rng = np.random.default_rng(11 * k)
     idx_reads = util.random_reads(rng, 4000, lo, L, n_rate=0.002)
@@ -366,7 +369,7 @@ def test_tiled_replay_three_to_six_mask_words(k, t, L, max_kmer, lo, words):
     ib, io = util.to_batch(idx_reads)
     qb, qo = util.to_batch(q_reads)
     fhw = L - t * k + 1
-    assert words == (2 if fhw <= 64 else 3 if fhw <= 96 else 4 if fhw <= 128 else 6)
+    assert words == (2 if fhw <= 64 else 3 if fhw <= 96 else 4 if fhw <= 128 else 6 if fhw <= 192 else 8)
     got = {}
     with commet_amd.Context(k=k, t=t) as ctx:
         ctx.set_option("max_kmer", max_kmer)
@@ -396,7 +399,7 @@ def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
     sixteen; when most of those are found there (reads that will be found early whatever the plan) the job goes on with
     the narrow tables, group by group, else with the wide rows.  Either way the CPU checker's bits."""
     import commet_amd
-    k, t, L, n_chunks = 16, 2, 80, 2200       # (round 6: 4200 before; nine groups of 256 chunk filters still, half the CPU checker's time)
+    k, t, L, n_chunks = 16, 2, 80, 4200
     rng = np.random.default_rng(99)
     idx_reads = util.random_reads(rng, 2 * n_chunks, L, L, n_rate=0.002)
     early = [idx_reads[int(i)] for i in rng.integers(0, 500, size=4000)]        # copies of reads of the first 250 chunks
@@ -413,7 +416,7 @@ def test_auto_mode_probes_before_choosing_wide_rows_or_narrow_tables():
             tags, stats, info = ctx.index_and_search(irs, [qrs])
             times = ctx.kernel_times()
         chunks = oracle_pool.chunks_from_counts(kc, 1)
-        assert info["n_chunks"] == len(chunks) > 2000
+        assert info["n_chunks"] == len(chunks) > 4000
         groups = (len(chunks) + 255) // 256
         # the probe is one launch of the narrow kernel; then either every group with it, or one wide pass
         if kernel == "search_sliced_kernel":
