@@ -414,7 +414,9 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
         }
         // two lanes: when every chunk of the group takes the bucketed construction (which writes all of its filter
         // slot itself), odd chunks are built on the second stream with the second workspace, beside the even ones
-        bool lanes = g > 1 && c->index_lanes > 1 && !c->kclock.on;   // per-kernel times are additive on one stream only
+        // (round 6: groups of exactly two chunks only — configs[1]: 12.57 against 12.79 ms per step; a 50 M-read set's seven chunks build
+        // in 58.7-60.9 ms on one lane and in 58.9-60.7 ms on two, and the second lane's workspace is 14 GiB more to ask the driver for)
+        bool lanes = g == 2 && c->index_lanes > 1 && !c->kclock.on;   // per-kernel times are additive on one stream only
         for (int i = 0; i < g && lanes; ++i) {
             const Chunk &ch = plan.chunks[ci + i];
             lanes = ch.n_reads && would_partition(c, index_rs, ch.kmers);
