@@ -675,11 +675,10 @@ def run(input_file, out_dir, k=33, t=2, l=0, n=-1, e=0.0, m=-1, bin_dir=None, ra
                 # ranks' images, in the order its jobs want them, as soon as each file appears.  Its first job starts when
                 # the two sets of that job are there, whatever the other ranks are still parsing.
                 wanted_by = {s_: sum(1 for r in range(world) if any(s_ in pairs[c] for c in runs[r])) for s_ in owned}
-                # (round 6) before the most wanted ones: the sets some rank can do NOTHING without — they are in every pair of its run (the
-                # reference set of a rank whose whole run is one row of the matrix): parsed second, such a set kept that rank idle for two
-                # parses (tools/schedule_sim.py, configs[3] at eight ranks: 2.58 -> 2.50 s with the job order above)
-                blocks = {s_: sum(1 for r in range(world) if len(runs[r]) and all(s_ in pairs[c] for c in runs[r])) for s_ in owned}
-                own_first = sorted((s_ for s_ in owned if s_ in needed or s_ in needed_by_others), key=lambda s_: (-blocks[s_], -wanted_by[s_], s_))
+                own_first = sorted((s_ for s_ in owned if s_ in needed or s_ in needed_by_others), key=lambda s_: (-wanted_by[s_], s_))
+                # (simulated and NOT adopted in round 6: parsing first the sets some rank cannot start without — in every pair of its run —
+                # helps the ranks that wait for those and delays the one with the longest run: configs[3] at eight ranks 2.50 against 2.58 s
+                # with one run's fitted costs, 2.65 against 2.53 s with another's: tools/schedule_sim.py, blocking_first)
 
             loaded_all = [False]
 

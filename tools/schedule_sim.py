@@ -60,7 +60,7 @@ def fit(job_log):
     return dict(j1=(a1, b1), jx=(a2, b2, c2), worst_rel_residual=(round(res1, 3), round(res2, 3)))
 
 
-def simulate(n_sets, world, model, parse_s, import_s, sizes=None, canary_s=0.0, ready_first=True, interleave=False, blocking_first=True):
+def simulate(n_sets, world, model, parse_s, import_s, sizes=None, canary_s=0.0, ready_first=True, interleave=False, blocking_first=False):
     """-> per-rank dicts + total seconds.  Mirrors matrix.run: pair cut, owner map, loader thread, job thread.
     canary_s: no rank imports a set before the canary process has its verdict.  ready_first: the job thread starts with a reference
     set that is resident together with one of its targets (round 6; False = the fixed order of rounds 4-5, for comparison).
@@ -91,7 +91,8 @@ def simulate(n_sets, world, model, parse_s, import_s, sizes=None, canary_s=0.0, 
         if world == 1:
             own_order[r] = list(range(n_sets - 1, -1, -1))
         else:
-            # (round 6) first the sets some rank can do NOTHING without (they are in every pair of its run), then the most wanted
+            # blocking_first (simulated, NOT adopted: it helps or hurts by 3-5 % depending on the fitted costs): first the sets some rank can
+            # do NOTHING without (they are in every pair of its run), then the most wanted
             blocks = {s: sum(1 for q in range(world) if mine[q] and all(s in p for p in mine[q])) for s in owned}
             own_order[r] = sorted((s for s in owned if s in needed[r] or s in needed_by_others[r]),
                                   key=lambda s: ((-blocks[s], -wanted_by[s], s) if blocking_first else (-wanted_by[s], s)))
@@ -223,7 +224,7 @@ def main():
     print(f"model: J1(n targets) = {report['model']['j1_ms']} ms, J2 / J3 call of n jobs = {report['model']['j2_j3_ms']} ms (worst relative residual {model['worst_rel_residual']}), "
           f"parse {parse_s:.3f} s per set, import {a.import_s} s per set")
     for w in a.world:
-        sim = simulate(n_sets, w, model, parse_s, a.import_s, canary_s=a.canary_s if w > 1 else 0.0, ready_first=not a.old_order, interleave=False, blocking_first=not a.old_order)
+        sim = simulate(n_sets, w, model, parse_s, a.import_s, canary_s=a.canary_s if w > 1 else 0.0, ready_first=not a.old_order, interleave=False, blocking_first=False)
         report["predictions"].append(sim)
         print(f"N = {w}: predicted total {sim['total_s']:.2f} s, imbalance {sim['imbalance']}, per rank (pairs / first job at / waits / jobs / end): "
               + "  ".join(f"[{o['pairs']} / {o['first_job_at_s']:.2f} / {o['set_wait_s']:.2f} / {o['jobs_s']:.2f} / {o['end_s']:.2f}]" for o in sim["per_rank"]))
