@@ -135,18 +135,163 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
             job.chunk_pos.push_back(at), at += ch.n_reads;
         }
     }
+    bool pairs = false;                            // jobs of ONE chunk each on a search set that takes the tiled search: two jobs per scan (below)
     if (fast) {
         // A search set that takes the tiled search (a query list within the cap: sets of up to ~15 M reads) loses little on its own — its
         // lane-a gathers come out of L2 — and jobs of one or two chunks each need no eight filter slots there (20 GiB more at k = 32, which a
-        // fresh box hands out at 15-30 ms per GiB): such jobs stay on their own (configs[2]'s leg: 1.5 s either way on a used box, 2.0 s
-        // against 1.5 s on a fresh one).
+        // fresh box hands out at 15-30 ms per GiB): such jobs stay out of the eight-slot passes (configs[2]'s leg: 1.5 s either way on a
+        // used box, 2.0 s against 1.5 s on a fresh one).
         size_t most = 0;
         for (const Job &job : jobs) most = std::max(most, job.plan.chunks.size());
         std::lock_guard<std::mutex> qlk(c->ql_mu);
-        if (most <= 2 && tiled_ok(c, search_rs, 2)) fast = false;
+        if (most <= 2 && tiled_ok(c, search_rs, 2)) {
+            fast = false;
+            pairs = most == 1 && c->multi_job != 2;
+        }
     }
-    if (!fast) return one_by_one();
+    if (!fast && !pairs) return one_by_one();
     lap(ph_plan);
+    if (pairs) {
+        // ---- two single-chunk jobs per tiled scan (round 6) ---------------------------------------------------------------------------
+        // The J2 / J3 jobs of a matrix of 10 M-read sets index a fifth of a set (one chunk filter) and search a whole one through the
+        // tiled search: probe 2.2 ms + replay 3 ms per job.  The probe's gather of a query record's plane-A word serves two interleaved
+        // filters as cheaply as one, so consecutive jobs go through the scan in twos: their filters in slots 0 and 1, one probe, one
+        // replay that keeps the two jobs apart (tq_replay_kernel, job_tag_words).  An odd job out, and everything when the list cannot
+        // be had, runs through commet_index_and_search.
+        const uint64_t tag_words = bitmap_words(search_rs->n_reads);
+        if (c->mtags_cap < 2 * tag_words) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void) dm_free(c->d_mtags);
+            c->d_mtags = nullptr, c->mtags_cap = 0;
+            if (dev_alloc(c, (void **) &c->d_mtags, 8 * tag_words * sizeof(uint64_t), true) != hipSuccess) {
+                (void) hipGetLastError();
+                return one_by_one();
+            }
+            c->mtags_cap = 8 * tag_words;
+        }
+        if (c->jobcnt_cap < 16) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void) dm_free(c->d_jobcnt);
+            c->d_jobcnt = nullptr, c->jobcnt_cap = 0;
+            HIP_OK(dev_alloc(c, (void **) &c->d_jobcnt, 64 * sizeof(unsigned long long), true));
+            c->jobcnt_cap = 64;
+        }
+        auto alone = [&](int j) -> int {           // one job through commet_index_and_search, summed into `sum`
+            commet_job_info ji = commet_job_info();
+            const uint8_t *ss = search_select;
+            uint8_t *to = tags_out ? tags_out[j] : nullptr;
+            if (commet_index_and_search(c, index_rs[j], index_select ? index_select[j] : nullptr, 1, &search_rs, search_select ? &ss : nullptr,
+                                        tags_out ? &to : nullptr, stats ? &stats[j] : nullptr, &ji))
+                return 1;
+            sum.n_chunks += ji.n_chunks, sum.kmers_indexed += ji.kmers_indexed, sum.reads_scanned += ji.reads_scanned;
+            sum.reads_indexed += ji.reads_indexed, sum.index_launches += ji.index_launches, sum.search_launches += ji.search_launches;
+            sum.zero_ms += ji.zero_ms, sum.index_ms += ji.index_ms, sum.index_kernel_ms += ji.index_kernel_ms, sum.search_ms += ji.search_ms;
+            return 0;
+        };
+        struct TidyP {
+            commet_ctx *c;
+            std::vector<hipEvent_t> evs;
+            ~TidyP()
+            {
+                c->cur_slot = 0;
+                for (hipEvent_t e : evs) (void) hipEventDestroy(e);
+            }
+        } tidy{c, {}};
+        int j0 = 0;
+        for (; j0 + 1 < n_jobs; j0 += 2) {
+            if (ensure_slots(c, 2, 2)) {
+                (void) hipGetLastError();
+                break;                             // no room for two slots: the rest one by one
+            }
+            hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+            for (hipEvent_t *e : {&ea, &eb, &ec}) {
+                HIP_OK(hipEventCreate(e));
+                tidy.evs.push_back(*e);
+            }
+            (void) hipEventRecord(ea, c->stream);
+            for (int j = j0; j < j0 + 2; ++j) {
+                const commet_readset *rs = index_rs[j];
+                Job &job = jobs[(size_t) j];
+                const Chunk &ch = job.plan.chunks[0];
+                const uint32_t *d_ids = nullptr;
+                if (!job.plan.dense && upload_bits(c, rs->d_sel, job.plan.indexed_bits.data(), rs->n_reads)) return 1;
+                if (!job.plan.dense && rs->uniform_len != 0) {   // the selected reads as a list (both jobs on the one stream: the context's buffer serves one after the other)
+                    const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
+                    if (c->ids_cap < job.plan.indexed_reads || c->idblk_cap < nb + 1) {
+                        HIP_OK(hipStreamSynchronize(c->stream));
+                        (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
+                        c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
+                        const uint64_t cap = std::max<uint64_t>(job.plan.indexed_reads, rs->n_reads / 2);
+                        HIP_OK(dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true));
+                        HIP_OK(dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true));
+                        c->ids_cap = cap, c->idblk_cap = nb + 1;
+                    }
+                    KScope ks(c, "sel_ids_kernels", c->stream);
+                    COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, (const uint64_t *) nullptr);
+                    COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_idblk, (uint32_t) nb);
+                    COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, c->d_ids, (const uint64_t *) nullptr);
+                    HIP_OK(hipGetLastError());
+                    d_ids = c->d_ids;
+                }
+                c->cur_slot = j - j0;
+                if (launch_index(c, rs, ch.first, ch.last - ch.first + 1, job.plan.dense ? nullptr : rs->d_sel, nullptr, ch.kmers, true, false, 0, d_ids, 0, ch.n_reads)) return 1;
+                ++sum.index_launches;
+            }
+            c->cur_slot = 0;
+            if (launch_interleave(c, 2, 2)) return 1;
+            (void) hipEventRecord(eb, c->stream);
+            HIP_OK(hipMemsetAsync(c->d_mtags, 0, 2 * tag_words * sizeof(uint64_t), c->stream));
+            HIP_OK(hipMemsetAsync(c->d_jobcnt, 0, 16 * sizeof(unsigned long long), c->stream));
+            bool scanned = false;
+            {
+                std::lock_guard<std::mutex> qlk(c->ql_mu);
+                if (tiled_ok(c, search_rs, 2) && build_query_list(c, search_rs) == 0 && ensure_query_results(c, search_rs) == 0) {
+                    if (launch_search_tiled(c, search_rs, 2, 0, nullptr, c->d_mtags, c->d_jobcnt, 2, tag_words)) return 1;
+                    scanned = true;
+                }
+            }
+            if (!scanned) {                        // the list could not be had after all: these two and the rest through the jobs' own path
+                HIP_OK(hipStreamSynchronize(c->stream));
+                break;
+            }
+            ++sum.search_launches;
+            (void) hipEventRecord(ec, c->stream);
+            lap(ph_launch);
+            unsigned long long h_cnt[4];
+            HIP_OK(hipMemcpyAsync(h_cnt, c->d_jobcnt, sizeof h_cnt, hipMemcpyDeviceToHost, c->stream));
+            for (int j = j0; j < j0 + 2; ++j)
+                if (tags_out && tags_out[j])
+                    HIP_OK(hipMemcpyAsync(tags_out[j], c->d_mtags + (uint64_t) (j - j0) * tag_words, bitmap_bytes_host(search_rs->n_reads), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            c->kclock.collect();
+            lap(ph_wait);
+            float ms_i = 0, ms_s = 0;
+            (void) hipEventElapsedTime(&ms_i, ea, eb);
+            (void) hipEventElapsedTime(&ms_s, eb, ec);
+            sum.index_ms += ms_i, sum.index_kernel_ms += ms_i, sum.search_ms += ms_s;
+            for (int j = j0; j < j0 + 2; ++j) {
+                const Job &job = jobs[(size_t) j];
+                const unsigned long long sc = h_cnt[2 * (j - j0)], fd = h_cnt[2 * (j - j0) + 1];
+                if (sc != search_rs->n_reads)
+                    return fail("internal error: device scanned %llu reads, host plan says %llu (job %d)", sc, (unsigned long long) search_rs->n_reads, j);
+                if (stats) {
+                    stats[j].indexed = job.plan.indexed_reads;
+                    stats[j].searched = search_rs->n_reads;
+                    stats[j].shared = fd;
+                    stats[j].search_ms = ms_s / 2.0;
+                }
+                sum.n_chunks += 1, sum.kmers_indexed += job.plan.kmers, sum.reads_indexed += job.plan.indexed_reads, sum.reads_scanned += search_rs->n_reads;
+            }
+        }
+        for (int j = j0; j < n_jobs; ++j)
+            if (alone(j)) return 1;
+        sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        if (c->job_verbose)
+            fprintf(stderr, "[jobs x%d, two per tiled scan] plans %.2f ms, launches %.2f ms, wait + download %.2f ms; device: index %.2f ms, search %.2f ms\n", n_jobs,
+                    ph_plan, ph_launch, ph_wait, sum.index_ms, sum.search_ms);
+        if (info) *info = sum;
+        return 0;
+    }
     // no room for what a shared pass needs (eight filter slots + their interleaved A planes are 20 GiB at k = 32): the jobs one after the
     // other, as the header promises — commet_index_and_search itself degrades to groups of four, then one.  Nothing a caller depends on
     // has been written by then that the jobs do not write again.

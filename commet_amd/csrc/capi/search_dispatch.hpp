@@ -409,8 +409,9 @@ bool query_list_blocks(const commet_ctx *c, const commet_readset *rs, uint64_t o
 }
 
 // one pass of rs over the g <= 2 chunk filters in slots slot0 .. slot0 + g - 1 (g == 2: slots 0, 1 with interleaved A planes)
+// job_tag_words != 0 (g == 2): the two filters belong to two jobs; job j's found flags go to d_tags + j * job_tag_words (zeroed by the caller)
 int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot0, const uint64_t *d_sel, uint64_t *d_tags,
-                        unsigned long long *d_counters, uint32_t cstride)
+                        unsigned long long *d_counters, uint32_t cstride, uint64_t job_tag_words = 0)
 {
     if (rs->n_reads == 0) return 0;
     const commet_readset::QueryList &q = rs->ql;
@@ -447,7 +448,7 @@ int launch_search_tiled(commet_ctx *c, const commet_readset *rs, int g, int slot
         {
             KScope ks(c, "tq_replay_kernel", st);
             const dim3 grid(p1 - p0), block(TQ_PIECE);
-#define COMMET_TQ_REPLAY(W, GS, MW) COMMET_LAUNCH((tq_replay_kernel<W, GS, MW>), grid, block, 0, st, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride, p0, (uint32_t) std::min<int>(c->tq_hit_cap, TQ_HIT_CAP))
+#define COMMET_TQ_REPLAY(W, GS, MW) COMMET_LAUNCH((tq_replay_kernel<W, GS, MW>), grid, block, 0, st, rs->view(), v, c->d_qres, fg, c->k, t, d_sel, d_tags, d_counters, cstride, p0, (uint32_t) std::min<int>(c->tq_hit_cap, TQ_HIT_CAP), job_tag_words)
 #define COMMET_TQ_REPLAY_MW(W, GS)                 \
     do {                                           \
         if (mw == 2) COMMET_TQ_REPLAY(W, GS, 2);   \

@@ -354,8 +354,13 @@ template <typename W, int GS, int MW>
 __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsView rv, QueryListView ql, const uint8_t *__restrict__ qres,
                                                              FilterGroupView fg, int k, int t, const uint64_t *__restrict__ sel,
                                                              uint64_t *__restrict__ tags, unsigned long long *__restrict__ counters,
-                                                             uint32_t cstride, uint32_t piece0, uint32_t hit_cap)
+                                                             uint32_t cstride, uint32_t piece0, uint32_t hit_cap, uint64_t job_tag_words)
 {
+    // job_tag_words != 0 (GS == 2 only; round 6): the two chunk filters belong to TWO jobs that search this set (two J2 jobs of a reference
+    // set, two J3 jobs of a target whose index selections make one chunk each, commet_index_many_and_search): the probe's one gather per
+    // record serves both; here job 1 starts afresh at chunk 1 — no read is skipped for what job 0 found — and job j's found flags go to
+    // tags + j * job_tag_words (zeroed by the host), its counters to its own chunk's slots.  `tags` is not read then.
+    const bool multi = GS == 2 && job_tag_words != 0;
     // hit_cap <= TQ_HIT_CAP: full hits of light scans a piece may post (tests set it to 0: every piece with a hit overflows)
     const uint32_t piece = blockIdx.x + piece0;          // (the launch covers pieces piece0 .. piece0 + gridDim.x - 1)
     __shared__ uint32_t masks[GS * 2 * MW * TQ_PIECE];   // [chunk][strand][word][read]
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
     uint64_t selw = ~0ull, tagw = 0;
     if (in_range) {
         if (sel) selw = sel[word];
-        if (tags) tagw = tags[word];
+        if (tags && !multi) tagw = tags[word];
     }
     const bool active = (r < rv.n) && ((selw >> lane) & 1ull) && !((tagw >> lane) & 1ull);
     uint64_t my_t0 = 0;
@@ -634,6 +639,7 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
     uint32_t *const tail_req = PASS_LIST ? hits : tail_arr, *const tail_bits = tail_req + TQ_PIECE;
     __shared__ uint32_t tail_n;
     int found_chunk = -1;
+    bool found_job0 = false, found_job1 = false;       // (two jobs in one scan)
     {
         const uint32_t *p = rv.planes + 3 * my_t0;
         const int last = (int) my_len - 1;
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
         const bool scanning = active && !(COMMET_TQ_ABLATE & (1024 | 8192));
         bool found = false;
         for (int i = 0; i < 2 * fg.g; ++i) {   // (uniform)
+            if (multi && i == 2) found_job0 = found, found = false;    // chunk 1 opens the second job: nothing carries over
             const int strand = i & 1;
             const uint32_t *pb = fg.slot0 + (uint64_t) (i >> 1) * fg.slot_words + fg.plane_words;
             const uint32_t *pc = pb + fg.plane_words, *pd = pc + fg.plane_words;
@@ -741,6 +748,23 @@ __global__ __launch_bounds__(TQ_PIECE) COMMET_SGPRS void tq_replay_kernel(ReadsV
             }
             if (found && found_chunk < 0) found_chunk = i >> 1;
         }
+        found_job1 = found;
+    }
+    if constexpr (GS == 2) if (multi) {
+        const uint64_t fb0 = __ballot(found_job0), fb1 = __ballot(found_job1), sc = __ballot(active);
+        if (lane == 0 && in_range && tags) tags[word] = fb0, tags[job_tag_words + word] = fb1;
+        __syncthreads();
+        if (counters) {
+            if (lane == 0) {
+                if (sc) atomicAdd(&wg_cnt[0], (unsigned int) __popcll(sc)), atomicAdd(&wg_cnt[2], (unsigned int) __popcll(sc));
+                if (fb0) atomicAdd(&wg_cnt[1], (unsigned int) __popcll(fb0));
+                if (fb1) atomicAdd(&wg_cnt[3], (unsigned int) __popcll(fb1));
+            }
+            __syncthreads();
+            if (threadIdx.x < 4u && wg_cnt[threadIdx.x])
+                atomicAdd(&counters[(uint64_t) (threadIdx.x >> 1) * cstride + (threadIdx.x & 1)], (unsigned long long) wg_cnt[threadIdx.x]);
+        }
+        return;
     }
     const bool found = found_chunk >= 0;
     const uint64_t fb = __ballot(found);

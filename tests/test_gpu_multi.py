@@ -104,3 +104,39 @@ def test_shared_passes_fall_back_to_the_jobs_alone_when_eight_slots_do_not_fit()
         assert "search_group8_kernel" in ctx.kernel_times() and i2["search_launches"] < len(irs)
         for j in range(len(irs)):
             assert np.array_equal(t2[j], tags[j])
+
+
+@pytest.mark.parametrize("k,t,L", [(32, 2, 100), (33, 2, (60, 140)), (28, 1, 120)])
+def test_single_chunk_jobs_go_through_the_tiled_search_in_twos(k, t, L):
+    """commet_index_many_and_search, jobs of ONE chunk filter each on a search set that takes the tiled search (the J2 / J3 jobs of a
+    matrix of 10 M-read sets): two jobs per scan — one probe, one replay that keeps the jobs apart (tq_replay_kernel, job_tag_words) —
+    an odd job out on its own; every job's tags and numbers are those of the job alone"""
+    import commet_amd
+    from commet_amd import synth
+    rng = np.random.default_rng(k * 10 + t)
+    n_i, n_s = 250_000, 500_000
+    make = (lambda s, n: synth.synth_set_ragged(s, n, L[0], L[1])) if isinstance(L, tuple) else (lambda s, n: synth.synth_set(s, n, L))
+    with commet_amd.Context(k=k, t=t) as ctx:
+        ctx.set_option("index_mode", 2)                  # the bucketed construction whatever a chunk's size (the shared paths' condition)
+        ctx.set_option("tiled_search", 2)                # the tiled search whatever the set's size
+        srs = commet_amd.ReadSet.from_files(ctx, [make(0, n_s)])
+        irs = [commet_amd.ReadSet.from_files(ctx, [make(s, n_i)]) for s in (1, 2, 3, 4, 5)]
+        sels = [_bits(rng, n_i, 0.3), None, _bits(rng, n_i, 0.2), _bits(rng, n_i, 0.6), None]
+        alone = [ctx.index_and_search(rs, [srs], index_select=sel) for rs, sel in zip(irs, sels)]
+        assert all(a[2]["n_chunks"] == 1 for a in alone)
+        ctx.set_option("kernel_timing", 1)
+        tags, stats, info = ctx.index_many_and_search(irs, srs, index_selects=sels)
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        assert times["tq_replay_kernel"][0] == 3 and times["tq_probe_kernel"][0] == 3      # two scans of two jobs, one of the fifth
+        assert "search_group8_kernel" not in times and info["search_launches"] == 3 and info["n_chunks"] == 5
+        for j, a in enumerate(alone):
+            assert np.array_equal(tags[j], a[0][0]), j
+            assert {f: stats[j][f] for f in ("indexed", "searched", "shared")} == {f: a[1][0][f] for f in ("indexed", "searched", "shared")}, j
+        assert stats[1]["shared"] > n_i // 8 * 0.5 and info["kmers_indexed"] == sum(a[2]["kmers_indexed"] for a in alone)
+        # job by job on request: the same bits
+        ctx.set_option("multi_job", 1)
+        t2, s2, i2 = ctx.index_many_and_search(irs, srs, index_selects=sels)
+        assert i2["search_launches"] == 5
+        for j in range(5):
+            assert np.array_equal(t2[j], tags[j]) and s2[j]["shared"] == stats[j]["shared"]
