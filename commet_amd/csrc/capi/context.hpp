@@ -118,6 +118,8 @@ void commet_destroy(commet_ctx *c)
     (void) dm_free(c->d_plansum);
     (void) dm_free(c->d_ids);
     (void) dm_free(c->d_idblk);
+    (void) dm_free(c->d_ids2);
+    (void) dm_free(c->d_idblk2);
     (void) dm_free(c->d_mtags);
     (void) dm_free(c->d_act);
     (void) dm_free(c->d_actblk);

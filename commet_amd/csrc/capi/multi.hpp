@@ -209,33 +209,58 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
                 tidy.evs.push_back(*e);
             }
             (void) hipEventRecord(ea, c->stream);
+            // the two chunks are built side by side on the context's two index lanes (as the two chunks of one job are): first, on the main
+            // stream, what each build reads — the selection bitmap and, for sets of one read length, the list of the selected reads, the
+            // second job's in a buffer of its own — then the fork
+            const uint32_t *ids_of[2] = {nullptr, nullptr};
+            const bool same_set = index_rs[j0] == index_rs[j0 + 1];    // (one set in both jobs: ONE selection bitmap on the device — the second job's goes up behind the first build)
+            auto prepare = [&](int j) -> int {       // job j's selection on the device: its bitmap and, for sets of one read length, the list of the selected reads
+                const commet_readset *rs = index_rs[j];
+                Job &job = jobs[(size_t) j];
+                if (job.plan.dense) return 0;
+                if (upload_bits(c, rs->d_sel, job.plan.indexed_bits.data(), rs->n_reads)) return 1;
+                if (rs->uniform_len == 0) return 0;
+                uint32_t *&ids = j == j0 ? c->d_ids : c->d_ids2, *&blk = j == j0 ? c->d_idblk : c->d_idblk2;
+                uint64_t &ids_cap = j == j0 ? c->ids_cap : c->ids2_cap, &blk_cap = j == j0 ? c->idblk_cap : c->idblk2_cap;
+                const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
+                if (ids_cap < job.plan.indexed_reads || blk_cap < nb + 1) {
+                    HIP_OK(hipStreamSynchronize(c->stream));
+                    HIP_OK(hipStreamSynchronize(c->aux_stream));
+                    (void) dm_free(ids), (void) dm_free(blk);
+                    ids = blk = nullptr, ids_cap = blk_cap = 0;
+                    const uint64_t cap = std::max<uint64_t>(job.plan.indexed_reads, rs->n_reads / 2);
+                    HIP_OK(dev_alloc(c, (void **) &ids, cap * sizeof(uint32_t), true));
+                    HIP_OK(dev_alloc(c, (void **) &blk, (nb + 1) * sizeof(uint32_t), true));
+                    ids_cap = cap, blk_cap = nb + 1;
+                }
+                KScope ks(c, "sel_ids_kernels", c->stream);
+                COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, blk, (const uint64_t *) nullptr);
+                COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, blk, (uint32_t) nb);
+                COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, blk, ids, (const uint64_t *) nullptr);
+                HIP_OK(hipGetLastError());
+                ids_of[j - j0] = ids;
+                return 0;
+            };
+            if (prepare(j0) || (!same_set && prepare(j0 + 1))) return 1;
+            const bool lanes = c->index_lanes > 1 && !c->kclock.on && !same_set;
+            if (lanes) {
+                HIP_OK(hipEventRecord(c->ev_fork, c->stream));
+                HIP_OK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            }
             for (int j = j0; j < j0 + 2; ++j) {
                 const commet_readset *rs = index_rs[j];
                 Job &job = jobs[(size_t) j];
                 const Chunk &ch = job.plan.chunks[0];
-                const uint32_t *d_ids = nullptr;
-                if (!job.plan.dense && upload_bits(c, rs->d_sel, job.plan.indexed_bits.data(), rs->n_reads)) return 1;
-                if (!job.plan.dense && rs->uniform_len != 0) {   // the selected reads as a list (both jobs on the one stream: the context's buffer serves one after the other)
-                    const uint64_t n_words = bitmap_words(rs->n_reads), nb = (n_words + IDS_BLOCK_WORDS - 1) / IDS_BLOCK_WORDS;
-                    if (c->ids_cap < job.plan.indexed_reads || c->idblk_cap < nb + 1) {
-                        HIP_OK(hipStreamSynchronize(c->stream));
-                        (void) dm_free(c->d_ids), (void) dm_free(c->d_idblk);
-                        c->d_ids = c->d_idblk = nullptr, c->ids_cap = c->idblk_cap = 0;
-                        const uint64_t cap = std::max<uint64_t>(job.plan.indexed_reads, rs->n_reads / 2);
-                        HIP_OK(dev_alloc(c, (void **) &c->d_ids, cap * sizeof(uint32_t), true));
-                        HIP_OK(dev_alloc(c, (void **) &c->d_idblk, (nb + 1) * sizeof(uint32_t), true));
-                        c->ids_cap = cap, c->idblk_cap = nb + 1;
-                    }
-                    KScope ks(c, "sel_ids_kernels", c->stream);
-                    COMMET_LAUNCH(sel_count_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, (const uint64_t *) nullptr);
-                    COMMET_LAUNCH(sel_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_idblk, (uint32_t) nb);
-                    COMMET_LAUNCH(sel_ids_kernel, dim3((unsigned) nb), dim3(64), 0, c->stream, rs->d_sel, n_words, c->d_idblk, c->d_ids, (const uint64_t *) nullptr);
-                    HIP_OK(hipGetLastError());
-                    d_ids = c->d_ids;
-                }
+                if (same_set && j == j0 + 1 && prepare(j)) return 1;
                 c->cur_slot = j - j0;
-                if (launch_index(c, rs, ch.first, ch.last - ch.first + 1, job.plan.dense ? nullptr : rs->d_sel, nullptr, ch.kmers, true, false, 0, d_ids, 0, ch.n_reads)) return 1;
+                if (launch_index(c, rs, ch.first, ch.last - ch.first + 1, job.plan.dense ? nullptr : rs->d_sel, nullptr, ch.kmers, true, false, lanes ? j - j0 : 0,
+                                 ids_of[j - j0], 0, ch.n_reads))
+                    return 1;
                 ++sum.index_launches;
+            }
+            if (lanes) {
+                HIP_OK(hipEventRecord(c->ev_join, c->aux_stream));
+                HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             }
             c->cur_slot = 0;
             if (launch_interleave(c, 2, 2)) return 1;

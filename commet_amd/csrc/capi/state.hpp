@@ -431,6 +431,8 @@ struct commet_ctx {
     unsigned long long *d_jobcnt = nullptr;   // per (chunk, set) counters of commet_index_and_search, kept between calls
     uint32_t *d_ids = nullptr, *d_idblk = nullptr;   // read numbers of the index selection of the running job, in order (sel_ids_kernel)
     uint64_t ids_cap = 0, idblk_cap = 0;
+    uint32_t *d_ids2 = nullptr, *d_idblk2 = nullptr; // the same for the second of two jobs whose chunks are built side by side (multi.hpp, two jobs per tiled scan)
+    uint64_t ids2_cap = 0, idblk2_cap = 0;
     uint32_t *d_act = nullptr, *d_actblk = nullptr;  // read numbers of a sparse search pass (sel & ~tags, in order) and the scan's block sums
     uint64_t act_cap = 0, actblk_cap = 0;
     uint64_t *d_mtags = nullptr;                     // found flags of the jobs of a commet_index_many_and_search pass (up to eight bitmaps over the search set)

@@ -140,3 +140,12 @@ def test_single_chunk_jobs_go_through_the_tiled_search_in_twos(k, t, L):
         assert i2["search_launches"] == 5
         for j in range(5):
             assert np.array_equal(t2[j], tags[j]) and s2[j]["shared"] == stats[j]["shared"]
+        ctx.set_option("multi_job", 0)
+        # the same index set in both jobs of a scan, under two selections (one selection bitmap per set on the device)
+        twice = [irs[0], irs[0], irs[2], irs[2]]
+        sels2 = [sels[0], _bits(rng, n_i, 0.5), None, sels[2]]
+        t3, s3, i3 = ctx.index_many_and_search(twice, srs, index_selects=sels2)
+        assert i3["search_launches"] == 2
+        for j, (rs, sel) in enumerate(zip(twice, sels2)):
+            a = ctx.index_and_search(rs, [srs], index_select=sel)
+            assert np.array_equal(t3[j], a[0][0]) and s3[j]["shared"] == a[1][0]["shared"] and s3[j]["indexed"] == a[1][0]["indexed"], j
