@@ -230,8 +230,10 @@ int commet_index_and_search(commet_ctx *ctx,
  * commet_index_and_search(index_rs[j], ..., 1, &search_rs, ...) gives for job j alone, bit for bit.  Where the jobs allow it
  * (index sets whose chunks, at most eight per job, take the bucketed construction; a search set that is visited
  * whole) the chunk filters of several jobs share a pass over the search set: the lane-a gathers of its reads, two thirds of a
- * job's memory requests, are then made once per pass instead of once per job.  Otherwise (and with option "multi_job" = 1) the
- * jobs run one after the other.  info (may be NULL) sums over the jobs. */
+ * job's memory requests, are then made once per pass instead of once per job: up to eight chunk filters per pass of the gather
+ * kernel; on a search set that takes the tiled search, jobs of one chunk filter each two per scan (one probe of the set's query list,
+ * one replay that keeps the two jobs apart).  Otherwise (and with option "multi_job" = 1, or when the device has no room for the
+ * slots of a shared pass) the jobs run one after the other.  info (may be NULL) sums over the jobs. */
 int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_readset *const *index_rs,
                                  const uint8_t *const *index_select, const commet_readset *search_rs,
                                  const uint8_t *search_select, uint8_t *const *tags_out, commet_pair_stats *stats,
