@@ -817,16 +817,18 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, b0, b1, info) if not ragged_hl else None
                 if out["cpu_baseline"] is not None and not args.cpu_full:
                     # the whole job was run once on one core (--cpu-full, minutes): quoted from the committed record of that run
-                    try:
-                        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_full", "bench.json")))
-                        fj = rec["cpu_baseline"]["full_job"]
-                        if rec["config"]["workload"] == workload and "error" not in fj:
-                            out["cpu_baseline"]["full_job_recorded"] = dict(fj, source="profiles/r04_cpu_full/bench.json")
-                            out["cpu_baseline"]["sample"] += (f"; the WHOLE job on one core, measured once with --cpu-full (profiles/r04_cpu_full): "
-                                                              f"{fj['reads_per_s']:.0f} reads/s (index {fj['index_s']} s + search {fj['search_s']} s), "
-                                                              f".bv bytes equal the GPU's: {fj['bv_bytes_equal_gpu']}")
-                    except Exception:
-                        pass
+                    for rec_dir in ("r06_cpu_full", "r04_cpu_full"):       # (the newest committed record of this very workload)
+                        try:
+                            rec = json.load(open(os.path.join(ROOT, "profiles", rec_dir, "bench.json")))
+                            fj = rec["cpu_baseline"]["full_job"]
+                            if rec["config"]["workload"] == workload and "error" not in fj:
+                                out["cpu_baseline"]["full_job_recorded"] = dict(fj, source=f"profiles/{rec_dir}/bench.json")
+                                out["cpu_baseline"]["sample"] += (f"; the WHOLE job on one core, measured once with --cpu-full (profiles/{rec_dir}): "
+                                                                  f"{fj['reads_per_s']:.0f} reads/s (index {fj['index_s']} s + search {fj['search_s']} s), "
+                                                                  f".bv bytes equal the GPU's: {fj['bv_bytes_equal_gpu']}")
+                                break
+                        except Exception:
+                            pass
                 if args.cpu_full and out["cpu_baseline"] is not None:
                     out["cpu_baseline"]["full_job"] = cpu_full_job(args, b0, b1, last["tags"][0], stats[0])
                     fj = out["cpu_baseline"]["full_job"]
