@@ -118,6 +118,7 @@ void commet_destroy(commet_ctx *c)
     (void) dm_free(c->d_plansum);
     (void) dm_free(c->d_ids);
     (void) dm_free(c->d_idblk);
+    (void) dm_free(c->d_lo_cnt);
     (void) dm_free(c->d_ids2);
     (void) dm_free(c->d_idblk2);
     (void) dm_free(c->d_mtags);

@@ -485,7 +485,9 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                 if (rs->n_reads) ++n_search_launches;
             } else if (g > 1 && (gs == 8 || group_searchable(c, rs, g))) {
                 (void) list_for_pass();
-                if (launch_search_group(c, rs, g, gs, sel_s, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes, al, visited[s])) { rc = 1; break; }
+                // a ragged set visited whole, the job's first pass over it (no tags yet): its reads in order of their window counts
+                const uint64_t n_listed = ordered_pass(c, rs, sel_s, ci == 0, &al) ? rs->n_reads : visited[s];
+                if (launch_search_group(c, rs, g, gs, sel_s, rs->d_tags, cnt, (uint32_t) (2 * n_search), d_probes, al, n_listed)) { rc = 1; break; }
                 if (rs->n_reads) ++n_search_launches;
             } else {
                 for (int i = 0; i < g && !rc; ++i) {
@@ -494,7 +496,8 @@ int commet_index_and_search(commet_ctx *c, const commet_readset *index_rs, const
                     if (tiled1 == 2) rc = 1;
                     else if (tiled1 == 1) {
                         (void) list_for_pass();
-                        if (launch_search(c, rs, sel_s, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes, al, visited[s])) rc = 1;
+                        const uint64_t n_listed = ordered_pass(c, rs, sel_s, ci == 0 && i == 0, &al) ? rs->n_reads : visited[s];
+                        if (launch_search(c, rs, sel_s, rs->d_tags, nullptr, cnt + 2 * (uint64_t) i * n_search, d_probes, al, n_listed)) rc = 1;
                     }
                     if (rs->n_reads) ++n_search_launches;
                 }

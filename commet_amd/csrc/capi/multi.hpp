@@ -415,7 +415,9 @@ int commet_index_many_and_search(commet_ctx *c, int n_jobs, const commet_readset
         (void) hipEventRecord(eb, c->stream);
         if (hipMemsetAsync(c->d_mtags, 0, (size_t) (j1 - j0) * tag_words * sizeof(uint64_t), c->stream) != hipSuccess ||
             hipMemsetAsync(c->d_jobcnt, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { rc = fail("memset failed"); break; }
-        if (launch_search_group(c, search_rs, g, 8, nullptr, c->d_mtags, c->d_jobcnt, 2, nullptr, ActiveList{nullptr, nullptr}, 0, job_mask, tag_words)) { rc = 1; break; }
+        ActiveList al{nullptr, nullptr};               // (a ragged search set: its reads in order of their window counts — every job's tags start empty)
+        const uint64_t n_listed = ordered_pass(c, search_rs, nullptr, true, &al) ? search_rs->n_reads : 0;
+        if (launch_search_group(c, search_rs, g, 8, nullptr, c->d_mtags, c->d_jobcnt, 2, nullptr, al, n_listed, job_mask, tag_words)) { rc = 1; break; }
         ++sum.search_launches;
         (void) hipEventRecord(ec, c->stream);
         lap(ph_launch);

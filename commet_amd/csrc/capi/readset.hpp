@@ -72,6 +72,7 @@ void commet_readset_destroy(commet_readset *rs)
     (void) dm_free(rs->d_tags);
     (void) dm_free(rs->d_found);
     rs->ql.release();
+    (void) dm_free(rs->d_len_order);
     for (int i = 0; i < 2; ++i) {
         if (rs->st[i].h_bases) (void) hipHostFree(rs->st[i].h_bases);
         if (rs->st[i].h_offs) (void) hipHostFree(rs->st[i].h_offs);

@@ -228,6 +228,52 @@ int build_active_list(commet_ctx *c, const commet_readset *rs, const uint64_t *d
     return 0;
 }
 
+// ---- ragged sets in order of their window counts (tile_search.hpp, lo_*_kernel) -------------------------------------------
+// al = the set's list when a pass qualifies: a ragged set visited whole (no selection, no tags yet: the first pass of a job), no other
+// list in use.  The list is made on the job's stream on first use (three small launches + the scan) and kept with the set; no room =
+// the natural order, as before.
+bool ordered_pass(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel, bool tags_empty, ActiveList *al)
+{
+    if (c->ordered_scan == 1 || rs->uniform_len != 0 || d_sel || !tags_empty || al->ids || c->count_probes || rs->len_order_failed) return false;
+    if (rs->n_reads == 0 || rs->n_reads >= (1ull << 32) - 1 || (c->ordered_scan == 0 && rs->n_reads < (1u << 16))) return false;
+    if (!rs->d_len_order) {
+        const uint64_t n_blocks = (rs->n_reads + LO_BLOCK - 1) / LO_BLOCK, entries = n_blocks * LO_CLASSES;
+        const uint32_t nb = (uint32_t) ((entries + 4095) / 4096);
+        uint32_t *ids = nullptr;
+        hipError_t e = dm_malloc((void **) &ids, (rs->n_reads + 1) * sizeof(uint32_t));
+        if (e == hipSuccess && c->lo_cnt_cap < entries + 1 + nb + 2) {
+            (void) dm_free(c->d_lo_cnt);
+            c->d_lo_cnt = nullptr, c->lo_cnt_cap = 0;
+            e = dm_malloc((void **) &c->d_lo_cnt, (entries + 1 + nb + 2) * sizeof(unsigned long long));
+            if (e == hipSuccess) c->lo_cnt_cap = entries + 1 + nb + 2;
+        }
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            (void) dm_free(ids);
+            rs->len_order_failed = true;
+            return false;
+        }
+        unsigned long long *cnt = c->d_lo_cnt, *totals = cnt + entries + 1;
+        const uint32_t tk = (uint32_t) std::min<int64_t>((int64_t) t_eff(c, rs) * c->k, 0x7FFFFFFF);
+        KScope ks(c, "len_order_kernels", c->stream);
+        COMMET_LAUNCH(lo_count_kernel, dim3((unsigned) n_blocks), dim3(256), 0, c->stream, rs->view(), tk, n_blocks, cnt);
+        COMMET_LAUNCH(tq_scan_blocks_kernel, dim3(nb), dim3(1024), 0, c->stream, cnt, entries, totals);
+        COMMET_LAUNCH(tq_scan_totals_kernel, dim3(1), dim3(1024), 0, c->stream, totals, nb, totals + nb);
+        COMMET_LAUNCH(tq_scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, cnt, entries, totals, totals + nb);
+        COMMET_LAUNCH(lo_fill_kernel, dim3((unsigned) n_blocks), dim3(256), 0, c->stream, rs->view(), tk, n_blocks, cnt, ids);
+        if (hipGetLastError() != hipSuccess) {
+            (void) hipStreamSynchronize(c->stream);
+            (void) dm_free(ids);
+            rs->len_order_failed = true;
+            return false;
+        }
+        rs->d_len_order = ids;
+    }
+    al->ids = rs->d_len_order;
+    al->n = rs->d_len_order + rs->n_reads;
+    return true;
+}
+
 // ---- tiled search (tile_search.hpp) ----------------------------------------------------------------------------
 constexpr int TQ_SBITS = 24;          // slice = 2^24 bits of plane A's address space: 2 MiB per chunk filter, 4 MiB for a group of two
                                       // (measured on configs[1]: 22 / 23 / 24 -> probe 2.43 / 2.56 / 2.35 ms, gpurun_out/r02_tq_ab2.log)

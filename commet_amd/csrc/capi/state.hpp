@@ -507,6 +507,10 @@ struct commet_ctx {
     uint8_t *d_qres = nullptr;        // tiled search (tile_search.hpp): one result byte per query record of the set being scanned
     uint64_t qres_cap = 0;
     int tq_hit_cap = TQ_HIT_CAP;      // option "tq_hit_cap" (tests): full hits a piece of the replay may post before its scans walk their own candidates
+    int ordered_scan = 0;             // option "ordered_scan": 0 = ragged sets of 2^16 reads and more are walked in order of their window counts by the
+                                      // gather kernels' first pass, 1 = never, 2 = whenever the set is ragged (tests)
+    unsigned long long *d_lo_cnt = nullptr;   // scratch of that list's counting sort (class-major block counts), kept
+    uint64_t lo_cnt_cap = 0;
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
     // environment knobs of A/B runs, read ONCE in commet_create (nothing on the launch path calls getenv)
     int tq_sbits = 0;                 // COMMET_TQ_SBITS: log2 bits per address slice of the query list (0 = TQ_SBITS)
@@ -602,6 +606,10 @@ struct commet_readset {
         }
     };
     mutable QueryList ql;
+    // the set's reads in order of their first-hit window counts (tile_search.hpp, lo_*_kernel): ragged sets only, made on the first pass
+    // of a gather kernel that visits the whole set; ids[n_reads] = n_reads closes the list
+    mutable uint32_t *d_len_order = nullptr;
+    mutable bool len_order_failed = false;
     mutable uint32_t ql_wanted = 0;                 // scans that would have taken the tiled search had the set's (large) list existed (tiled_ok)
     mutable std::atomic<uint64_t> ql_reserved_at{0};  // g_devmem.trims when the memory was set aside: a trim since then has given it back
     mutable std::atomic<bool> ql_reserved{false};   // the memory of the set's list waits in the library's device cache (commet_readset_reserve_cache): a list above the cap may be built

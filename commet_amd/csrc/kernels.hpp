@@ -999,8 +999,12 @@ __global__ __launch_bounds__(256, G8_WAVES) COMMET_SGPRS void search_group8_kern
     }
     // (several jobs) what a job leaves behind: its found flags, one ballot word per 64 reads, and its chunks' counters
     auto end_job = [&](int first, int end) {
-        const uint64_t fb = __ballot(found);
-        if ((threadIdx.x & 63) == 0 && me.in_range && tags) tags[(uint64_t) job * job_tag_words + me.word] = fb;
+        if (al.ids) {                                     // list form (a ragged set's reads in order of their window counts): one atomic OR per found read
+            if (found && tags) (void) __hip_atomic_fetch_or(tags + (uint64_t) job * job_tag_words + me.word, 1ull << (me.r & 63ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const uint64_t fb = __ballot(found);
+            if ((threadIdx.x & 63) == 0 && me.in_range && tags) tags[(uint64_t) job * job_tag_words + me.word] = fb;
+        }
         if (counters) add_chunk_counters(counters + (uint64_t) first * cstride, cstride, end - first, active, found_chunk < 0 ? -1 : found_chunk - first, wg_cnt);
     };
 #pragma unroll

@@ -186,6 +186,57 @@ __global__ __launch_bounds__(1024) void tq_scan_add_kernel(unsigned long long *_
     if (blockIdx.x == 0 && threadIdx.x == 0) a[n] = *grand_total;   // closes the table
 }
 
+// ---------------------------------------------------------------------------
+// Reads of a RAGGED set in order of their first-hit window counts (round 6).  The gather kernels give a read to a thread and walk its
+// windows one round trip at a time: a workgroup lives as long as its longest read, its other lanes' request slots idle meanwhile — on
+// a set of 50-150-bp reads a pass cost 73 ps per window and read against 50 on 100-bp reads (tools/group_bench.py), and no dealing
+// of reads INSIDE a workgroup helps (measured: its registers stay allocated until its last wave is through).  With the reads listed
+// in 32 classes of window counts (most first; inside a class in read order), a launch in list form (ActiveList) hands every
+// workgroup reads of one class.  A counting sort: per-block class counts, a scan in class-major order (the scan kernels above), the
+// fill.  ids[n] = n closes the list (ActiveList::n).  Depends on (k, t) and the set only: cached with the set.
+// ---------------------------------------------------------------------------
+constexpr uint32_t LO_BLOCK = 1024, LO_CLASSES = 32;
+__device__ __forceinline__ uint32_t lo_class(const ReadsView &rv, uint64_t r, uint32_t tk)
+{
+    const uint64_t len = rv.goff[r + 1] - rv.goff[r];
+    const uint64_t wins = len >= tk ? len - tk + 1 : 0;
+    return LO_CLASSES - 1u - (uint32_t) min(wins / 8, (uint64_t) (LO_CLASSES - 1));
+}
+
+__global__ __launch_bounds__(256) void lo_count_kernel(ReadsView rv, uint32_t tk, uint64_t n_blocks, unsigned long long *__restrict__ cnt)
+{
+    __shared__ uint32_t h[LO_CLASSES];
+    if (threadIdx.x < LO_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t) blockIdx.x * LO_BLOCK;
+    for (uint32_t i = threadIdx.x; i < LO_BLOCK; i += 256)
+        if (r0 + i < rv.n) atomicAdd(&h[lo_class(rv, r0 + i, tk)], 1u);
+    __syncthreads();
+    if (threadIdx.x < LO_CLASSES) cnt[(uint64_t) threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void lo_fill_kernel(ReadsView rv, uint32_t tk, uint64_t n_blocks, const unsigned long long *__restrict__ off,
+                                                      uint32_t *__restrict__ ids)
+{
+    __shared__ uint32_t h[LO_CLASSES];
+    __shared__ unsigned long long base[LO_CLASSES];
+    if (threadIdx.x < LO_CLASSES) {
+        h[threadIdx.x] = 0;
+        base[threadIdx.x] = off[(uint64_t) threadIdx.x * n_blocks + blockIdx.x];
+    }
+    __syncthreads();
+    const uint64_t r0 = (uint64_t) blockIdx.x * LO_BLOCK;
+    // (thread x takes reads x, x + 256, ...: inside a class the block's reads come out in four interleaved runs — order inside a class
+    // decides nothing)
+    for (uint32_t i = threadIdx.x; i < LO_BLOCK; i += 256) {
+        const uint64_t r = r0 + i;
+        if (r >= rv.n) break;
+        const uint32_t c = lo_class(rv, r, tk);
+        ids[base[c] + atomicAdd(&h[c], 1u)] = (uint32_t) r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ids[rv.n] = (uint32_t) rv.n;
+}
+
 // piece-major copy of the tile bounds (the replay reads all slices of ONE piece: 256 strided 8-byte loads become two short
 // contiguous arrays).  Records < 2^32 and tiles < 2^16 records are guaranteed by the host (list <= 4 GiB, 256 reads x 255 windows).
 __global__ __launch_bounds__(256) void tq_bounds_kernel(const unsigned long long *__restrict__ tile_off, uint32_t n_slices, uint32_t n_pieces,

@@ -173,6 +173,54 @@ def test_job_tiled_search_matches_oracle(tmp_path, seed):
                 pos += n
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_job_ordered_scan_matches_oracle(tmp_path, seed):
+    """ragged sets walked in order of their first-hit window counts (round 6: the list form of the gather kernels fed with the set's
+    length-ordered list — tile_search.hpp lo_*_kernel, capi ordered_pass — on a job's first pass over a set that is visited whole),
+    forced on the randomised scenarios for the plain kernel and groups of 2, 4 and 5..8 chunk filters; every seed against the CPU
+    checker's bits and log numbers, and against the same job in natural order"""
+    import commet_amd as commet
+    k = [20, 25, 28, 32, 33, 16, 31, 34][seed % 8]
+    scn = Scenario(str(tmp_path / "scn"), 1300 + seed, k=k, n_scale=[1.0, 5.0, 12.0][seed % 3])
+    max_kmer = [0, 2500, 700][(seed // 8) % 3]
+    out_o, log_o = str(tmp_path / "out"), str(tmp_path / "log")
+    rc, res, chunks, kmers = run_oracle(scn, out_o, log_o, max_kmer=max_kmer)
+    assert rc == 0
+    with commet.Context(k=scn.k, t=scn.t) as ctx:
+        irs, isel = _load_set(commet, ctx, scn.sets[scn.index_name], scn.dir)
+        srs, ssel = [], []
+        for nme in sorted(scn.search_names):
+            r, s = _load_set(commet, ctx, scn.sets[nme], scn.dir)
+            srs.append(r)
+            ssel.append(s)
+        ctx.set_option("tiled_search", 1)
+        ctx.set_option("slice_mode", 1)
+        ctx.set_option("max_kmer", max_kmer)
+        ctx.set_option("chunk_group", [8, 1, 4, 2][(seed // 2) % 4])
+        ctx.set_option("ordered_scan", 2)
+        ctx.set_option("kernel_timing", 1)
+        got = ctx.index_and_search(irs, srs, isel, ssel)
+        times = ctx.kernel_times()
+        ctx.set_option("kernel_timing", 0)
+        ctx.set_option("ordered_scan", 1)
+        ref = ctx.index_and_search(irs, srs, isel, ssel)
+        for a, b in zip(got[0], ref[0]):
+            assert np.array_equal(a, b)
+        assert [(s["indexed"], s["searched"], s["shared"]) for s in got[1]] == [(s["indexed"], s["searched"], s["shared"]) for s in ref[1]]
+        tags, stats, info = got
+        assert info["n_chunks"] == chunks and info["kmers_indexed"] == kmers
+        by_name = {r["name"]: r for r in res}
+        for nme, tg, st in zip(sorted(scn.search_names), tags, stats):
+            o = by_name[nme]
+            assert (st["indexed"], st["searched"], st["shared"]) == (o["indexed"], o["searched"], o["shared"]), nme
+            pos = 0
+            for fa, _, reads, _ in scn.sets[nme]:
+                _, n, bits = util.read_bv(os.path.join(out_o, os.path.basename(fa) + "_in_" + scn.index_name + ".bv"))
+                assert np.array_equal(util.bools_from_bits(tg, pos + n)[pos:pos + n], util.bools_from_bits(bits, n)), (nme, fa)
+                pos += n
+
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_job_sparse_passes_match_oracle(tmp_path, seed):
     """a pass over a selection of a search set walks the list of its reads (kernels.hpp ActiveList: sel & ~tags, in order, re-made
