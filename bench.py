@@ -82,7 +82,7 @@ def parse_args():
     ap.add_argument("--ragged", default="50-150",
                     help="LO-HI: a second, untimed-from-the-headline leg on RAGGED sets (read lengths uniform in [LO, HI], same copy / mutation rules; "
                          "50-150 has the bases, k-mers and first-hit windows per read of the 100-bp sets) — one GPU only: the configs[1] step and the "
-                         "10-set matrix of configs[2], reported in detail.ragged; 'none' skips it")
+                         "10-set matrices of configs[2] and configs[3], reported in detail.ragged; 'none' skips it")
     ap.add_argument("--ragged-only", action="store_true", help="the headline step itself on ragged sets (A/B runs, profiles): value is then the ragged rate")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, meet at the barriers, print the line's launch fields and leave (no GPU work: the CPU test of the launch path)")
@@ -887,6 +887,17 @@ def main():
                     ragged_detail["matrix"] = {"error": f"{type(ex).__name__}: {ex}"}
             # (a rank whose import of another rank's set hangs ends itself from a watchdog thread: rank 0 prints the line first)
             matrix_detail = matrix_leg(args, ranks, n_m, note, fatal_hook=lambda msg: (emit({"error": msg}, matrix_c2), sys.stdout.flush()))
+            if (world == 1 and args.matrix_reads is None and n_m > 10_000_000 and parse_ragged(args.ragged) and isinstance(ragged_detail, dict)
+                    and "error" not in ragged_detail and matrix_detail and "error" not in matrix_detail):
+                # ... and the like-for-like matrix on ragged sets, too (detail.ragged.matrix_configs3): sets of this size have no query lists,
+                # their passes are the gather kernels' — where reads of many lengths cost more than their windows (MEASUREMENTS.md)
+                try:
+                    mr3 = matrix_leg(args, ranks, n_m, ragged=parse_ragged(args.ragged))
+                    if mr3:
+                        mr3["vs_fixed_length_total_s"] = round(mr3["total_s"] / matrix_detail["total_s"], 4)
+                    ragged_detail["matrix_configs3"] = mr3
+                except Exception as ex:
+                    ragged_detail["matrix_configs3"] = {"error": f"{type(ex).__name__}: {ex}"}
         except Exception as ex:   # the headline measured above must not be lost with this extra leg
             import traceback
             traceback.print_exc()
