@@ -12,4 +12,4 @@ def test_design_md_references_hold_their_symbols():
     bad, n = m.check("DESIGN.md")
     assert n >= 40, "DESIGN.md lost its file:line references"
     assert not bad, "stale references in DESIGN.md (python tools/doc_refs.py --fix): " + "; ".join(bad)
-    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) < 24 * 1024, "DESIGN.md is the mechanism only: measurements go to MEASUREMENTS.md"
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 15 * 1024, "DESIGN.md is the mechanism only: measurements go to MEASUREMENTS.md"

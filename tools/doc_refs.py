@@ -9,7 +9,16 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASES = ("", "commet_amd/csrc")          # a path is taken from the repo root, else from the library's source directory (DESIGN.md says so)
 REF = re.compile(r"`([A-Za-z_][\w:<>, ]*?)`\s*\(`([\w/.]+\.(?:hpp|h|hip|cpp|py|c)):(\d+)`\)")
+
+
+def resolve(path):
+    for b in BASES:
+        full = os.path.join(ROOT, b, path)
+        if os.path.exists(full):
+            return full
+    return None
 
 
 def _name(sym):
@@ -17,7 +26,7 @@ def _name(sym):
 
 
 def find_line(path, sym):
-    lines = open(os.path.join(ROOT, path), errors="replace").read().split("\n")
+    lines = open(resolve(path), errors="replace").read().split("\n")
     name = _name(sym)
     word = re.compile(r"\b" + re.escape(name) + r"\b")
     defs = [i for i, ln in enumerate(lines, 1) if word.search(ln) and re.search(r"(\bstruct\b|\bclass\b|\bconstexpr\b|\bdef \b|\binline\b|__global__|^\w[\w:<>\*& ]* \*?" + re.escape(name) + r"\()", ln)
@@ -34,8 +43,8 @@ def check(doc):
     bad = []
     for m in REF.finditer(text):
         sym, path, line = m.group(1), m.group(2), int(m.group(3))
-        full = os.path.join(ROOT, path)
-        if not os.path.exists(full):
+        full = resolve(path)
+        if full is None:
             bad.append(f"{path}: no such file ({sym})")
             continue
         lines = open(full, errors="replace").read().split("\n")
@@ -50,7 +59,7 @@ def fix(doc):
 
     def sub(m):
         sym, path = m.group(1), m.group(2)
-        if not os.path.exists(os.path.join(ROOT, path)):
+        if resolve(path) is None:
             return m.group(0)
         ln = find_line(path, sym)
         return m.group(0) if ln is None else m.group(0).replace(f"{path}:{m.group(3)}", f"{path}:{ln}")
