@@ -116,6 +116,10 @@ int commet_set_option(commet_ctx *c, const char *name, int64_t value)
         c->ordered_scan = (int) std::max<int64_t>(0, std::min<int64_t>(value, 2));
         return 0;
     }
+    if (!strcmp(name, "mask_split")) {
+        c->mask_split = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "tq_hit_cap")) {
         c->tq_hit_cap = (int) std::max<int64_t>(0, std::min<int64_t>(value, TQ_HIT_CAP));
         return 0;

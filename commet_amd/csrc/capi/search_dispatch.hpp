@@ -143,24 +143,37 @@ int launch_search_group(commet_ctx *c, const commet_readset *rs, int g, int gs, 
     fg.plane_words = c->plane_words;
     fg.g = g;
     if (gs == 8) {   // register masks, no LDS (group8_ok)
-        const dim3 grid((unsigned) (((al.ids ? n_launch : rs->n_reads) + 255) / 256)), block(256);
-        const int mw = mask_words(c, rs);   // mask words per strand and filter: 2, 3, 4, 6 or 8
-        KScope ks(c, "search_group8_kernel", c->stream);
-#define COMMET_G8(W, MW) COMMET_LAUNCH((search_group8_kernel<W, MW>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel, d_tags, d_counters, cstride, al, job_mask, job_tag_words)
-        if (c->k <= 32) {
-            if (mw == 2) COMMET_G8(uint32_t, 2);
-            else if (mw == 3) COMMET_G8(uint32_t, 3);
-            else if (mw == 4) COMMET_G8(uint32_t, 4);
-            else if (mw == 6) COMMET_G8(uint32_t, 6);
-            else COMMET_G8(uint32_t, 8);
-        } else {
-            if (mw == 2) COMMET_G8(uint64_t, 2);
-            else if (mw == 3) COMMET_G8(uint64_t, 3);
-            else if (mw == 4) COMMET_G8(uint64_t, 4);
-            else if (mw == 6) COMMET_G8(uint64_t, 6);
-            else COMMET_G8(uint64_t, 8);
-        }
+        const int mw_set = mask_words(c, rs);   // mask words per strand and filter: 2, 3, 4, 6 or 8
+        auto launch = [&](int mw, ActiveList l, uint64_t n_l) {
+            KScope ks(c, "search_group8_kernel", c->stream);
+            const dim3 grid((unsigned) (((l.ids ? n_l : rs->n_reads) + 255) / 256)), block(256);
+#define COMMET_G8(W, MW) COMMET_LAUNCH((search_group8_kernel<W, MW>), grid, block, 0, c->stream, rs->view(), fg, c->k, t_eff(c, rs), d_sel, d_tags, d_counters, cstride, l, job_mask, job_tag_words)
+            if (c->k <= 32) {
+                if (mw == 2) COMMET_G8(uint32_t, 2);
+                else if (mw == 3) COMMET_G8(uint32_t, 3);
+                else if (mw == 4) COMMET_G8(uint32_t, 4);
+                else if (mw == 6) COMMET_G8(uint32_t, 6);
+                else COMMET_G8(uint32_t, 8);
+            } else {
+                if (mw == 2) COMMET_G8(uint64_t, 2);
+                else if (mw == 3) COMMET_G8(uint64_t, 3);
+                else if (mw == 4) COMMET_G8(uint64_t, 4);
+                else if (mw == 6) COMMET_G8(uint64_t, 6);
+                else COMMET_G8(uint64_t, 8);
+            }
 #undef COMMET_G8
+        };
+        if (al.ids && al.ids == rs->d_len_order && rs->n_len_seg > 1 && !c->mask_split) {
+            // the set's reads in order of their window counts: every segment of the list with the narrowest masks its reads fit
+            // (three mask words cost 135 VGPRs and a fifth of the request rate of two; a 50-150-bp set has half its windows in
+            // reads that need two)
+            for (int sg = 0; sg < rs->n_len_seg; ++sg) {
+                const commet_readset::LenSeg &seg = rs->len_seg[sg];
+                launch(std::min(seg.mw, mw_set), ActiveList{rs->d_len_order + seg.start, rs->d_len_order + rs->n_reads + 1 + sg}, seg.count);
+            }
+        } else {
+            launch(mw_set, al, n_launch);
+        }
         HIP_OK(hipGetLastError());
         return 0;
     }
@@ -240,7 +253,7 @@ bool ordered_pass(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
         const uint64_t n_blocks = (rs->n_reads + LO_BLOCK - 1) / LO_BLOCK, entries = n_blocks * LO_CLASSES;
         const uint32_t nb = (uint32_t) ((entries + 4095) / 4096);
         uint32_t *ids = nullptr;
-        hipError_t e = dm_malloc((void **) &ids, (rs->n_reads + 1) * sizeof(uint32_t));
+        hipError_t e = dm_malloc((void **) &ids, (rs->n_reads + 8) * sizeof(uint32_t));   // (+ 1: the list's length; + 5: its segments')
         if (e == hipSuccess && c->lo_cnt_cap < entries + 1 + nb + 2) {
             (void) dm_free(c->d_lo_cnt);
             c->d_lo_cnt = nullptr, c->lo_cnt_cap = 0;
@@ -266,6 +279,37 @@ bool ordered_pass(commet_ctx *c, const commet_readset *rs, const uint64_t *d_sel
             (void) dm_free(ids);
             rs->len_order_failed = true;
             return false;
+        }
+        // where the classes of 64, 96, 128 and 192 windows and more end (class = 31 - windows / 8: tile_search.hpp, lo_class; after the
+        // scan cnt[class * n_blocks] = the class's first place in the list): the list's segments by mask width.  One read-back per
+        // set; a segment of few reads joins its wider neighbour
+        rs->n_len_seg = 0;
+        unsigned long long first[4] = {0, 0, 0, 0};
+        static const uint32_t cls[4] = {8, 16, 20, 24};
+        static const int width[5] = {8, 6, 4, 3, 2};
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; ++i)
+            ok = hipMemcpyAsync(&first[i], cnt + (uint64_t) cls[i] * n_blocks, sizeof first[i], hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (ok) {
+            const uint64_t bound[6] = {0, first[0], first[1], first[2], first[3], rs->n_reads};
+            const uint64_t few = c->ordered_scan == 2 ? 1 : 4096;
+            for (int i = 0; i < 5; ++i) {
+                const uint64_t a = bound[i], b = bound[i + 1];
+                if (b <= a || b > rs->n_reads) continue;
+                if (rs->n_len_seg > 0 && b - a < few)
+                    rs->len_seg[rs->n_len_seg - 1].count += (uint32_t) (b - a);
+                else
+                    rs->len_seg[rs->n_len_seg++] = commet_readset::LenSeg{(uint32_t) a, (uint32_t) (b - a), width[i]};
+            }
+            uint32_t counts[5] = {0, 0, 0, 0, 0};
+            for (int i = 0; i < rs->n_len_seg; ++i) counts[i] = rs->len_seg[i].count;
+            ok = hipMemcpyAsync(ids + rs->n_reads + 1, counts, sizeof counts, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                 hipStreamSynchronize(c->stream) == hipSuccess;       // (counts[] is on this stack)
+        }
+        if (!ok) {
+            (void) hipGetLastError();
+            rs->n_len_seg = 0;                                         // (the list itself is good: one launch at the set's width)
         }
         rs->d_len_order = ids;
     }

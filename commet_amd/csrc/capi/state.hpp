@@ -509,6 +509,7 @@ struct commet_ctx {
     int tq_hit_cap = TQ_HIT_CAP;      // option "tq_hit_cap" (tests): full hits a piece of the replay may post before its scans walk their own candidates
     int ordered_scan = 0;             // option "ordered_scan": 0 = ragged sets of 2^16 reads and more are walked in order of their window counts by the
                                       // gather kernels' first pass, 1 = never, 2 = whenever the set is ragged (tests)
+    int mask_split = 0;               // option "mask_split": 0 = a pass over that list runs segment by segment, each with the mask width its reads need, 1 = one launch
     unsigned long long *d_lo_cnt = nullptr;   // scratch of that list's counting sort (class-major block counts), kept
     uint64_t lo_cnt_cap = 0;
     int tiled_mode = 0;               // option "tiled_search": 0 auto (large sets, groups of 1 or 2 chunks), 1 never, 2 whenever possible
@@ -610,6 +611,12 @@ struct commet_readset {
     // of a gather kernel that visits the whole set; ids[n_reads] = n_reads closes the list
     mutable uint32_t *d_len_order = nullptr;
     mutable bool len_order_failed = false;
+    // ... cut by mask width (round 6): the list starts with the reads of most windows, so the register-mask kernel runs segment by
+    // segment with the narrowest masks the segment's reads fit (search_dispatch.hpp, launch_search_group); segment s = reads
+    // [start, start + count) of the list, its count also at d_len_order[n_reads + 1 + s] for the kernel
+    struct LenSeg { uint32_t start, count; int mw; };
+    mutable LenSeg len_seg[5];
+    mutable int n_len_seg = 0;
     mutable uint32_t ql_wanted = 0;                 // scans that would have taken the tiled search had the set's (large) list existed (tiled_ok)
     mutable std::atomic<uint64_t> ql_reserved_at{0};  // g_devmem.trims when the memory was set aside: a trim since then has given it back
     mutable std::atomic<bool> ql_reserved{false};   // the memory of the set's list waits in the library's device cache (commet_readset_reserve_cache): a list above the cap may be built

@@ -274,6 +274,8 @@ int commet_index_many_and_search(commet_ctx *ctx, int n_jobs, const commet_reads
  *   ordered_scan (0/1/2) ragged sets (reads of several lengths): the first pass of a gather kernel over a whole set walks its reads in
  *                        order of their first-hit window counts (a list made once per set: a workgroup lives as long as its longest
  *                        read, its other lanes idle meanwhile): 0 = sets of 2^16 reads and more, 1 = never, 2 = any ragged set (tests)
+ *   mask_split (0/1)     a pass of the register-mask gather kernel over that list: 0 = segment by segment, each launched with the
+ *                        narrowest masks its reads fit (the list starts with the reads of most windows), 1 = one launch at the set's width
  *   tq_hit_cap           TEST HOOK of the tiled search's replay: full hits a piece of 256 reads may post for its owners (default and
  *                        at most 1024; beyond it every scan of the piece walks its own candidates — same bits, slower); 0 forces that path
  *   tq_parts (1..16)     tiled search in parts, the replay of one beside the probe of the next (default 1: measured slower)

@@ -46,6 +46,7 @@ def fuzz_one(seed):
             # (round 6) ragged sets: hist / scatter1 on the chunk's item list, or — one seed in five — on the round planner
             ctx.set_option("part_list", int(seed % 5 == 3))
             ctx.set_option("ordered_scan", [2, 0, 1][seed % 3])      # (round 6) ragged search sets walked in order of their window counts on a job's first pass
+            ctx.set_option("mask_split", int(seed % 7 == 5))         # (round 6) ... segment by segment with the narrowest masks (0) or in one launch (1)
             if not counting and seed % 3 == 1:
                 ctx.set_option("sparse_search", 2)     # passes over a selection walk the list of their reads (kernels.hpp, ActiveList)
             if forced:

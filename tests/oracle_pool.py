@@ -72,3 +72,43 @@ def search_sample_over_chunks(scratch, tag, index_bases, L, chunks, k, t, sample
     if first_chunk:
         return found, [fed for fed, _ in res], first
     return found, [fed for fed, _ in res]
+
+
+def chunk_loop_in_threads(k, t, ib, io, qb, qo, chunks, n_q, workers=None):
+    """The reference's chunk loop (index_and_search.cpp:255-277) over `chunks` of the index batch (ib, io) for the query batch
+    (qb, qo), on the CPU checker, the chunks dealt to threads in contiguous runs (the checker is called through ctypes, which
+    releases the interpreter lock).  A read's tag is the OR of its per-chunk results and a read found by a chunk is merely skipped
+    afterwards, so every run may start from empty tags.  Returns (found bits uint8[n_q // 8 + 1], reads the LAST chunk searched =
+    the log line's "searched").  k >= 33: 4-8 GiB per filter, so four threads at most."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_binding as ob
+    chunks = list(chunks)
+    if workers is None:
+        workers = 4 if k >= 33 else 8
+    workers = max(1, min(workers, len(chunks)))
+    per = -(-len(chunks) // workers)
+    runs = [chunks[i: i + per] for i in range(0, len(chunks), per)]
+
+    def run(my, is_last):
+        found = np.zeros(n_q // 8 + 1, dtype=np.uint8)
+        before_last = None
+        for ci, (a, e) in enumerate(my):
+            if is_last and ci == len(my) - 1:
+                before_last = found.copy()
+            f = ob.Bloom(k)
+            f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
+            fnd, _ = f.search(t, qb, qo, ~found)
+            found |= fnd
+            f.close()
+        return found, before_last
+
+    with ThreadPoolExecutor(len(runs)) as pool:
+        res = list(pool.map(lambda a: run(*a), [(r, i == len(runs) - 1) for i, r in enumerate(runs)]))
+    found = np.zeros(n_q // 8 + 1, dtype=np.uint8)
+    seen_before_last = res[-1][1].copy()
+    for i, (f, _) in enumerate(res):
+        found |= f
+        if i < len(res) - 1:
+            seen_before_last |= f
+    pad = np.unpackbits(seen_before_last, bitorder="little")[:n_q]
+    return found, int(n_q - pad.sum())

@@ -181,22 +181,27 @@ def test_group8_instantiations_match_cpu_checker(k, t, L, max_kmer, n_idx, lo):
         for group in (8, 4, 1):
             ctx.set_option("chunk_group", group)
             res[group] = ctx.index_and_search(irs, [qrs])
+        if lo != L:
+            # ragged sets: the first pass walks the set's reads in order of their window counts, segment by segment with the
+            # narrowest masks a segment's reads fit (capi/search_dispatch.hpp, launch_search_group; `mask_split` 1 = one launch)
+            ctx.set_option("chunk_group", 8)
+            ctx.set_option("ordered_scan", 2)
+            launches = {}
+            for split_off in (0, 1):
+                ctx.set_option("mask_split", split_off)
+                ctx.set_option("kernel_timing", 1)
+                res["split" if not split_off else "whole"] = ctx.index_and_search(irs, [qrs])
+                launches[split_off] = ctx.kernel_times()["search_group8_kernel"][0]
+                ctx.set_option("kernel_timing", 0)
+            passes = (len(oracle_pool.chunks_from_counts(kc, max_kmer or ob.max_kmer(k))) + 7) // 8
+            assert launches[1] == passes and launches[0] >= passes + 2, launches     # the first pass ran in three segments or more
     chunks = oracle_pool.chunks_from_counts(kc, max_kmer or ob.max_kmer(k))
     assert len(chunks) > 4
     tags, stats, info = res[8]
     assert info["n_chunks"] == len(chunks)
     assert info["search_launches"] == (len(chunks) + 7) // 8               # the eight-filter kernel did run
-    found = np.zeros(len(q_reads) // 8 + 1, dtype=np.uint8)
-    searched_last = 0
-    for (a, e) in chunks:
-        f = ob.Bloom(k)
-        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
-        active = ~found
-        searched_last = int(util.bools_from_bits(active, len(q_reads)).sum())
-        fnd, _ = f.search(t, qb, qo, active)
-        found |= fnd
-        f.close()
-    for group in (8, 4, 1):
+    found, searched_last = oracle_pool.chunk_loop_in_threads(k, t, ib, io, qb, qo, chunks, len(q_reads))
+    for group in res:
         tg, sg, _ = res[group]
         assert np.array_equal(tg[0], found), group
         assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
@@ -288,16 +293,7 @@ def test_wide_rows_instantiations_match_cpu_checker(k, t, L, n_chunks, cap_words
     nw = -(-groups // passes) * 8
     pieces = nw // 4
     assert inst == f"{8 if pieces <= 8 else 16 if pieces <= 16 else 32 if pieces <= 32 else 64}x{1 if pieces <= 64 else 2}"
-    found = np.zeros(len(q_reads) // 8 + 1, dtype=np.uint8)
-    searched_last = 0
-    for (a, e) in chunks:
-        f = ob.Bloom(k)
-        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
-        active = ~found
-        searched_last = int(util.bools_from_bits(active, len(q_reads)).sum())
-        fnd, _ = f.search(t, qb, qo, active)
-        found |= fnd
-        f.close()
+    found, searched_last = oracle_pool.chunk_loop_in_threads(k, t, ib, io, qb, qo, chunks, len(q_reads))
     for tg, sg in ((tags, stats), (narrow[0], narrow[1])):
         assert np.array_equal(tg[0], found)
         assert sg[0]["shared"] == int(util.bools_from_bits(found, len(q_reads)).sum())
@@ -309,17 +305,7 @@ def test_wide_rows_instantiations_match_cpu_checker(k, t, L, n_chunks, cap_words
 # instantiations the randomised scenarios do not reach (tests/test_gpu_zz_dispatch_coverage.py keeps the list honest)
 # ---------------------------------------------------------------------------------------------------------------
 def _chunk_loop_on_cpu_checker(k, t, ib, io, qb, qo, chunks, n_q):
-    found = np.zeros(n_q // 8 + 1, dtype=np.uint8)
-    searched_last = 0
-    for (a, e) in chunks:
-        f = ob.Bloom(k)
-        f.index(ib[int(io[a]): int(io[e])], io[a: e + 1] - io[a])
-        active = ~found
-        searched_last = int(util.bools_from_bits(active, n_q).sum())
-        fnd, _ = f.search(t, qb, qo, active)
-        found |= fnd
-        f.close()
-    return found, searched_last
+    return oracle_pool.chunk_loop_in_threads(k, t, ib, io, qb, qo, chunks, n_q)
 
 
 @pytest.mark.parametrize("k,t,L,max_kmer,group", [(33, 2, 100, 40000, 2), (34, 2, 110, 30000, 4)])
